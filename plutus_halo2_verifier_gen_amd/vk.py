@@ -1,0 +1,356 @@
+"""VerifyingKey surface for the Halo2/KZG (BLS12-381) verification hot path.
+
+Mirrors what the reference reads out of `midnight_proofs::plonk::VerifyingKey` + `ParamsVerifierKZG`
+when it builds a verifier:
+  * InstantiationSpecificData  /root/reference/src/plutus_gen/extraction/data/circuit_types/instantiation_data.rs:26-41
+    (fixed/permutation commitments, omega, omega^-1, n^-1, s_g2, n, blinding_factors, transcript_repr,
+    public-input count, committed-instance flags); rendered at aiken-verifier/templates/vk_constants.hbs:8-27
+  * the ConstraintSystem pieces `extract_circuit` walks (src/plutus_gen/extraction/mod.rs:31-232): query lists,
+    gate polynomials, lookup (input, table) expressions, trashcans, permutation columns, degree.
+
+Expressions are nested tuples with the semantics of `Expression<Scalar>` as transpiled at
+src/plutus_gen/extraction/data/languages/aiken.rs:122-182:
+  ("const", int) | ("fixed", query_idx) | ("advice", query_idx) | ("neg", e) | ("sum", a, b) |
+  ("prod", a, b) | ("scaled", e, int)          (query indices are 0-based here; Selector/Instance/Challenge
+                                                 are unsupported by the reference and by this build)
+"""
+from __future__ import annotations
+
+import json
+import random
+from dataclasses import dataclass, field, asdict
+from typing import List, Optional, Tuple
+
+from . import bls12_381 as bls
+
+# Fr multiplicative generator 7, two-adicity 32: ROOT_OF_UNITY = 7^((r-1)/2^32); delta = 7^(2^32)
+TWO_ADICITY = 32
+ROOT_OF_UNITY = pow(7, (bls.R - 1) >> TWO_ADICITY, bls.R)
+
+ROT_CUR, ROT_NEXT, ROT_PREV = 0, 1, -1
+
+
+def domain_omega(k: int) -> int:
+    w = ROOT_OF_UNITY
+    for _ in range(TWO_ADICITY - k):
+        w = w * w % bls.R
+    return w
+
+
+@dataclass
+class VerifyingKey:
+    name: str
+    k: int
+    blinding_factors: int
+    cs_degree: int
+    transcript_repr: int
+    num_advice_columns: int
+    num_fixed_columns: int
+    advice_queries: List[Tuple[int, int]]  # (column, rotation)
+    fixed_queries: List[Tuple[int, int]]
+    instance_queries: List[Tuple[int, int]]
+    gates: list  # list of polynomial expressions (flattened over gates)
+    lookups: list  # list of (input_exprs, table_exprs)
+    trashcans: list  # list of (selector_expr, constraint_exprs)
+    permutation_columns: List[Tuple[str, int]]  # ("advice"|"fixed"|"instance", column index)
+    fixed_commitments: List[str]  # hex of 48-byte compressed G1
+    permutation_commitments: List[str]
+    s_g2: str  # hex of 96-byte compressed G2
+    n_public_inputs: int
+    n_committed_instances: int = 0  # 0 or 1
+
+    # ---- derived (instantiation_data.rs:84-103)
+    @property
+    def n(self) -> int:
+        return 1 << self.k
+
+    @property
+    def omega(self) -> int:
+        return domain_omega(self.k)
+
+    @property
+    def omega_inv(self) -> int:
+        return bls.fr_inv(self.omega)
+
+    @property
+    def barycentric_weight(self) -> int:
+        return bls.fr_inv(self.n)
+
+    @property
+    def chunk_len(self) -> int:
+        return self.cs_degree - 2
+
+    @property
+    def n_perm_chunks(self) -> int:
+        c = len(self.permutation_columns)
+        return (c + self.chunk_len - 1) // self.chunk_len
+
+    @property
+    def quotient_poly_degree(self) -> int:
+        return self.cs_degree - 1
+
+    def to_json(self) -> str:
+        return json.dumps(asdict(self))
+
+    @staticmethod
+    def from_json(s: str) -> "VerifyingKey":
+        d = json.loads(s)
+
+        def tup(e):
+            if isinstance(e, list):
+                return tuple(tup(x) for x in e)
+            return e
+
+        d["advice_queries"] = [tuple(q) for q in d["advice_queries"]]
+        d["fixed_queries"] = [tuple(q) for q in d["fixed_queries"]]
+        d["instance_queries"] = [tuple(q) for q in d["instance_queries"]]
+        d["gates"] = [tup(g) for g in d["gates"]]
+        d["lookups"] = [([tup(e) for e in i], [tup(e) for e in t]) for i, t in d["lookups"]]
+        d["trashcans"] = [(tup(s), [tup(e) for e in c]) for s, c in d["trashcans"]]
+        d["permutation_columns"] = [tuple(c) for c in d["permutation_columns"]]
+        return VerifyingKey(**d)
+
+
+@dataclass
+class Trapdoor:
+    """Test-SRS secret + discrete logs of the VK commitments (synthetic workloads only)."""
+    s: int
+    fixed_dlogs: List[int] = field(default_factory=list)
+    perm_dlogs: List[int] = field(default_factory=list)
+
+
+# ----------------------------------------------------------------------------- expression helpers
+def const(c):
+    return ("const", c % bls.R)
+
+
+def fixed(q):
+    return ("fixed", q)
+
+
+def advice(q):
+    return ("advice", q)
+
+
+def neg(e):
+    return ("neg", e)
+
+
+def add(a, b):
+    return ("sum", a, b)
+
+
+def mul(a, b):
+    return ("prod", a, b)
+
+
+def sub(a, b):
+    return ("sum", a, ("neg", b))
+
+
+def scaled(e, c):
+    return ("scaled", e, c % bls.R)
+
+
+def expr_degree(e) -> int:
+    t = e[0]
+    if t == "const":
+        return 0
+    if t in ("fixed", "advice"):
+        return 1
+    if t in ("neg", "scaled"):
+        return expr_degree(e[1])
+    if t == "sum":
+        return max(expr_degree(e[1]), expr_degree(e[2]))
+    if t == "prod":
+        return expr_degree(e[1]) + expr_degree(e[2])
+    raise ValueError(t)
+
+
+def expr_op_counts(e, acc=None):
+    acc = acc if acc is not None else {"neg": 0, "add": 0, "mul": 0, "const": 0}
+    t = e[0]
+    if t == "const":
+        acc["const"] += 1
+    elif t == "neg":
+        acc["neg"] += 1
+        expr_op_counts(e[1], acc)
+    elif t == "scaled":
+        acc["mul"] += 1
+        expr_op_counts(e[1], acc)
+    elif t == "sum":
+        acc["add"] += 1
+        expr_op_counts(e[1], acc)
+        expr_op_counts(e[2], acc)
+    elif t == "prod":
+        acc["mul"] += 1
+        expr_op_counts(e[1], acc)
+        expr_op_counts(e[2], acc)
+    return acc
+
+
+# ----------------------------------------------------------------------------- VK builders
+def _commitments(rng: random.Random, count: int):
+    dlogs = [rng.randrange(1, bls.R) for _ in range(count)]
+    return dlogs, [bls.g1_compress(bls.g1_mul(bls.G1_GEN, d)).hex() for d in dlogs]
+
+
+def _finish(name, rng, k, bf, degree, n_adv, n_fix, aq, fq, iq, gates, lookups, trash, perm_cols, n_pi, n_ci,
+            transcript_repr=None):
+    s = rng.randrange(2, bls.R)
+    fd, fc = _commitments(rng, n_fix)
+    pd, pc = _commitments(rng, len(perm_cols))
+    vk = VerifyingKey(
+        name=name, k=k, blinding_factors=bf, cs_degree=degree,
+        transcript_repr=transcript_repr if transcript_repr is not None else rng.randrange(bls.R),
+        num_advice_columns=n_adv, num_fixed_columns=n_fix,
+        advice_queries=aq, fixed_queries=fq, instance_queries=iq,
+        gates=gates, lookups=lookups, trashcans=trash, permutation_columns=perm_cols,
+        fixed_commitments=fc, permutation_commitments=pc,
+        s_g2=bls.g2_compress(bls.g2_mul(bls.G2_GEN, s)).hex(),
+        n_public_inputs=n_pi, n_committed_instances=n_ci,
+    )
+    return vk, Trapdoor(s=s, fixed_dlogs=fd, perm_dlogs=pd)
+
+
+def simple_mul_vk(seed: int = 0x48325631):
+    """simple_mul circuit shape (/root/reference/src/circuits/simple_mul_circuit.rs:42-60, :144-159):
+    2 advice columns (a0 queried at cur and next, a1 at cur), fixed = constant column + compressed selector,
+    gate s_mul * (a0*a1 - a0_next), permutation over [constant, a0, a1] (degree 3 => chunk_len 1 => 3 chunks),
+    instance column declared but never queried; 3 public inputs (examples/simple_mul.rs:68)."""
+    rng = random.Random(seed)
+    aq = [(0, 0), (1, 0), (0, 1)]
+    fq = [(0, 0), (1, 0)]
+    gate = mul(fixed(1), sub(mul(advice(0), advice(1)), advice(2)))
+    return _finish(
+        "simple_mul", rng, k=4, bf=5, degree=3, n_adv=2, n_fix=2, aq=aq, fq=fq, iq=[],
+        gates=[gate], lookups=[], trash=[], perm_cols=[("fixed", 0), ("advice", 0), ("advice", 1)],
+        n_pi=3, n_ci=0,
+        transcript_repr=0x53772FDA8C4D27D16E6D1B3B0ED0F0C492414695F8050480AAEB9F0C1257BC6B,
+    )
+
+
+def lookup_table_vk(seed: int = 0x48325632):
+    """lookup_table circuit shape (/root/reference/src/circuits/lookup_table_circuit.rs:42-78): 4 advice value
+    columns with equality, fixed = tag, complex selector, 2 table columns; no gates; 4 lookup arguments
+    [(tag, t_tag), (sel*val, t_val)] => lookup degree 5, chunk_len 3, 2 permutation chunks, 4 h-splits."""
+    rng = random.Random(seed)
+    aq = [(c, 0) for c in range(4)]
+    fq = [(0, 0), (1, 0), (2, 0), (3, 0)]  # tag, selector, t_tag, t_val
+    lookups = [([fixed(0), mul(fixed(1), advice(c))], [fixed(2), fixed(3)]) for c in range(4)]
+    return _finish(
+        "lookup_table", rng, k=6, bf=5, degree=5, n_adv=4, n_fix=4, aq=aq, fq=fq, iq=[],
+        gates=[], lookups=lookups, trash=[], perm_cols=[("advice", c) for c in range(4)], n_pi=1, n_ci=0,
+    )
+
+
+def _random_expr(rng, n_adv_q, n_fix_q, n_mul, n_add, n_neg, max_degree):
+    """Random expression with exactly the requested op counts (products limited by max_degree by pairing
+    a fresh leaf with each multiplication above the degree cap: Scaled keeps degree)."""
+    def leaf():
+        c = rng.random()
+        if c < 0.55:
+            return advice(rng.randrange(n_adv_q))
+        if c < 0.9 and n_fix_q:
+            return fixed(rng.randrange(n_fix_q))
+        return const(rng.randrange(bls.R))
+
+    e = leaf()
+    ops = ["m"] * n_mul + ["a"] * n_add + ["n"] * n_neg
+    rng.shuffle(ops)
+    for op in ops:
+        if op == "n":
+            e = neg(e)
+        elif op == "a":
+            e = add(e, leaf()) if rng.random() < 0.5 else add(leaf(), e)
+        else:
+            if expr_degree(e) + 1 <= max_degree:
+                e = mul(e, leaf()) if rng.random() < 0.5 else mul(leaf(), e)
+            else:
+                e = scaled(e, rng.randrange(bls.R))
+    return e
+
+
+def _split_counts(rng, total, parts):
+    cuts = sorted(rng.randrange(total + 1) for _ in range(parts - 1))
+    prev = 0
+    out = []
+    for c in cuts + [total]:
+        out.append(c - prev)
+        prev = c
+    return out
+
+
+def _shaped_vk(name, seed, *, k, degree, n_adv, n_fix, n_cc, lookup_arg_exprs, gate_exprs, gate_ops,
+               adv_rot_sets, n_pi, n_ci, bf=6):
+    """Shape-faithful synthetic VK for circuits whose real VK cannot be extracted offline
+    (needs keygen_vk; SURVEY.md §7 'Hard parts').  adv_rot_sets: per advice column the rotations queried."""
+    rng = random.Random(seed)
+    aq = []
+    for col, rots in enumerate(adv_rot_sets):
+        for r in rots:
+            aq.append((col, r))
+    fq = [(c, 0) for c in range(n_fix)]
+    iq = []
+    if n_ci:
+        iq.append((0, 0))
+        iq.append((1, 0))
+    else:
+        iq.append((0, 0))
+    muls = _split_counts(rng, gate_ops["mul"], gate_exprs)
+    adds = _split_counts(rng, gate_ops["add"], gate_exprs)
+    negs = _split_counts(rng, gate_ops["neg"], gate_exprs)
+    gates = [_random_expr(rng, len(aq), len(fq), muls[i], adds[i], negs[i], degree) for i in range(gate_exprs)]
+    lookups = []
+    for n_e in lookup_arg_exprs:
+        ins = [_random_expr(rng, len(aq), len(fq), 1, 1, 0, 2) for _ in range(n_e)]
+        tabs = [fixed(rng.randrange(len(fq))) for _ in range(n_e)]
+        lookups.append((ins, tabs))
+    # permutation columns: advice columns first (all queried at cur), then fixed, then the instance columns
+    perm_cols = []
+    cur_adv = [c for c, rots in enumerate(adv_rot_sets) if 0 in rots]
+    for c in cur_adv[: max(0, n_cc - 1)]:
+        perm_cols.append(("advice", c))
+    while len(perm_cols) < n_cc - 1:
+        perm_cols.append(("fixed", len(perm_cols) % n_fix))
+    perm_cols.append(("instance", 1 if n_ci else 0))
+    return _finish(name, rng, k=k, bf=bf, degree=degree, n_adv=n_adv, n_fix=n_fix, aq=aq, fq=fq, iq=iq,
+                   gates=gates, lookups=lookups, trash=[], perm_cols=perm_cols, n_pi=n_pi, n_ci=n_ci)
+
+
+def atms_with_lookups_vk(seed: int = 0x48325633):
+    """ATMS + lookup shape: 11 advice / 21 fixed evaluations, 5 gate polynomials, 1 lookup argument
+    (/root/reference/aiken-verifier/templates/gates_test.hbs:27-59, src/circuits/atms_with_lookups_circuit.rs:36)."""
+    adv = [[0, 1]] * 4 + [[0]] * 3  # 7 columns, 11 queries
+    return _shaped_vk("atms_with_lookups", seed, k=14, degree=5, n_adv=7, n_fix=21, n_cc=8,
+                      lookup_arg_exprs=[2], gate_exprs=5,
+                      gate_ops={"mul": 60, "add": 50, "neg": 10}, adv_rot_sets=adv, n_pi=2, n_ci=0)
+
+
+def sha256_vk(seed: int = 0x48325634):
+    """sha256-chip shape (/root/reference/docs/chip_profiles.json "sha256"; examples/sha256.rs:42,133): 8 advice,
+    25 fixed, 7 copy-constraint columns, 2 lookup arguments (6 expressions), 22 gate expressions
+    (156 mul / 173 add / 22 neg), degree 5, committed instance column (= identity in the example), 32 public
+    inputs, commitment-map set sizes [36,3,2,2,8]."""
+    adv = [[0, 1, -1]] * 2 + [[0, 1]] * 1 + [[0]] * 5
+    return _shaped_vk("sha256", seed, k=17, degree=5, n_adv=8, n_fix=25, n_cc=7,
+                      lookup_arg_exprs=[3, 3], gate_exprs=22,
+                      gate_ops={"mul": 156, "add": 173, "neg": 22}, adv_rot_sets=adv, n_pi=32, n_ci=1)
+
+
+def secp256k1_vk(seed: int = 0x48325635):
+    """secp256k1 foreign-field chip shape (docs/chip_profiles.json "secp256k1"): 9 advice, 23 fixed, 10 copy-
+    constraint columns, 1 lookup argument (10 expressions), 22 gate expressions (641 mul / 476 add / 67 neg)."""
+    adv = [[0, 1, -1]] * 2 + [[0, 1]] * 2 + [[0]] * 5
+    return _shaped_vk("secp256k1", seed, k=17, degree=5, n_adv=9, n_fix=23, n_cc=10,
+                      lookup_arg_exprs=[10], gate_exprs=22,
+                      gate_ops={"mul": 641, "add": 476, "neg": 67}, adv_rot_sets=adv, n_pi=4, n_ci=1)
+
+
+BUILDERS = {
+    "simple_mul": simple_mul_vk,
+    "lookup_table": lookup_table_vk,
+    "atms_with_lookups": atms_with_lookups_vk,
+    "sha256": sha256_vk,
+    "secp256k1": secp256k1_vk,
+}
