@@ -1,0 +1,828 @@
+"""Verifier-plan compiler: VerifyingKey -> flat binary "plan" consumed by the HIP backend.
+
+This is the MI355X-side counterpart of the reference's plan-time layer `extract_circuit`
+(/root/reference/src/plutus_gen/extraction/mod.rs:31-232): where the reference walks the VK once and emits
+Plinth/Aiken *source text* for the verifier, this compiler walks the same data once and emits
+
+  * a straight-line, branch-free bytecode program over an Fr register file (transcript replay P1-P2 +
+    Fr combiner P3-P6 of SURVEY.md §3.2) that every GPU lane executes in lock-step for its own proof,
+  * the static proof-point table (byte offset of every G1 in the proof) for the decompression kernel,
+  * the flattened final-MSM term table  er = sum_t s_t * B_t  (SURVEY.md App. A.3),
+  * device-ready constants: Fr constant pool, VK bases (affine, Montgomery limbs), and the precomputed
+    optimal-ate line tables of the two FIXED G2 pairing arguments s_g2 and G2.
+
+Reference definitions followed (same order, same formulas):
+  proof layout        src/plutus_gen/extraction/data/extraction_steps/proof.rs:13-143, pcs/kzg.rs:55-79
+  inputs/absorbs      src/plutus_gen/emitters/aiken.rs:44-84
+  instance eval       emitters/aiken.rs:200-223
+  lagrange basis      aiken-verifier/aiken_halo2/lib/lagrange.ak:79-96
+  gates/lookups       emitters/aiken.rs:248-330, extraction/data/languages/aiken.rs:18-29,122-182
+  permutation         extraction/data/extraction_steps/permutation.rs:80-303, emitters/aiken.rs:332-441
+  trashcans           emitters/aiken.rs:444-461
+  hEval / vanishing   emitters/aiken.rs:463-575, aiken-verifier/templates/verification_h2.hbs:85-96,
+                      extraction/data/extraction_steps/vanishing.rs:6-52
+  queries / sets      extraction/mod.rs:120-226, extraction/pcs/mod.rs:36-109, emitters/aiken.rs:580-587
+  multi-open          aiken-verifier/aiken_halo2/lib/halo2_kzg.ak:15-171, lagrange.ak:40-77
+
+All field inversions of one proof depend only on the challenges x and x3, so they are gathered into ONE
+Montgomery-trick batch with a single INV instruction.  The reference rejects (recip_eea divides by zero,
+bls_utils.ak:151-154) iff any inverted value is zero; the product of the merged batch is zero under exactly
+the same condition, so accept/reject is unchanged.  (Only deviation: the interpolation denominators are taken
+as x^(m-1)*prod(w^a - w^b), which differs from lagrange.ak's value-comparison skip only when x == 0.)
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+from . import bls12_381 as bls
+from .vk import VerifyingKey
+
+R = bls.R
+
+# ---- opcodes (mirrored in csrc/h2v_plan.h)
+OP_END, OP_ABSORB_REG, OP_ABSORB_CI, OP_LOAD_INSTANCE, OP_READ_POINT, OP_READ_SCALAR, OP_SQUEEZE, OP_CONST, \
+    OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_INV, OP_OUT_SCALAR = range(14)
+OP_NAMES = ["END", "ABSORB_REG", "ABSORB_CI", "LOAD_INSTANCE", "READ_POINT", "READ_SCALAR", "SQUEEZE", "CONST",
+            "ADD", "SUB", "MUL", "NEG", "INV", "OUT_SCALAR"]
+
+# ---- MSM term kinds
+TERM_PROOF_POINT, TERM_VK_BASE, TERM_COMMITTED_INSTANCE = 0, 1, 2
+
+# ---- trace slots (same order as the oracle's trace struct; expressions start at TRACE_EXPR0)
+TRACE_NAMES = ["theta", "beta", "gamma", "trash", "y", "x", "x1", "x2", "x3", "x4", "x_prev", "x_next", "x_last", "xn",
+               "l_last", "l_0", "active_rows", "h_eval", "vanishing_s", "f_eval", "v"]
+TRACE_EXPR0 = 32
+MAX_TRACE_EXPR = 256
+
+MILLER_LINES = 68
+PLAN_MAGIC = b"H2VPLAN1"
+PLAN_VERSION = 1
+
+ROT_LAST = "last"  # rotation key of x_last = w^-(bf+1) x
+
+
+@dataclass
+class Plan:
+    vk_name: str
+    proof_len: int
+    n_pi: int
+    n_ci: int
+    n_regs: int
+    instrs: List[Tuple[int, int, int, int]]  # (op, dst, a, b)
+    consts: List[int]
+    points: List[int]  # proof byte offset of each G1 read from the proof, in read order
+    point_names: List[str]
+    vk_bases: List[Optional[Tuple[int, int]]]  # affine points
+    terms: List[Tuple[int, int]]  # (kind, index)
+    term_names: List[str]
+    pi_point: int
+    lines_sg2: list
+    lines_g2: list
+    trace: List[Tuple[int, int]]  # (slot id, register)
+    n_squeezes: int = 0
+    stream_len: int = 0  # bytes hashed by the transcript
+
+    @property
+    def n_terms(self) -> int:
+        return len(self.terms)
+
+    def to_bytes(self) -> bytes:
+        def pad8(b: bytearray):
+            while len(b) % 8:
+                b.append(0)
+
+        body = bytearray()
+        offs = {}
+
+        def section(name, data: bytes):
+            pad8(body)
+            offs[name] = len(body)
+            body.extend(data)
+
+        section("instr", b"".join(struct.pack("<BBHHH", op, 0, d, a, b) for op, d, a, b in self.instrs))
+        section("consts", b"".join(bls.fr_mont_bytes(c) for c in self.consts))
+        section("points", b"".join(struct.pack("<I", o) for o in self.points))
+        vb = bytearray()
+        for p in self.vk_bases:
+            vb += bytes(96) if p is None else bls.fp_mont_bytes(p[0]) + bls.fp_mont_bytes(p[1])
+        section("vk_bases", bytes(vb))
+        section("terms", b"".join(struct.pack("<II", k, i) for k, i in self.terms))
+        for name, tab in (("lines_sg2", self.lines_sg2), ("lines_g2", self.lines_g2)):
+            assert len(tab) == MILLER_LINES
+            section(name, b"".join(bls.f2_mont_bytes(lam) + bls.f2_mont_bytes(c) for lam, c in tab))
+        section("trace", b"".join(struct.pack("<II", s, r) for s, r in self.trace))
+        pad8(body)
+        hdr_len = 8 + 4 * 24
+        fields = [PLAN_VERSION, self.proof_len, self.n_pi, self.n_ci, self.n_regs, len(self.instrs), len(self.consts),
+                  len(self.points), len(self.vk_bases), len(self.terms), len(self.trace), self.pi_point,
+                  self.n_squeezes, self.stream_len]
+        sect = [hdr_len + offs[k] for k in ("instr", "consts", "points", "vk_bases", "terms", "lines_sg2", "lines_g2",
+                                            "trace")]
+        fields += sect + [hdr_len + len(body)]
+        fields += [0] * (24 - len(fields))
+        return PLAN_MAGIC + struct.pack("<24I", *fields) + bytes(body)
+
+
+class _Builder:
+    """Straight-line program builder over virtual registers with hash-consing of pure operations."""
+
+    def __init__(self):
+        self.code: List[List[int]] = []  # [op, dst, a, b] on virtual registers
+        self.n_virt = 0
+        self.consts: List[int] = []
+        self.const_idx: Dict[int, int] = {}
+        self.cse: Dict[tuple, int] = {}
+        self.const_reg: Dict[int, int] = {}
+        self.value_of_const_reg: Dict[int, int] = {}
+
+    def new(self) -> int:
+        self.n_virt += 1
+        return self.n_virt - 1
+
+    def emit(self, op, dst=0, a=0, b=0):
+        self.code.append([op, dst, a, b])
+
+    def const(self, v: int) -> int:
+        v %= R
+        if v in self.const_reg:
+            return self.const_reg[v]
+        if v not in self.const_idx:
+            self.const_idx[v] = len(self.consts)
+            self.consts.append(v)
+        r = self.new()
+        self.emit(OP_CONST, r, self.const_idx[v], 0)
+        self.const_reg[v] = r
+        self.value_of_const_reg[r] = v
+        return r
+
+    def _pure(self, op, a, b=0, commutative=False):
+        key = (op, min(a, b), max(a, b)) if commutative else (op, a, b)
+        if key in self.cse:
+            return self.cse[key]
+        r = self.new()
+        self.emit(op, r, a, b)
+        self.cse[key] = r
+        return r
+
+    def add(self, a, b):
+        return self._pure(OP_ADD, a, b, True)
+
+    def sub(self, a, b):
+        return self._pure(OP_SUB, a, b)
+
+    def mul(self, a, b):
+        return self._pure(OP_MUL, a, b, True)
+
+    def neg(self, a):
+        return self._pure(OP_NEG, a)
+
+    def inv(self, a):
+        return self._pure(OP_INV, a)
+
+    def batch_inverse(self, regs: List[int]) -> List[int]:
+        """Montgomery trick: len-1 + 1 INV + 2(len-1) multiplications; zero anywhere => INV of zero => reject."""
+        if not regs:
+            return []
+        pre = [regs[0]]
+        for r in regs[1:]:
+            pre.append(self.mul(pre[-1], r))
+        inv = self.inv(pre[-1])
+        out = [0] * len(regs)
+        for i in range(len(regs) - 1, 0, -1):
+            out[i] = self.mul(inv, pre[i - 1])
+            inv = self.mul(inv, regs[i])
+        out[0] = inv
+        return out
+
+
+def _rot_value(vk: VerifyingKey, rot) -> int:
+    """omega^rotation as a constant."""
+    n = -(vk.blinding_factors + 1) if rot == ROT_LAST else rot
+    return pow(vk.omega, n, R) if n >= 0 else pow(vk.omega_inv, -n, R)
+
+
+def _rot_sort_key(rot):
+    # RotationDescription derive(Ord): Last < Previous < Current < Next < Custom(n)   (rotation_description.rs:14-24)
+    if rot == ROT_LAST:
+        return (0, 0)
+    if rot == -1:
+        return (1, 0)
+    if rot == 0:
+        return (2, 0)
+    if rot == 1:
+        return (3, 0)
+    return (4, rot)
+
+
+def compile_plan(vk: VerifyingKey) -> Plan:
+    b = _Builder()
+    L = len(vk.lookups)
+    Cn = vk.n_perm_chunks
+    n_trash = len(vk.trashcans)
+    n_splits = vk.quotient_poly_degree
+    n_ci = vk.n_committed_instances
+    assert n_ci in (0, 1)
+    assert len(vk.permutation_commitments) == len(vk.permutation_columns) > 0
+    assert vk.cs_degree >= 3
+
+    pos = 0
+    points: List[int] = []
+    point_names: List[str] = []
+    n_squeezes = 0
+    stream_len = 0
+
+    def read_point(name) -> int:
+        nonlocal pos, stream_len
+        idx = len(points)
+        points.append(pos)
+        point_names.append(name)
+        b.emit(OP_READ_POINT, 0, pos & 0xFFFF, pos >> 16)
+        pos += 48
+        stream_len += 49
+        return idx
+
+    def read_scalar() -> int:
+        nonlocal pos, stream_len
+        r = b.new()
+        b.emit(OP_READ_SCALAR, r, pos & 0xFFFF, pos >> 16)
+        pos += 32
+        stream_len += 33
+        return r
+
+    def squeeze() -> int:
+        nonlocal n_squeezes, stream_len
+        r = b.new()
+        b.emit(OP_SQUEEZE, r)
+        n_squeezes += 1
+        stream_len += 1
+        return r
+
+    def absorb(reg):
+        nonlocal stream_len
+        b.emit(OP_ABSORB_REG, 0, reg, 0)
+        stream_len += 33
+
+    one = b.const(1)
+    zero = b.const(0)
+
+    # ---- P1: transcript init + inputs (verification_h2.hbs:26-28, aiken.rs:44-84)
+    absorb(b.const(vk.transcript_repr))
+    if n_ci:
+        b.emit(OP_ABSORB_CI)
+        stream_len += 49
+    absorb(b.const(vk.n_public_inputs))
+    pis = []
+    for k in range(vk.n_public_inputs):
+        r = b.new()
+        b.emit(OP_LOAD_INSTANCE, r, k, 0)
+        absorb(r)
+        pis.append(r)
+
+    # ---- P2: proof read order (proof.rs:13-143)
+    adv_pts = [read_point("a%d" % (i + 1)) for i in range(vk.num_advice_columns)]
+    theta = squeeze()
+    lk_pin, lk_ptab = [], []
+    for i in range(L):
+        lk_pin.append(read_point("permuted_input_%d" % (i + 1)))
+        lk_ptab.append(read_point("permuted_table_%d" % (i + 1)))
+    beta = squeeze()
+    gamma = squeeze()
+    perm_pts = [read_point("permutations_committed_%s" % chr(ord("a") + i)) for i in range(Cn)]
+    lk_prod = [read_point("lookup_commitment_%d" % (i + 1)) for i in range(L)]
+    trash = squeeze()
+    trash_pts = [read_point("trashcan_commitment_%d" % (i + 1)) for i in range(n_trash)]
+    vanish_rand_pt = read_point("vanishing_rand")
+    y = squeeze()
+    split_pts = [read_point("vanishing_split_%d" % (i + 1)) for i in range(n_splits)]
+    x = squeeze()
+    # xn_minus_one = x^(n-1), xn = xn_minus_one * x  (aiken.rs:124-136); n = 2^k
+    acc = one
+    for _ in range(vk.k):
+        acc = b.mul(b.mul(acc, acc), x)
+    xn_minus_one = acc
+    xn = b.mul(xn_minus_one, x)
+
+    # instance evaluations: committed columns are read now, public ones are computed after the batch inversion
+    instance_eval: List[Optional[int]] = []
+    for (col, _rot) in vk.instance_queries:
+        if col < n_ci:
+            instance_eval.append(read_scalar())
+        else:
+            instance_eval.append(None)
+    advice_eval = [read_scalar() for _ in vk.advice_queries]
+    fixed_eval = [read_scalar() for _ in vk.fixed_queries]
+    random_eval = read_scalar()
+    perm_common = [read_scalar() for _ in vk.permutation_commitments]
+    perm_eval = []
+    for i in range(Cn):
+        z = [read_scalar(), read_scalar()]
+        z.append(read_scalar() if i != Cn - 1 else None)
+        perm_eval.append(z)
+    lk_eval = []
+    for i in range(L):
+        # product, product_next, permuted_input, permuted_input_inv, permuted_table  (aiken.rs:180-192)
+        lk_eval.append([read_scalar() for _ in range(5)])
+    trash_eval = [read_scalar() for _ in range(n_trash)]
+
+    # ---- queries -> commitment map -> point sets (mod.rs:120-226, pcs/mod.rs:36-109)
+    queries = []  # (commitment key, eval register or callable, rotation)
+    for qi, (col, rot) in enumerate(vk.advice_queries):
+        queries.append((("advice", col), ("advice", qi), rot))
+    for qi, (col, rot) in enumerate(vk.instance_queries):
+        if col < n_ci:
+            queries.append((("instance", col), ("instance", qi), rot))
+    for i in range(Cn):
+        queries.append((("perm", i), ("perm", i, 0), 0))
+        queries.append((("perm", i), ("perm", i, 1), 1))
+    for i in range(Cn - 2, -1, -1):
+        queries.append((("perm", i), ("perm", i, 2), ROT_LAST))
+    for i in range(L):
+        queries.append((("lookup", i), ("lk", i, 0), 0))
+        queries.append((("perm_input", i), ("lk", i, 2), 0))
+        queries.append((("perm_table", i), ("lk", i, 4), 0))
+        queries.append((("perm_input", i), ("lk", i, 3), -1))
+        queries.append((("lookup", i), ("lk", i, 1), 1))
+    for i in range(n_trash):
+        queries.append((("trash", i), ("trash", i), 0))
+    for qi, (col, rot) in enumerate(vk.fixed_queries):
+        queries.append((("fixed", col), ("fixed", qi), rot))
+    for i in range(len(vk.permutation_commitments)):
+        queries.append((("common", i), ("common", i), 0))
+    queries.append((("vanishing_g", 0), ("vanishing_s",), 0))
+    queries.append((("vanishing_rand", 0), ("random",), 0))
+
+    commitments: List[tuple] = []
+    cmap: Dict[tuple, list] = {}
+    for ck, ek, rot in queries:
+        if ck not in cmap:
+            cmap[ck] = []
+            commitments.append(ck)
+        cmap[ck].append((rot, ek))
+    for ck in commitments:
+        cmap[ck].sort(key=lambda pe: _rot_sort_key(pe[0]))  # stable, by point
+    uniq_sets: List[tuple] = []
+    set_of: Dict[tuple, int] = {}
+    for ck in commitments:
+        pts = tuple(p for p, _ in cmap[ck])
+        if pts not in uniq_sets:
+            uniq_sets.append(pts)
+        set_of[ck] = uniq_sets.index(pts)
+    sort_order = sorted(range(len(uniq_sets)), key=lambda i: (len(uniq_sets[i]), i))  # aiken.rs:580-587
+    S = len(uniq_sets)
+
+    # ---- PCS tail (pcs/kzg.rs:55-79)
+    x1 = squeeze()
+    x2 = squeeze()
+    f_pt = read_point("f_commitment")
+    x3 = squeeze()
+    q_evals = [read_scalar() for _ in range(S)]
+    x4 = squeeze()
+    pi_pt = read_point("pi")
+    proof_len = pos
+
+    # ---- rotated evaluation points (verification_h2.hbs:32-37)
+    def rotated(rot):
+        w = _rot_value(vk, rot)
+        return x if w == 1 else b.mul(b.const(w), x)
+
+    x_last = rotated(ROT_LAST)
+
+    # ---- the single batch inversion ------------------------------------------------------------------
+    inv_in: List[int] = []
+    # (a) lagrange basis at rotations -(bf+1)..0 : denominators x - w^i  (lagrange.ak:79-96)
+    bf = vk.blinding_factors
+    van_rot_w = [_rot_value(vk, i) for i in range(-(bf + 1), 1)]
+    van_idx = []
+    for w in van_rot_w:
+        van_idx.append(len(inv_in))
+        inv_in.append(b.sub(x, b.const(w)))
+    # (b) public-input lagrange basis at rotations 0..n_pi (aiken.rs:207-222)
+    need_pi_basis = any(e is None for e in instance_eval) and vk.n_public_inputs > 0
+    pi_rot_w = [pow(vk.omega, i, R) for i in range(vk.n_public_inputs + 1)] if need_pi_basis else []
+    pi_idx = []
+    for w in pi_rot_w:
+        pi_idx.append(len(inv_in))
+        inv_in.append(b.sub(x, b.const(w)))
+    # (c) xn - 1 (verification_h2.hbs:90)
+    xn_m1 = b.sub(xn, one)
+    xn_idx = len(inv_in)
+    inv_in.append(xn_m1)
+    # (d) interpolation denominators per sorted set: prod_{j != i} (p_i - p_j) = x^(m-1) * prod (w_i - w_j)
+    xpow = {0: one, 1: x}
+
+    def x_power(e):
+        if e not in xpow:
+            xpow[e] = b.mul(x_power(e - 1), x)
+        return xpow[e]
+
+    interp_idx = []
+    for s in range(S):
+        pts = uniq_sets[sort_order[s]]
+        ws = [_rot_value(vk, p) for p in pts]
+        idxs = []
+        for i in range(len(pts)):
+            c = 1
+            for j in range(len(pts)):
+                if j != i:
+                    c = c * (ws[i] - ws[j]) % R
+            idxs.append(len(inv_in))
+            inv_in.append(b.mul(b.const(c), x_power(len(pts) - 1)) if len(pts) > 1 else one)
+        interp_idx.append(idxs)
+    # (e) f_eval denominators prod_j (x3 - p_j)  (halo2_kzg.ak:134-141)
+    set_points = []
+    fden_idx = []
+    for s in range(S):
+        pts = [rotated(p) for p in uniq_sets[sort_order[s]]]
+        set_points.append(pts)
+        d = one
+        for p in pts:
+            d = b.mul(d, b.sub(x3, p))
+        fden_idx.append(len(inv_in))
+        inv_in.append(d)
+    inv_out = b.batch_inverse(inv_in)
+
+    # ---- P3: lagrange basis, active rows (verification_h2.hbs:39-60)
+    common = b.mul(xn_m1, b.const(vk.barycentric_weight))
+    basis = [b.mul(b.mul(inv_out[van_idx[i]], common), b.const(van_rot_w[i])) for i in range(bf + 2)]
+    l_last = basis[0]
+    l_blind = basis[1:1 + bf]
+    l_0 = basis[-1]
+    sum_blind = zero
+    for e in l_blind:
+        sum_blind = b.add(e, sum_blind)
+    active_rows = b.sub(one, b.add(l_last, sum_blind))
+    # public-input column evaluation: inner_product(basis[0..n_pi), inputs)
+    if need_pi_basis:
+        pbasis = [b.mul(b.mul(inv_out[pi_idx[i]], common), b.const(pi_rot_w[i])) for i in range(vk.n_public_inputs)]
+        acc = zero
+        for i in range(vk.n_public_inputs):
+            acc = b.add(b.mul(pbasis[i], pis[i]), acc)
+        pub_eval = acc
+    else:
+        pub_eval = zero
+    instance_eval = [e if e is not None else pub_eval for e in instance_eval]
+
+    # ---- P4: combiner
+    def ev(e) -> int:
+        t = e[0]
+        if t == "const":
+            return b.const(e[1])
+        if t == "fixed":
+            return fixed_eval[e[1]]
+        if t == "advice":
+            return advice_eval[e[1]]
+        if t == "neg":
+            return b.neg(ev(e[1]))
+        if t == "sum":
+            return b.add(ev(e[1]), ev(e[2]))
+        if t == "prod":
+            return b.mul(ev(e[1]), ev(e[2]))
+        if t == "scaled":
+            return b.mul(ev(e[1]), b.const(e[2]))
+        raise ValueError(t)
+
+    def compress(exprs, ch):
+        acc = zero
+        for e in exprs:
+            acc = b.add(b.mul(acc, ch), ev(e))
+        return acc
+
+    expressions: List[int] = [ev(g) for g in vk.gates]
+    # permutation terms (permutation.rs:80-143)
+    expressions.append(b.mul(l_0, b.sub(one, perm_eval[0][0])))
+    zl = perm_eval[Cn - 1][0]
+    expressions.append(b.mul(l_last, b.sub(b.mul(zl, zl), zl)))
+    for i in range(1, Cn):
+        expressions.append(b.mul(b.sub(perm_eval[i][0], perm_eval[i - 1][2]), l_0))
+    # permutation sets (permutation.rs:145-303; aiken.rs:345-441)
+    bx = b.mul(beta, x)
+
+    def column_eval(ty, col):
+        if ty == "advice":
+            return advice_eval[vk.advice_queries.index((col, 0))]
+        if ty == "fixed":
+            return fixed_eval[vk.fixed_queries.index((col, 0))]
+        return instance_eval[vk.instance_queries.index((col, 0))]
+
+    not_blind = b.sub(one, b.add(l_last, sum_blind))
+    for i in range(Cn):
+        left = perm_eval[i][1]
+        right = perm_eval[i][0]
+        for idx in range(vk.chunk_len):
+            col = i * vk.chunk_len + idx
+            if col >= len(vk.permutation_columns):
+                break
+            e = column_eval(*vk.permutation_columns[col])
+            left = b.mul(left, b.add(b.add(e, b.mul(beta, perm_common[col])), gamma))
+            right = b.mul(right, b.add(b.add(e, b.mul(bx, b.const(pow(bls.DELTA, col, R)))), gamma))
+        expressions.append(b.mul(b.sub(left, right), not_blind))
+    # lookups (aiken.rs:264-330)
+    for i, (ins, tabs) in enumerate(vk.lookups):
+        tab = compress(tabs, theta)
+        inp = compress(ins, theta)
+        prod, prod_next, pin, pinv, ptab = lk_eval[i]
+        expressions.append(b.mul(l_0, b.sub(one, prod)))
+        expressions.append(b.mul(l_last, b.sub(b.mul(prod, prod), prod)))
+        left = b.mul(b.mul(prod_next, b.add(pin, beta)), b.add(ptab, gamma))
+        right = b.mul(b.mul(prod, b.add(inp, beta)), b.add(tab, gamma))
+        expressions.append(b.mul(b.sub(left, right), active_rows))
+        d = b.sub(pin, ptab)
+        expressions.append(b.mul(l_0, d))
+        expressions.append(b.mul(b.mul(d, b.sub(pin, pinv)), active_rows))
+    # trashcans (aiken.rs:444-461)
+    for i, (sel, cons) in enumerate(vk.trashcans):
+        expressions.append(b.sub(compress(cons, trash), b.mul(b.sub(one, ev(sel)), trash_eval[i])))
+    # hEval = Horner in y with acc0 = 0 (aiken.rs:557-563); vanishing_s = hEval / (xn - 1)
+    h_eval = zero
+    for e in expressions:
+        h_eval = b.add(b.mul(h_eval, y), e)
+    vanishing_s = b.mul(h_eval, inv_out[xn_idx])
+
+    # ---- P6: multi-open scalars
+    def eval_reg(ek):
+        k = ek[0]
+        if k == "advice":
+            return advice_eval[ek[1]]
+        if k == "instance":
+            return instance_eval[ek[1]]
+        if k == "fixed":
+            return fixed_eval[ek[1]]
+        if k == "perm":
+            return perm_eval[ek[1]][ek[2]]
+        if k == "lk":
+            return lk_eval[ek[1]][ek[2]]
+        if k == "trash":
+            return trash_eval[ek[1]]
+        if k == "common":
+            return perm_common[ek[1]]
+        if k == "vanishing_s":
+            return vanishing_s
+        if k == "random":
+            return random_eval
+        raise ValueError(ek)
+
+    vk_bases: List[Optional[Tuple[int, int]]] = []
+    vk_base_idx: Dict[tuple, int] = {}
+
+    def vk_base(key, pt):
+        if key not in vk_base_idx:
+            vk_base_idx[key] = len(vk_bases)
+            vk_bases.append(pt)
+        return vk_base_idx[key]
+
+    fixed_pts = [bls.g1_decompress(bytes.fromhex(h)) for h in vk.fixed_commitments]
+    perm_cpts = [bls.g1_decompress(bytes.fromhex(h)) for h in vk.permutation_commitments]
+
+    terms: List[Tuple[int, int]] = []
+    term_names: List[str] = []
+    term_scalar: List[int] = []
+
+    def add_term(kind, index, scalar_reg, name):
+        terms.append((kind, index))
+        term_scalar.append(scalar_reg)
+        term_names.append(name)
+
+    q_eval_sets: List[List[int]] = []
+    x4p = one
+    for s in range(S):
+        old = sort_order[s]
+        m = len(uniq_sets[old])
+        acc_evals: List[Optional[int]] = [None] * m
+        x1p = one
+        for ck in commitments:
+            if set_of[ck] != old:
+                continue
+            coeff = b.mul(x4p, x1p)  # x4^s * x1^j
+            kind = ck[0]
+            if kind == "advice":
+                add_term(TERM_PROOF_POINT, adv_pts[ck[1]], coeff, point_names[adv_pts[ck[1]]])
+            elif kind == "instance":
+                add_term(TERM_COMMITTED_INSTANCE, 0, coeff, "ci_1")
+            elif kind == "perm":
+                add_term(TERM_PROOF_POINT, perm_pts[ck[1]], coeff, point_names[perm_pts[ck[1]]])
+            elif kind == "lookup":
+                add_term(TERM_PROOF_POINT, lk_prod[ck[1]], coeff, point_names[lk_prod[ck[1]]])
+            elif kind == "perm_input":
+                add_term(TERM_PROOF_POINT, lk_pin[ck[1]], coeff, point_names[lk_pin[ck[1]]])
+            elif kind == "perm_table":
+                add_term(TERM_PROOF_POINT, lk_ptab[ck[1]], coeff, point_names[lk_ptab[ck[1]]])
+            elif kind == "trash":
+                add_term(TERM_PROOF_POINT, trash_pts[ck[1]], coeff, point_names[trash_pts[ck[1]]])
+            elif kind == "fixed":
+                add_term(TERM_VK_BASE, vk_base(ck, fixed_pts[ck[1]]), coeff, "f%d_commitment" % (ck[1] + 1))
+            elif kind == "common":
+                add_term(TERM_VK_BASE, vk_base(ck, perm_cpts[ck[1]]), coeff, "p%d_commitment" % (ck[1] + 1))
+            elif kind == "vanishing_rand":
+                add_term(TERM_PROOF_POINT, vanish_rand_pt, coeff, "vanishing_rand")
+            elif kind == "vanishing_g":
+                # vanishing_g = sum_i (x^(n-1))^i * H_{i+1}  (vanishing.rs:6-52) flattened into the MSM
+                c = coeff
+                for i in range(n_splits):
+                    add_term(TERM_PROOF_POINT, split_pts[i], c, point_names[split_pts[i]])
+                    c = b.mul(c, xn_minus_one)
+            else:
+                raise ValueError(ck)
+            for j, (_p, ek) in enumerate(cmap[ck]):
+                t = b.mul(eval_reg(ek), x1p)
+                acc_evals[j] = t if acc_evals[j] is None else b.add(acc_evals[j], t)
+            x1p = b.mul(x1p, x1)
+        q_eval_sets.append([e for e in acc_evals])
+        x4p = b.mul(x4p, x4)
+    x4_S = x4p
+    add_term(TERM_PROOF_POINT, f_pt, x4_S, "f_commitment")
+
+    # f_eval (halo2_kzg.ak:121-159): r_eval by interpolation (lagrange.ak:40-77)
+    f_eval = zero
+    r_evals = []
+    for s in range(S):
+        pts = set_points[s]
+        m = len(pts)
+        r_eval = zero
+        for i in range(m):
+            num = one
+            for j in range(m):
+                if j != i:
+                    num = b.mul(num, b.sub(x3, pts[j]))
+            r_eval = b.add(r_eval, b.mul(q_eval_sets[s][i], b.mul(num, inv_out[interp_idx[s][i]])))
+        r_evals.append(r_eval)
+    for s in range(S - 1, -1, -1):
+        e = b.mul(b.sub(q_evals[s], r_evals[s]), inv_out[fden_idx[s]])
+        f_eval = b.add(b.mul(f_eval, x2), e)
+    # v (halo2_kzg.ak:161-171)
+    v = zero
+    x4p = one
+    for s in range(S + 1):
+        v = b.add(v, b.mul(x4p, q_evals[s] if s < S else f_eval))
+        x4p = b.mul(x4p, x4)
+    # er = final_com + v*(-G1) + x3*pi ; el = pi
+    add_term(TERM_VK_BASE, vk_base(("neg_g1", 0), bls.g1_neg(bls.G1_GEN)), v, "neg_g1_generator")
+    add_term(TERM_PROOF_POINT, pi_pt, x3, "pi")
+
+    for t, reg in enumerate(term_scalar):
+        b.emit(OP_OUT_SCALAR, t, reg, 0)
+    b.emit(OP_END)
+
+    # ---- trace registers
+    named = {"theta": theta, "beta": beta, "gamma": gamma, "trash": trash, "y": y, "x": x, "x1": x1, "x2": x2,
+             "x3": x3, "x4": x4, "x_last": x_last, "xn": xn, "l_last": l_last, "l_0": l_0,
+             "active_rows": active_rows, "h_eval": h_eval, "vanishing_s": vanishing_s, "f_eval": f_eval, "v": v}
+    trace_virt = [(TRACE_NAMES.index(n), r) for n, r in named.items()]
+    for i, e in enumerate(expressions[:MAX_TRACE_EXPR]):
+        trace_virt.append((TRACE_EXPR0 + i, e))
+
+    # ---- register allocation (linear scan over the straight-line code)
+    keep_alive = {r for _, r in trace_virt}
+    instrs, n_regs, mapping = _allocate(b, keep_alive)
+    trace = [(slot, mapping[r]) for slot, r in trace_virt]
+
+    s_g2 = bls.g2_decompress(bytes.fromhex(vk.s_g2))
+    plan = Plan(
+        vk_name=vk.name, proof_len=proof_len, n_pi=vk.n_public_inputs, n_ci=n_ci, n_regs=n_regs, instrs=instrs,
+        consts=b.consts, points=points, point_names=point_names, vk_bases=vk_bases, terms=terms,
+        term_names=term_names, pi_point=pi_pt, lines_sg2=bls.g2_line_table(s_g2),
+        lines_g2=bls.g2_line_table(bls.G2_GEN), trace=trace, n_squeezes=n_squeezes, stream_len=stream_len,
+    )
+    return plan
+
+
+def _uses(op, dst, a, b):
+    if op in (OP_ADD, OP_SUB, OP_MUL):
+        return (a, b)
+    if op in (OP_NEG, OP_INV, OP_ABSORB_REG, OP_OUT_SCALAR):
+        return (a,)
+    return ()
+
+
+def _defines(op):
+    return op in (OP_LOAD_INSTANCE, OP_READ_SCALAR, OP_SQUEEZE, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_INV)
+
+
+def _allocate(b: _Builder, keep_alive):
+    """Constants are rematerialised right before each use-run would cost instructions; instead every virtual
+    register simply gets a physical one for [def, last use]; registers named in the trace table live to the end."""
+    code = b.code
+    last_use = {}
+    for i, (op, dst, a, c) in enumerate(code):
+        for r in _uses(op, dst, a, c):
+            last_use[r] = i
+    end = len(code)
+    for r in keep_alive:
+        last_use[r] = end
+    free: List[int] = []
+    n_phys = 0
+    mapping: Dict[int, int] = {}
+    expiring: Dict[int, List[int]] = {}
+    out = []
+    for i, (op, dst, a, c) in enumerate(code):
+        pa, pc = a, c
+        if op in (OP_ADD, OP_SUB, OP_MUL):
+            pa, pc = mapping[a], mapping[c]
+        elif op in (OP_NEG, OP_INV, OP_ABSORB_REG, OP_OUT_SCALAR):
+            pa = mapping[a]
+        # release registers whose last use is this instruction BEFORE allocating dst (dst may reuse a source:
+        # every op reads its sources fully before writing)
+        for r in expiring.pop(i, []):
+            free.append(mapping[r])
+        if _defines(op):
+            if dst not in last_use:
+                # dead value (e.g. an unused constant): still needs a slot for the write
+                last_use[dst] = i
+            if free:
+                p = free.pop()
+            else:
+                p = n_phys
+                n_phys += 1
+            mapping[dst] = p
+            lu = last_use[dst]
+            if lu <= i:
+                free.append(p)
+            elif lu < end:
+                expiring.setdefault(lu, []).append(dst)
+            pd = p
+        else:
+            pd = dst
+        out.append((op, pd, pa, pc))
+    assert n_phys < 65536
+    return out, max(n_phys, 1), mapping
+
+
+# ----------------------------------------------------------------------------- big-integer interpreter
+class PlanReject(Exception):
+    pass
+
+
+def run_plan(plan: Plan, proof: bytes, instances: List[int], committed: Optional[bytes] = None,
+             stop_before_point: Optional[int] = None):
+    """Executes the plan's bytecode with Python integers (host-side tool: used by the synthetic-proof forger and by
+    the CPU tests of the compiler; NOT the verification path).  Returns (term scalars, registers, status).
+    status: None = ran to the end, or a reject reason string.  With stop_before_point=i the run stops just before
+    READ_POINT of point slot i (used to forge the last proof element)."""
+    import hashlib
+
+    regs = [0] * plan.n_regs
+    scalars = [0] * plan.n_terms
+    acc = bytearray()
+    status = None
+    n_points_read = 0
+    if len(proof) < plan.proof_len and stop_before_point is None:
+        return scalars, regs, "short"
+    for op, d, a, c in plan.instrs:
+        if op == OP_END:
+            break
+        if op == OP_ABSORB_REG:
+            acc += b"\x01" + regs[a].to_bytes(32, "little")
+        elif op == OP_ABSORB_CI:
+            acc += b"\x01" + committed
+        elif op == OP_LOAD_INSTANCE:
+            regs[d] = instances[a] % R
+        elif op == OP_READ_POINT:
+            if stop_before_point is not None and n_points_read == stop_before_point:
+                return scalars, regs, "stopped"
+            off = a | (c << 16)
+            acc += b"\x01" + proof[off:off + 48]
+            n_points_read += 1
+        elif op == OP_READ_SCALAR:
+            off = a | (c << 16)
+            raw = proof[off:off + 32]
+            val = int.from_bytes(raw, "little")
+            if val >= R:
+                status = status or "scalar"
+            regs[d] = val % R
+            acc += b"\x01" + raw
+        elif op == OP_SQUEEZE:
+            acc += b"\x00"
+            h = hashlib.blake2b(bytes(acc), digest_size=32).digest()
+            h2 = hashlib.blake2b(h, digest_size=32).digest()
+            regs[d] = (int.from_bytes(h, "little") + int.from_bytes(h2, "little") * bls.R_2_256) % R
+        elif op == OP_CONST:
+            regs[d] = plan.consts[a]
+        elif op == OP_ADD:
+            regs[d] = (regs[a] + regs[c]) % R
+        elif op == OP_SUB:
+            regs[d] = (regs[a] - regs[c]) % R
+        elif op == OP_MUL:
+            regs[d] = regs[a] * regs[c] % R
+        elif op == OP_NEG:
+            regs[d] = (-regs[a]) % R
+        elif op == OP_INV:
+            if regs[a] == 0:
+                status = status or "inverse"
+                regs[d] = 0
+            else:
+                regs[d] = pow(regs[a], R - 2, R)
+        elif op == OP_OUT_SCALAR:
+            scalars[d] = regs[a]
+        else:
+            raise ValueError("bad opcode %d" % op)
+    return scalars, regs, status
+
+
+def plan_stats(plan: Plan) -> dict:
+    hist = {}
+    for op, *_ in plan.instrs:
+        hist[OP_NAMES[op]] = hist.get(OP_NAMES[op], 0) + 1
+    return {"instrs": len(plan.instrs), "regs": plan.n_regs, "consts": len(plan.consts), "points": len(plan.points),
+            "terms": plan.n_terms, "proof_len": plan.proof_len, "ops": hist, "squeezes": plan.n_squeezes,
+            "stream_len": plan.stream_len}
