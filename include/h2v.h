@@ -1,0 +1,115 @@
+/* h2v - MI355X (gfx950) batch verifier backend for Halo2/KZG proofs over BLS12-381: the C-ABI boundary.
+ *
+ * This library is a drop-in for ONE hot path of input-output-hk/plutus-halo2-verifier-gen: the verification the
+ * reference runs on the CPU as the two-call sequence re-exported at /root/reference/src/lib.rs:9-15
+ *
+ *     let guard = prepare(&vk, committed_instances, instances, &mut transcript)?;     // examples/simple_mul.rs:98
+ *     guard.verify(&params.verifier_params())?;                                        // examples/simple_mul.rs:101
+ *
+ * (in the IVC example the guard is a DualMSM with `.check(&params) -> bool`, examples/ivc.rs:85-96,195-198), and
+ * that it re-states as generated Plinth/Aiken code (aiken-verifier/templates/verification_h2.hbs:21-129).
+ * The reference has no FFI for this path (Rust generics over midnight-proofs); these entry points are what a
+ * `extern "C"` binding of that call pair needs - see INTEGRATION.md for the Rust-side stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the library never retains caller pointers past return;
+ *   - scalars: 32 bytes little-endian (the transcript wire format, transcript.ak:29-45);
+ *     G1: 48 bytes zcash-compressed (bls_utils.ak:17-28);
+ *   - return codes: 0 = ok, negative = API misuse / device error (H2V_E_*).  A malformed or invalid PROOF is
+ *     never an API error: it is accept[i] = 0, mirroring `Err(_)` => reject on the Rust side;
+ *   - no CPU fallback: every verify call runs on the GPU or fails with H2V_E_DEVICE.
+ */
+#ifndef H2V_H
+#define H2V_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H2V_OK 0
+#define H2V_E_ARG (-1)     /* null / inconsistent argument */
+#define H2V_E_PLAN (-2)    /* malformed plan blob */
+#define H2V_E_DEVICE (-3)  /* HIP error (no device, out of memory, launch failure) */
+#define H2V_E_LIMIT (-4)   /* plan exceeds a backend limit (e.g. more than 64 MSM terms) */
+
+/* per-proof status bits (h2v_verify_batch_ex / trace): 0 = accepted */
+#define H2V_ST_BAD_SCALAR 1u       /* non-canonical scalar encoding in the proof */
+#define H2V_ST_INVERSE_OF_ZERO 2u  /* an inversion the verifier needs hit zero (recip_eea panics, bls_utils.ak:151-154) */
+#define H2V_ST_SHORT_PROOF 4u      /* fewer bytes than the plan's proof layout */
+#define H2V_ST_BAD_POINT 8u        /* a G1 encoding is malformed / off-curve / not in the subgroup */
+#define H2V_ST_PAIRING 16u         /* e(pi, s_g2) != e(er, G2) */
+
+typedef struct h2v_plan h2v_plan;           /* replaces VerifyingKey<F,CS> + ParamsVerifierKZG for this path */
+typedef struct h2v_workspace h2v_workspace; /* reusable device scratch for batches of up to max_batch proofs */
+
+/* One batch of independent proofs for the same plan.  Replaces the arguments of `prepare`
+ * (src/lib.rs:9-15; call sites examples/simple_mul.rs:98, examples/sha256.rs:131-137):
+ *   proofs      concatenated proof bytes, proof i = proofs[proof_off[i] .. proof_off[i+1])   (transcript bytes)
+ *   instances   n * n_public_inputs * 32 bytes  (instances: &[&[&[F]]], one public column)
+ *   committed   n * 48 bytes or NULL            (committed_instances: &[&[CS::Commitment]], 0 or 1 per proof) */
+typedef struct {
+    uint64_t n;
+    const uint8_t *proofs;
+    const uint64_t *proof_off; /* n + 1 entries */
+    const uint8_t *instances;
+    const uint8_t *committed;
+} h2v_batch;
+
+/* optional per-stage device timings (milliseconds, HIP events on the launch stream) */
+typedef struct {
+    float transcript_combiner_ms, g1_decompress_ms, g1_msm_ms, pairing_ms, total_ms;
+} h2v_timings;
+
+/* ---- plan (VerifyingKey) lifecycle -------------------------------------------------------------------------
+ * h2v_plan_load: parse + validate the plan blob (plutus_halo2_verifier_gen_amd.plan.compile_plan(vk).to_bytes())
+ * and upload it to `device`.  Immutable after load; may be shared by threads (each with its own workspace). */
+int h2v_plan_load(const uint8_t *plan, size_t len, int device, h2v_plan **out);
+void h2v_plan_free(h2v_plan *plan);
+/* plan facts: proof length in bytes, public inputs per proof, committed instances per proof (0/1), MSM terms T */
+int h2v_plan_info(const h2v_plan *plan, uint32_t *proof_len, uint32_t *n_public_inputs, uint32_t *n_committed,
+                  uint32_t *n_msm_terms);
+
+int h2v_workspace_create(const h2v_plan *plan, uint64_t max_batch, h2v_workspace **out);
+void h2v_workspace_free(h2v_workspace *ws);
+
+/* ---- verification (replaces prepare + Guard::verify / DualMSM::check) --------------------------------------
+ * Host-buffer form: copies the batch to the device, verifies, copies accept[] (n bytes, 1 = accept) back.
+ * ws may be NULL (a temporary workspace is created for the call). */
+int h2v_verify_batch(const h2v_plan *plan, const h2v_batch *batch, uint8_t *accept, h2v_workspace *ws);
+
+/* Device-resident form: every pointer in `batch` and `accept`/`status` are DEVICE pointers on the plan's device
+ * (e.g. torch tensors' data_ptr()); work is enqueued on `stream` (a hipStream_t, NULL = default stream) and the
+ * call returns after enqueueing unless `timings` is given (then it synchronises to read the events).
+ * status (n x uint32, may be NULL) receives the H2V_ST_* bits. */
+int h2v_verify_batch_device(const h2v_plan *plan, const h2v_batch *batch, uint8_t *accept, uint32_t *status,
+                            h2v_workspace *ws, void *stream, h2v_timings *timings);
+
+/* ---- parity / debugging surface ----------------------------------------------------------------------------
+ * The reference's own intermediate-value trace (cargo feature plutus_debug, src/plutus_gen/emitters/plinth.rs:792-831):
+ * theta, beta, gamma, x, y, hEval, vanishing_s, ..., every expression_i, plus el / er.
+ * Host buffers.  scalars_out: n_trace * 32 bytes LE in the order of h2v_plan_trace_slots(); er_out / el_out:
+ * 96 bytes affine x||y big-endian (all-zero = infinity). */
+int h2v_plan_trace_slots(const h2v_plan *plan, uint32_t *slot_ids, uint32_t cap, uint32_t *n_out);
+int h2v_trace(const h2v_plan *plan, const uint8_t *proof, size_t proof_len, const uint8_t *instances,
+              const uint8_t *committed, uint8_t *scalars_out, uint8_t *msm_scalars_out /* T*32 or NULL */,
+              uint8_t el_out[96], uint8_t er_out[96], uint32_t *status_out, uint8_t *accept_out);
+
+/* primitive probes for the GPU parity tests (host buffers; canonical little-endian limbs) */
+int h2v_probe_field(int device, int op, uint32_t n, const uint32_t *a, const uint32_t *b, uint32_t *out);
+int h2v_probe_blake2b(int device, uint32_t n, uint32_t len, const uint8_t *msgs, uint8_t *digests);
+int h2v_probe_g1_decompress(int device, uint32_t n, const uint8_t *compressed, uint8_t *xy_be, uint8_t *valid);
+/* sum_t s_t * B_t per group: n groups of T terms; scalars n*T*32 B LE, bases n*T*48 B compressed; out n*96 B affine BE */
+int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_t *scalars, const uint8_t *bases_compressed,
+                     uint8_t *out_xy_be);
+/* e(p1, s_g2 of plan) == e(p2, G2) for n pairs of compressed G1 points; out[i] = 1/0 */
+int h2v_probe_pairing(const h2v_plan *plan, uint32_t n, const uint8_t *p1_compressed, const uint8_t *p2_compressed,
+                      uint8_t *out);
+
+const char *h2v_last_error(void);
+int h2v_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

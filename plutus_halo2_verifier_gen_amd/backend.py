@@ -1,0 +1,226 @@
+"""ctypes binding of the C-ABI library (include/h2v.h -> libh2v_hip.so, built in-tree by __graft_entry__.build()).
+
+There is deliberately NO fallback: if the HIP library is missing, or no GPU is present, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libh2v_hip.so")
+
+H2V_OK = 0
+ST_BAD_SCALAR, ST_INVERSE_OF_ZERO, ST_SHORT_PROOF, ST_BAD_POINT, ST_PAIRING = 1, 2, 4, 8, 16
+
+
+class H2VError(RuntimeError):
+    pass
+
+
+class Batch(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("proofs", C.c_void_p), ("proof_off", C.c_void_p), ("instances", C.c_void_p),
+                ("committed", C.c_void_p)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("transcript_combiner_ms", C.c_float), ("g1_decompress_ms", C.c_float), ("g1_msm_ms", C.c_float),
+                ("pairing_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+EXPORTS = [
+    "h2v_plan_load", "h2v_plan_free", "h2v_plan_info", "h2v_workspace_create", "h2v_workspace_free",
+    "h2v_verify_batch", "h2v_verify_batch_device", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
+    "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_pairing", "h2v_last_error",
+    "h2v_device_count",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libh2v_hip.so.  Raises if it has not been built: the HIP extension is mandatory."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise H2VError("HIP backend library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.h2v_last_error.restype = C.c_char_p
+        L.h2v_plan_load.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+        L.h2v_plan_free.argtypes = [C.c_void_p]
+        L.h2v_plan_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4
+        L.h2v_workspace_create.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.h2v_workspace_free.argtypes = [C.c_void_p]
+        L.h2v_verify_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
+        L.h2v_verify_batch_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.POINTER(Timings)]
+        L.h2v_plan_trace_slots.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
+        L.h2v_trace.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
+        L.h2v_probe_field.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.h2v_probe_blake2b.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p]
+        L.h2v_probe_g1_decompress.argtypes = [C.c_int, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p]
+        L.h2v_probe_g1_msm.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p]
+        L.h2v_probe_pairing.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != H2V_OK:
+        raise H2VError("h2v error %d: %s" % (rc, (lib().h2v_last_error() or b"").decode()))
+
+
+def device_count() -> int:
+    return lib().h2v_device_count()
+
+
+class DevicePlan:
+    """A plan uploaded to one GPU (h2v_plan*)."""
+
+    def __init__(self, plan_bytes: bytes, device: int = 0):
+        self._h = C.c_void_p()
+        self.device = device
+        check(lib().h2v_plan_load(plan_bytes, len(plan_bytes), device, C.byref(self._h)))
+        v = [C.c_uint32() for _ in range(4)]
+        check(lib().h2v_plan_info(self._h, *[C.byref(x) for x in v]))
+        self.proof_len, self.n_pi, self.n_ci, self.n_terms = [x.value for x in v]
+        n = C.c_uint32()
+        check(lib().h2v_plan_trace_slots(self._h, None, 0, C.byref(n)))
+        slots = (C.c_uint32 * max(1, n.value))()
+        check(lib().h2v_plan_trace_slots(self._h, slots, n.value, C.byref(n)))
+        self.trace_slots = list(slots[:n.value])
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().h2v_plan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer batch verify
+    def verify_batch(self, proofs: bytes, proof_off, instances: bytes, committed: Optional[bytes], ws=None) -> bytes:
+        n = len(proof_off) - 1
+        off = (C.c_uint64 * (n + 1))(*proof_off)
+        pbuf = C.create_string_buffer(proofs, len(proofs)) if proofs else C.create_string_buffer(1)
+        ibuf = C.create_string_buffer(instances, len(instances)) if instances else None
+        cbuf = C.create_string_buffer(committed, len(committed)) if committed else None
+        b = Batch(n, C.cast(pbuf, C.c_void_p), C.cast(off, C.c_void_p),
+                  C.cast(ibuf, C.c_void_p) if ibuf is not None else None,
+                  C.cast(cbuf, C.c_void_p) if cbuf is not None else None)
+        acc = (C.c_uint8 * max(1, n))()
+        check(lib().h2v_verify_batch(self._h, C.byref(b), acc, ws.handle if ws else None))
+        return bytes(acc[:n])
+
+    # ---- device-resident batch verify (pointers = torch tensor data_ptr())
+    def verify_batch_device(self, n, d_proofs, d_off, d_inst, d_ci, d_accept, d_status=None, ws=None, stream=None,
+                            timings: bool = False):
+        b = Batch(n, d_proofs, d_off, d_inst, d_ci)
+        tm = Timings() if timings else None
+        check(lib().h2v_verify_batch_device(self._h, C.byref(b), d_accept, d_status, ws.handle if ws else None, stream,
+                                            C.byref(tm) if timings else None))
+        return tm
+
+    def trace(self, proof: bytes, instances: bytes, committed: Optional[bytes]):
+        nt = len(self.trace_slots)
+        sc = C.create_string_buffer(32 * max(1, nt))
+        ms = C.create_string_buffer(32 * self.n_terms)
+        el = C.create_string_buffer(96)
+        er = C.create_string_buffer(96)
+        st = C.c_uint32()
+        acc = C.c_uint8()
+        check(lib().h2v_trace(self._h, proof, len(proof), instances, committed, sc, ms, el, er, C.byref(st), C.byref(acc)))
+        scal = {self.trace_slots[k]: int.from_bytes(sc.raw[32 * k:32 * k + 32], "little") for k in range(nt)}
+        msm = [int.from_bytes(ms.raw[32 * k:32 * k + 32], "little") for k in range(self.n_terms)]
+
+        def pt(b):
+            return None if b == bytes(96) else (int.from_bytes(b[:48], "big"), int.from_bytes(b[48:], "big"))
+
+        return {"scalars": scal, "msm_scalars": msm, "el": pt(el.raw), "er": pt(er.raw), "status": st.value,
+                "accept": acc.value}
+
+
+class Workspace:
+    def __init__(self, plan: DevicePlan, max_batch: int):
+        self._h = C.c_void_p()
+        check(lib().h2v_workspace_create(plan.handle, max_batch, C.byref(self._h)))
+        self.max_batch = max_batch
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().h2v_workspace_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- primitive probes (GPU parity tests)
+def probe_field(op: int, a_list, b_list, device: int = 0):
+    nl = 12 if op < 4 else 8
+    n = len(a_list)
+    nb = nl * 4
+
+    def pack(vals):
+        return b"".join(int(v).to_bytes(nb, "little") for v in vals)
+
+    out = C.create_string_buffer(n * nb)
+    pa, pb = pack(a_list), pack(b_list)
+    check(lib().h2v_probe_field(device, op, n, pa, pb, out))
+    return [int.from_bytes(out.raw[nb * i:nb * (i + 1)], "little") for i in range(n)]
+
+
+def probe_blake2b(msgs, device: int = 0):
+    n = len(msgs)
+    ln = len(msgs[0])
+    assert all(len(m) == ln for m in msgs)
+    out = C.create_string_buffer(32 * n)
+    check(lib().h2v_probe_blake2b(device, n, ln, b"".join(msgs), out))
+    return [out.raw[32 * i:32 * i + 32] for i in range(n)]
+
+
+def _unxy(b):
+    return None if b == bytes(96) else (int.from_bytes(b[:48], "big"), int.from_bytes(b[48:], "big"))
+
+
+def probe_g1_decompress(compressed_list, device: int = 0):
+    n = len(compressed_list)
+    out = C.create_string_buffer(96 * n)
+    valid = C.create_string_buffer(n)
+    check(lib().h2v_probe_g1_decompress(device, n, b"".join(compressed_list), out, valid))
+    return [(valid.raw[i] == 1, _unxy(out.raw[96 * i:96 * i + 96])) for i in range(n)]
+
+
+def probe_g1_msm(scalar_groups, base_groups, device: int = 0):
+    """scalar_groups[i] = list of T ints, base_groups[i] = list of T 48-byte compressed points."""
+    n = len(scalar_groups)
+    T = len(scalar_groups[0])
+    sc = b"".join(int(s).to_bytes(32, "little") for g in scalar_groups for s in g)
+    bs = b"".join(b for g in base_groups for b in g)
+    out = C.create_string_buffer(96 * n)
+    check(lib().h2v_probe_g1_msm(device, n, T, sc, bs, out))
+    return [_unxy(out.raw[96 * i:96 * i + 96]) for i in range(n)]
+
+
+def probe_pairing(plan: DevicePlan, p1_list, p2_list):
+    n = len(p1_list)
+    out = C.create_string_buffer(n)
+    check(lib().h2v_probe_pairing(plan.handle, n, b"".join(p1_list), b"".join(p2_list), out))
+    return [out.raw[i] for i in range(n)]

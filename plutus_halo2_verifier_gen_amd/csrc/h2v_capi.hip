@@ -1,0 +1,530 @@
+// C-ABI of the MI355X Halo2/KZG batch verifier (include/h2v.h).  Host side: plan parsing/validation/upload,
+// workspace management, stream orchestration of the four kernels.  No arithmetic happens on the host and there
+// is no CPU fallback: a missing or failing device is an error (H2V_E_DEVICE), never a silent detour.
+#include "../../include/h2v.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "h2v_kernels.hip"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(H2V_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+extern "C" const char *h2v_last_error(void) { return g_err.c_str(); }
+extern "C" int h2v_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+struct h2v_plan {
+    int device = 0;
+    H2vDevPlan d{};            // device view
+    void *blob = nullptr;      // one device allocation holding every section
+    uint32_t n_squeezes = 0, stream_len = 0;
+    std::vector<uint32_t> trace_slots;
+};
+
+struct h2v_workspace {
+    int device = 0;
+    uint64_t cap = 0;       // max batch
+    uint32_t stride = 0;    // register-file stride (cap rounded up to 64)
+    uint32_t *regs = nullptr, *scalars = nullptr, *pts = nullptr, *er = nullptr, *status = nullptr, *trace = nullptr;
+    uint8_t *valid = nullptr, *accept = nullptr;
+    // staging for the host-buffer entry point
+    uint8_t *in_proofs = nullptr, *in_inst = nullptr, *in_ci = nullptr;
+    uint64_t *in_off = nullptr;
+    size_t in_proofs_cap = 0, in_inst_cap = 0, in_ci_cap = 0, in_off_cap = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+static uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static uint32_t next_pow2(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------- plan
+extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_plan **out) {
+    if (!blob || !out) return fail(H2V_E_ARG, "null argument");
+    *out = nullptr;
+    const size_t hdr = 8 + 4 * H2V_PLAN_HDR_WORDS;
+    if (len < hdr || memcmp(blob, H2V_PLAN_MAGIC, 8) != 0) return fail(H2V_E_PLAN, "bad magic / truncated header");
+    uint32_t w[H2V_PLAN_HDR_WORDS];
+    for (int i = 0; i < H2V_PLAN_HDR_WORDS; i++) w[i] = rd32(blob + 8 + 4 * i);
+    if (w[H2V_HW_VERSION] != H2V_PLAN_VERSION) return fail(H2V_E_PLAN, "unsupported plan version");
+    if (w[H2V_HW_TOTAL_LEN] != len) return fail(H2V_E_PLAN, "length mismatch");
+    struct Sec { int off_word; uint64_t bytes; };
+    const uint32_t n_instr = w[H2V_HW_N_INSTR], n_consts = w[H2V_HW_N_CONSTS], n_points = w[H2V_HW_N_POINTS],
+                   n_bases = w[H2V_HW_N_VK_BASES], n_terms = w[H2V_HW_N_TERMS], n_trace = w[H2V_HW_N_TRACE],
+                   n_regs = w[H2V_HW_N_REGS], proof_len = w[H2V_HW_PROOF_LEN], n_pi = w[H2V_HW_N_PI], n_ci = w[H2V_HW_N_CI];
+    const Sec secs[] = {{H2V_HW_OFF_INSTR, 8ull * n_instr}, {H2V_HW_OFF_CONSTS, 32ull * n_consts}, {H2V_HW_OFF_POINTS, 4ull * n_points},
+                        {H2V_HW_OFF_VK_BASES, 96ull * n_bases}, {H2V_HW_OFF_TERMS, 8ull * n_terms},
+                        {H2V_HW_OFF_LINES_SG2, 192ull * H2V_MILLER_LINES}, {H2V_HW_OFF_LINES_G2, 192ull * H2V_MILLER_LINES},
+                        {H2V_HW_OFF_TRACE, 8ull * n_trace}};
+    for (const Sec &s : secs) {
+        const uint64_t off = w[s.off_word];
+        if (off < hdr || (off & 7) || off + s.bytes > len) return fail(H2V_E_PLAN, "section out of bounds");
+    }
+    if (n_instr == 0 || n_instr > (1u << 20) || n_regs == 0 || n_regs > 65535 || n_points == 0 || n_points > 4096 ||
+        n_terms == 0 || n_ci > 1 || n_pi > (1u << 16) || proof_len > (1u << 24))
+        return fail(H2V_E_PLAN, "implausible counts");
+    if (n_terms > 64) return fail(H2V_E_LIMIT, "more than 64 MSM terms per proof is not supported by this backend");
+    if (w[H2V_HW_PI_POINT] >= n_points) return fail(H2V_E_PLAN, "pi point index out of range");
+    // validate the program: every register / constant / offset the kernels will touch is in range
+    const uint8_t *ip = blob + w[H2V_HW_OFF_INSTR];
+    bool has_end = false;
+    uint32_t n_sq = 0;
+    for (uint32_t k = 0; k < n_instr; k++) {
+        const uint8_t op = ip[8 * k];
+        const uint32_t dst = ip[8 * k + 2] | (ip[8 * k + 3] << 8), a = ip[8 * k + 4] | (ip[8 * k + 5] << 8), b = ip[8 * k + 6] | (ip[8 * k + 7] << 8);
+        const uint32_t off = a | (b << 16);
+        bool ok = true;
+        switch (op) {
+        case H2V_OP_END: has_end = true; break;
+        case H2V_OP_ABSORB_REG: ok = a < n_regs; break;
+        case H2V_OP_ABSORB_CI: ok = n_ci == 1; break;
+        case H2V_OP_LOAD_INSTANCE: ok = dst < n_regs && a < n_pi; break;
+        case H2V_OP_READ_POINT: ok = (uint64_t)off + 48 <= proof_len; break;
+        case H2V_OP_READ_SCALAR: ok = dst < n_regs && (uint64_t)off + 32 <= proof_len; break;
+        case H2V_OP_SQUEEZE: ok = dst < n_regs; n_sq++; break;
+        case H2V_OP_CONST: ok = dst < n_regs && a < n_consts; break;
+        case H2V_OP_ADD: case H2V_OP_SUB: case H2V_OP_MUL: ok = dst < n_regs && a < n_regs && b < n_regs; break;
+        case H2V_OP_NEG: case H2V_OP_INV: ok = dst < n_regs && a < n_regs; break;
+        case H2V_OP_OUT_SCALAR: ok = dst < n_terms && a < n_regs; break;
+        default: ok = false;
+        }
+        if (!ok) return fail(H2V_E_PLAN, "instruction " + std::to_string(k) + " out of range");
+        if (has_end) break;
+    }
+    if (!has_end) return fail(H2V_E_PLAN, "program has no END");
+    const uint8_t *pp = blob + w[H2V_HW_OFF_POINTS];
+    for (uint32_t k = 0; k < n_points; k++)
+        if ((uint64_t)rd32(pp + 4 * k) + 48 > proof_len) return fail(H2V_E_PLAN, "point offset out of range");
+    const uint8_t *tp = blob + w[H2V_HW_OFF_TERMS];
+    for (uint32_t k = 0; k < n_terms; k++) {
+        const uint32_t kind = rd32(tp + 8 * k), idx = rd32(tp + 8 * k + 4);
+        const bool ok = (kind == H2V_TERM_PROOF_POINT && idx < n_points) || (kind == H2V_TERM_VK_BASE && idx < n_bases) ||
+                        (kind == H2V_TERM_COMMITTED_INSTANCE && n_ci == 1);
+        if (!ok) return fail(H2V_E_PLAN, "MSM term out of range");
+    }
+    const uint8_t *trp = blob + w[H2V_HW_OFF_TRACE];
+    for (uint32_t k = 0; k < n_trace; k++)
+        if (rd32(trp + 8 * k + 4) >= n_regs) return fail(H2V_E_PLAN, "trace register out of range");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(H2V_E_DEVICE, "no HIP device: the HIP backend is required (no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(H2V_E_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    h2v_plan *p = new h2v_plan();
+    p->device = device;
+    if (hipMalloc(&p->blob, len) != hipSuccess) { delete p; return fail(H2V_E_DEVICE, "hipMalloc(plan) failed"); }
+    // device copy of the blob with the committed-instance MSM terms rewritten to "per-proof slot n_points"
+    // (the decompression kernel stores the committed instance there), so the MSM kernel sees two term kinds only
+    std::vector<uint8_t> patched(blob, blob + len);
+    for (uint32_t k = 0; k < n_terms; k++) {
+        uint8_t *t = patched.data() + w[H2V_HW_OFF_TERMS] + 8 * k;
+        if (rd32(t) == H2V_TERM_COMMITTED_INSTANCE) {
+            const uint32_t kind = H2V_TERM_PROOF_POINT, idx = n_points;
+            memcpy(t, &kind, 4);
+            memcpy(t + 4, &idx, 4);
+        }
+    }
+    if (hipMemcpy(p->blob, patched.data(), len, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p->blob); delete p; return fail(H2V_E_DEVICE, "plan upload failed"); }
+    const uint8_t *base = (const uint8_t *)p->blob;
+    H2vDevPlan &d = p->d;
+    d.proof_len = proof_len; d.n_pi = n_pi; d.n_ci = n_ci; d.n_regs = n_regs; d.n_instr = n_instr; d.n_consts = n_consts;
+    d.n_points = n_points; d.n_vk_bases = n_bases; d.n_terms = n_terms; d.n_trace = n_trace; d.pi_point = w[H2V_HW_PI_POINT];
+    d.instr = (const H2vInstr *)(base + w[H2V_HW_OFF_INSTR]);
+    d.consts = (const uint32_t *)(base + w[H2V_HW_OFF_CONSTS]);
+    d.points = (const uint32_t *)(base + w[H2V_HW_OFF_POINTS]);
+    d.vk_bases = (const uint32_t *)(base + w[H2V_HW_OFF_VK_BASES]);
+    d.terms = (const uint32_t *)(base + w[H2V_HW_OFF_TERMS]);
+    d.lines_sg2 = (const uint32_t *)(base + w[H2V_HW_OFF_LINES_SG2]);
+    d.lines_g2 = (const uint32_t *)(base + w[H2V_HW_OFF_LINES_G2]);
+    d.trace = (const uint32_t *)(base + w[H2V_HW_OFF_TRACE]);
+    p->n_squeezes = n_sq;
+    p->stream_len = w[H2V_HW_STREAM_LEN];
+    for (uint32_t k = 0; k < n_trace; k++) p->trace_slots.push_back(rd32(trp + 8 * k));
+    *out = p;
+    return H2V_OK;
+}
+extern "C" void h2v_plan_free(h2v_plan *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->blob) (void)hipFree(p->blob);
+    delete p;
+}
+extern "C" int h2v_plan_info(const h2v_plan *p, uint32_t *proof_len, uint32_t *n_pi, uint32_t *n_ci, uint32_t *n_terms) {
+    if (!p) return fail(H2V_E_ARG, "null plan");
+    if (proof_len) *proof_len = p->d.proof_len;
+    if (n_pi) *n_pi = p->d.n_pi;
+    if (n_ci) *n_ci = p->d.n_ci;
+    if (n_terms) *n_terms = p->d.n_terms;
+    return H2V_OK;
+}
+extern "C" int h2v_plan_trace_slots(const h2v_plan *p, uint32_t *slot_ids, uint32_t cap, uint32_t *n_out) {
+    if (!p || !n_out) return fail(H2V_E_ARG, "null argument");
+    *n_out = (uint32_t)p->trace_slots.size();
+    for (uint32_t k = 0; k < cap && k < p->trace_slots.size(); k++) slot_ids[k] = p->trace_slots[k];
+    return H2V_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- workspace
+static void ws_release(h2v_workspace *w) {
+    (void)hipSetDevice(w->device);
+    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (w->side) (void)hipStreamDestroy(w->side);
+    if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
+    if (w->ev_join) (void)hipEventDestroy(w->ev_join);
+    for (hipEvent_t e : w->ev) if (e) (void)hipEventDestroy(e);
+}
+static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bool with_trace, h2v_workspace **out) {
+    if (max_batch == 0 || max_batch > (1ull << 24)) return fail(H2V_E_ARG, "max_batch out of range");
+    HIPCHK(hipSetDevice(device));
+    h2v_workspace *w = new h2v_workspace();
+    w->device = device;
+    w->cap = max_batch;
+    w->stride = (uint32_t)((max_batch + 63) / 64 * 64);
+    const uint64_t slots = d.n_points + d.n_ci;
+#define WSALLOC(field, bytes)                                                                  \
+    if (hipMalloc((void **)&w->field, (bytes)) != hipSuccess) { ws_release(w); delete w; return fail(H2V_E_DEVICE, "hipMalloc(" #field ") failed"); }
+    WSALLOC(regs, (size_t)d.n_regs * 8 * w->stride * 4)
+    WSALLOC(scalars, (size_t)max_batch * d.n_terms * 32)
+    WSALLOC(pts, (size_t)max_batch * slots * 96)
+    WSALLOC(valid, (size_t)max_batch * slots)
+    WSALLOC(er, (size_t)max_batch * 144)
+    WSALLOC(status, (size_t)max_batch * 4)
+    WSALLOC(accept, (size_t)max_batch)
+    if (with_trace && d.n_trace) { WSALLOC(trace, (size_t)max_batch * d.n_trace * 32) }
+#undef WSALLOC
+    if (hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess) { ws_release(w); delete w; return fail(H2V_E_DEVICE, "stream/event creation failed"); }
+    for (int k = 0; k < 5; k++)
+        if (hipEventCreate(&w->ev[k]) != hipSuccess) { ws_release(w); delete w; return fail(H2V_E_DEVICE, "event creation failed"); }
+    *out = w;
+    return H2V_OK;
+}
+extern "C" int h2v_workspace_create(const h2v_plan *p, uint64_t max_batch, h2v_workspace **out) {
+    if (!p || !out) return fail(H2V_E_ARG, "null argument");
+    return ws_create_for(p->d, p->device, max_batch, false, out);
+}
+extern "C" void h2v_workspace_free(h2v_workspace *w) {
+    if (!w) return;
+    ws_release(w);
+    delete w;
+}
+
+// ---------------------------------------------------------------------------------------------- pipeline
+// Enqueues the four kernels.  Without timings the transcript/combiner kernel (few, long waves) and the
+// decompression kernel (many short ones) run concurrently on two streams and join before the MSM.
+static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst,
+                        const uint8_t *ci, uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st,
+                        h2v_timings *tm, bool want_trace) {
+    const uint32_t slots = d.n_points + d.n_ci;
+    const uint32_t tp = next_pow2(d.n_terms);
+    const uint32_t vm_blocks = (n + 63) / 64;
+    const uint32_t dec_blocks = (n * slots + 63) / 64;
+    const uint32_t msm_blocks = (n + (64 / tp) - 1) / (64 / tp);
+    const uint32_t pair_blocks = (n + 63) / 64;
+    uint32_t *trace = want_trace ? w->trace : nullptr;
+    uint32_t *status = w->status;
+    static const bool dbg = getenv("H2V_DEBUG_SYNC") != nullptr;  // serialise + sync after every kernel, say which one ran
+    if (dbg) {
+#define DBG_STAGE(name, launch)                                                                 \
+        fprintf(stderr, "[h2v] launching %s (n=%u)\n", name, n); fflush(stderr);               \
+        launch;                                                                                 \
+        HIPCHK(hipGetLastError());                                                              \
+        HIPCHK(hipDeviceSynchronize());                                                         \
+        fprintf(stderr, "[h2v] %s done\n", name); fflush(stderr);
+        DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(64), 0, st, d, n, proofs, off, ci, w->pts, w->valid))
+        DBG_STAGE("k_transcript_combiner", hipLaunchKernelGGL(k_transcript_combiner, dim3(vm_blocks), dim3(64), 0, st, d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace))
+        DBG_STAGE("k_g1_msm", hipLaunchKernelGGL(k_g1_msm, dim3(msm_blocks), dim3(MSM_BLOCK), 0, st, d, n, tp, w->scalars, w->pts, w->er))
+        DBG_STAGE("k_pairing_check", hipLaunchKernelGGL(k_pairing_check, dim3(pair_blocks), dim3(64), 0, st, d, n, w->pts, w->valid, w->er, status, accept))
+#undef DBG_STAGE
+        if (status_out) HIPCHK(hipMemcpyAsync(status_out, status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        return H2V_OK;
+    }
+    if (tm) {
+        HIPCHK(hipEventRecord(w->ev[0], st));
+        hipLaunchKernelGGL(k_transcript_combiner, dim3(vm_blocks), dim3(64), 0, st, d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace);
+        HIPCHK(hipEventRecord(w->ev[1], st));
+        hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(64), 0, st, d, n, proofs, off, ci, w->pts, w->valid);
+        HIPCHK(hipEventRecord(w->ev[2], st));
+    } else {
+        HIPCHK(hipEventRecord(w->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
+        hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(64), 0, w->side, d, n, proofs, off, ci, w->pts, w->valid);
+        HIPCHK(hipEventRecord(w->ev_join, w->side));
+        hipLaunchKernelGGL(k_transcript_combiner, dim3(vm_blocks), dim3(64), 0, st, d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace);
+        HIPCHK(hipStreamWaitEvent(st, w->ev_join, 0));
+    }
+    hipLaunchKernelGGL(k_g1_msm, dim3(msm_blocks), dim3(MSM_BLOCK), 0, st, d, n, tp, w->scalars, w->pts, w->er);
+    if (tm) HIPCHK(hipEventRecord(w->ev[3], st));
+    hipLaunchKernelGGL(k_pairing_check, dim3(pair_blocks), dim3(64), 0, st, d, n, w->pts, w->valid, w->er, status, accept);
+    if (tm) HIPCHK(hipEventRecord(w->ev[4], st));
+    HIPCHK(hipGetLastError());
+    if (status_out) HIPCHK(hipMemcpyAsync(status_out, status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    if (tm) {
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipEventElapsedTime(&tm->transcript_combiner_ms, w->ev[0], w->ev[1]));
+        HIPCHK(hipEventElapsedTime(&tm->g1_decompress_ms, w->ev[1], w->ev[2]));
+        HIPCHK(hipEventElapsedTime(&tm->g1_msm_ms, w->ev[2], w->ev[3]));
+        HIPCHK(hipEventElapsedTime(&tm->pairing_ms, w->ev[3], w->ev[4]));
+        HIPCHK(hipEventElapsedTime(&tm->total_ms, w->ev[0], w->ev[4]));
+    }
+    return H2V_OK;
+}
+
+extern "C" int h2v_verify_batch_device(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, uint32_t *status,
+                                       h2v_workspace *ws, void *stream, h2v_timings *timings) {
+    if (!p || !b || !accept) return fail(H2V_E_ARG, "null argument");
+    if (b->n == 0) return H2V_OK;
+    if (!b->proofs || !b->proof_off) return fail(H2V_E_ARG, "null proofs / offsets");
+    if (p->d.n_pi && !b->instances) return fail(H2V_E_ARG, "plan has public inputs but instances == NULL");
+    if (p->d.n_ci && !b->committed) return fail(H2V_E_ARG, "plan has a committed instance but committed == NULL");
+    HIPCHK(hipSetDevice(p->device));
+    h2v_workspace *tmp = nullptr;
+    if (!ws) {
+        int rc = ws_create_for(p->d, p->device, b->n, false, &tmp);
+        if (rc) return rc;
+        ws = tmp;
+    }
+    if (ws->device != p->device || ws->cap < b->n) { if (tmp) h2v_workspace_free(tmp); return fail(H2V_E_ARG, "workspace too small / wrong device"); }
+    int rc = run_pipeline(p->d, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws,
+                          (hipStream_t)stream, timings, false);
+    if (tmp) {
+        if (rc == H2V_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = fail(H2V_E_DEVICE, "stream synchronize failed");
+        h2v_workspace_free(tmp);
+    }
+    return rc;
+}
+
+static int stage_inputs(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws) {
+    const uint64_t n = b->n;
+    const uint64_t total = b->proof_off[n];
+    for (uint64_t i = 0; i < n; i++)
+        if (b->proof_off[i + 1] < b->proof_off[i]) return fail(H2V_E_ARG, "proof offsets must be non-decreasing");
+    auto grow = [&](void **ptr, size_t *cap, size_t need) -> int {
+        if (need <= *cap && *ptr) return H2V_OK;
+        if (*ptr) (void)hipFree(*ptr);
+        *ptr = nullptr;
+        *cap = 0;
+        if (hipMalloc(ptr, need ? need : 8) != hipSuccess) return fail(H2V_E_DEVICE, "hipMalloc(staging) failed");
+        *cap = need ? need : 8;
+        return H2V_OK;
+    };
+    int rc;
+    if ((rc = grow((void **)&ws->in_proofs, &ws->in_proofs_cap, total + 64))) return rc;
+    if ((rc = grow((void **)&ws->in_off, &ws->in_off_cap, (n + 1) * 8))) return rc;
+    if ((rc = grow((void **)&ws->in_inst, &ws->in_inst_cap, n * p->d.n_pi * 32))) return rc;
+    if ((rc = grow((void **)&ws->in_ci, &ws->in_ci_cap, n * p->d.n_ci * 48))) return rc;
+    HIPCHK(hipMemcpy(ws->in_proofs, b->proofs, total, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ws->in_off, b->proof_off, (n + 1) * 8, hipMemcpyHostToDevice));
+    if (p->d.n_pi) HIPCHK(hipMemcpy(ws->in_inst, b->instances, n * p->d.n_pi * 32, hipMemcpyHostToDevice));
+    if (p->d.n_ci) HIPCHK(hipMemcpy(ws->in_ci, b->committed, n * 48, hipMemcpyHostToDevice));
+    return H2V_OK;
+}
+
+extern "C" int h2v_verify_batch(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, h2v_workspace *ws) {
+    if (!p || !b || !accept) return fail(H2V_E_ARG, "null argument");
+    if (b->n == 0) return H2V_OK;
+    if (!b->proofs || !b->proof_off) return fail(H2V_E_ARG, "null proofs / offsets");
+    if (p->d.n_pi && !b->instances) return fail(H2V_E_ARG, "plan has public inputs but instances == NULL");
+    if (p->d.n_ci && !b->committed) return fail(H2V_E_ARG, "plan has a committed instance but committed == NULL");
+    HIPCHK(hipSetDevice(p->device));
+    h2v_workspace *tmp = nullptr;
+    int rc;
+    if (!ws) {
+        if ((rc = ws_create_for(p->d, p->device, b->n, false, &tmp))) return rc;
+        ws = tmp;
+    }
+    if (ws->device != p->device || ws->cap < b->n) { if (tmp) h2v_workspace_free(tmp); return fail(H2V_E_ARG, "workspace too small / wrong device"); }
+    rc = stage_inputs(p, b, ws);
+    if (rc == H2V_OK)
+        rc = run_pipeline(p->d, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, nullptr, nullptr, false);
+    if (rc == H2V_OK && hipMemcpy(accept, ws->accept, b->n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(H2V_E_DEVICE, "accept download failed");
+    if (tmp) h2v_workspace_free(tmp);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------- trace
+extern "C" int h2v_trace(const h2v_plan *p, const uint8_t *proof, size_t proof_len, const uint8_t *instances,
+                         const uint8_t *committed, uint8_t *scalars_out, uint8_t *msm_scalars_out, uint8_t el_out[96],
+                         uint8_t er_out[96], uint32_t *status_out, uint8_t *accept_out) {
+    if (!p || !proof) return fail(H2V_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(p->device));
+    h2v_workspace *ws = nullptr;
+    int rc = ws_create_for(p->d, p->device, 1, true, &ws);
+    if (rc) return rc;
+    uint64_t off[2] = {0, proof_len};
+    h2v_batch b = {1, proof, off, instances, committed};
+    uint8_t *d_pts96 = nullptr;
+    rc = stage_inputs(p, &b, ws);
+    if (rc == H2V_OK) rc = run_pipeline(p->d, 1, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, nullptr, nullptr, true);
+    do {
+        if (rc) break;
+        if (hipMalloc((void **)&d_pts96, 192) != hipSuccess) { rc = fail(H2V_E_DEVICE, "hipMalloc failed"); break; }
+        const uint32_t slots = p->d.n_points + p->d.n_ci;
+        (void)slots;
+        hipLaunchKernelGGL(k_export_points, dim3(1), dim3(64), 0, nullptr, 1u, 0, ws->pts + (size_t)p->d.pi_point * 24, d_pts96);
+        hipLaunchKernelGGL(k_export_points, dim3(1), dim3(64), 0, nullptr, 1u, 1, ws->er, d_pts96 + 96);
+        if (hipDeviceSynchronize() != hipSuccess) { rc = fail(H2V_E_DEVICE, "trace kernels failed"); break; }
+        uint8_t both[192];
+        if (hipMemcpy(both, d_pts96, 192, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(H2V_E_DEVICE, "download failed"); break; }
+        if (el_out) memcpy(el_out, both, 96);
+        if (er_out) memcpy(er_out, both + 96, 96);
+        if (scalars_out && p->d.n_trace && hipMemcpy(scalars_out, ws->trace, (size_t)p->d.n_trace * 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(H2V_E_DEVICE, "download failed"); break; }
+        if (msm_scalars_out && hipMemcpy(msm_scalars_out, ws->scalars, (size_t)p->d.n_terms * 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(H2V_E_DEVICE, "download failed"); break; }
+        if (status_out && hipMemcpy(status_out, ws->status, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(H2V_E_DEVICE, "download failed"); break; }
+        if (accept_out && hipMemcpy(accept_out, ws->accept, 1, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(H2V_E_DEVICE, "download failed"); break; }
+    } while (0);
+    if (d_pts96) (void)hipFree(d_pts96);
+    h2v_workspace_free(ws);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------- probes
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { return hipMalloc(&p, n ? n : 8) == hipSuccess ? 0 : -1; }
+    template <class T> T *as() { return (T *)p; }
+};
+static int pick_device(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(H2V_E_DEVICE, "no HIP device: the HIP backend is required (no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(H2V_E_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    return H2V_OK;
+}
+extern "C" int h2v_probe_field(int device, int op, uint32_t n, const uint32_t *a, const uint32_t *b, uint32_t *out) {
+    int rc = pick_device(device);
+    if (rc) return rc;
+    if (op < 0 || op > 5 || !a || !b || !out || n == 0) return fail(H2V_E_ARG, "bad argument");
+    const size_t bytes = (size_t)n * (op < 4 ? 48 : 32);
+    DevBuf da, db, dout;
+    if (da.alloc(bytes) || db.alloc(bytes) || dout.alloc(bytes)) return fail(H2V_E_DEVICE, "hipMalloc failed");
+    HIPCHK(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_field, dim3((n + 63) / 64), dim3(64), 0, nullptr, op, n, da.as<uint32_t>(), db.as<uint32_t>(), dout.as<uint32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return H2V_OK;
+}
+extern "C" int h2v_probe_blake2b(int device, uint32_t n, uint32_t len, const uint8_t *msgs, uint8_t *digests) {
+    int rc = pick_device(device);
+    if (rc) return rc;
+    if (!msgs || !digests || n == 0) return fail(H2V_E_ARG, "bad argument");
+    DevBuf dm, dout;
+    if (dm.alloc((size_t)n * len) || dout.alloc((size_t)n * 32)) return fail(H2V_E_DEVICE, "hipMalloc failed");
+    if (len) HIPCHK(hipMemcpy(dm.p, msgs, (size_t)n * len, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_blake2b, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, len, dm.as<uint8_t>(), dout.as<uint32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(digests, dout.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+    return H2V_OK;
+}
+// A throw-away plan whose "proof" is `slots` consecutive compressed points and whose MSM takes them in order.
+struct MiniPlan {
+    H2vDevPlan d{};
+    DevBuf points, terms;
+    int build(uint32_t slots, uint32_t n_terms, const uint32_t *lines_sg2, const uint32_t *lines_g2) {
+        std::vector<uint32_t> pts(slots), terms_h(2 * (n_terms ? n_terms : 1));
+        for (uint32_t j = 0; j < slots; j++) pts[j] = 48 * j;
+        for (uint32_t t = 0; t < n_terms; t++) { terms_h[2 * t] = H2V_TERM_PROOF_POINT; terms_h[2 * t + 1] = t; }
+        if (points.alloc(slots * 4) || terms.alloc(terms_h.size() * 4)) return -1;
+        if (hipMemcpy(points.p, pts.data(), slots * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
+        if (hipMemcpy(terms.p, terms_h.data(), terms_h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
+        d.proof_len = 48 * slots; d.n_points = slots; d.n_terms = n_terms; d.pi_point = 0;
+        d.points = points.as<uint32_t>(); d.terms = terms.as<uint32_t>();
+        d.lines_sg2 = lines_sg2; d.lines_g2 = lines_g2;
+        return 0;
+    }
+};
+static int upload_offsets(DevBuf &doff, uint32_t n, uint32_t rec) {
+    std::vector<uint64_t> off(n + 1);
+    for (uint32_t i = 0; i <= n; i++) off[i] = (uint64_t)i * rec;
+    if (doff.alloc((n + 1) * 8)) return -1;
+    return hipMemcpy(doff.p, off.data(), (n + 1) * 8, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+extern "C" int h2v_probe_g1_decompress(int device, uint32_t n, const uint8_t *compressed, uint8_t *xy_be, uint8_t *valid) {
+    int rc = pick_device(device);
+    if (rc) return rc;
+    if (!compressed || !xy_be || !valid || n == 0) return fail(H2V_E_ARG, "bad argument");
+    MiniPlan mp;
+    DevBuf din, doff, dpts, dvalid, dout;
+    if (mp.build(1, 0, nullptr, nullptr) || upload_offsets(doff, n, 48) || din.alloc((size_t)n * 48) || dpts.alloc((size_t)n * 96) ||
+        dvalid.alloc(n) || dout.alloc((size_t)n * 96)) return fail(H2V_E_DEVICE, "probe setup failed");
+    HIPCHK(hipMemcpy(din.p, compressed, (size_t)n * 48, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n + 63) / 64), dim3(64), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
+    hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 0, dpts.as<uint32_t>(), dout.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(xy_be, dout.p, (size_t)n * 96, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(valid, dvalid.p, n, hipMemcpyDeviceToHost));
+    return H2V_OK;
+}
+extern "C" int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_t *scalars, const uint8_t *bases_compressed, uint8_t *out_xy_be) {
+    int rc = pick_device(device);
+    if (rc) return rc;
+    if (!scalars || !bases_compressed || !out_xy_be || n == 0 || T == 0 || T > 64) return fail(H2V_E_ARG, "bad argument");
+    MiniPlan mp;
+    DevBuf din, doff, dsc, dpts, dvalid, der, dout;
+    if (mp.build(T, T, nullptr, nullptr) || upload_offsets(doff, n, 48 * T) || din.alloc((size_t)n * T * 48) || dsc.alloc((size_t)n * T * 32) ||
+        dpts.alloc((size_t)n * T * 96) || dvalid.alloc((size_t)n * T) || der.alloc((size_t)n * 144) || dout.alloc((size_t)n * 96))
+        return fail(H2V_E_DEVICE, "probe setup failed");
+    HIPCHK(hipMemcpy(din.p, bases_compressed, (size_t)n * T * 48, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dsc.p, scalars, (size_t)n * T * 32, hipMemcpyHostToDevice));
+    const uint32_t tp = next_pow2(T);
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(64), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
+    hipLaunchKernelGGL(k_g1_msm, dim3((n + (64 / tp) - 1) / (64 / tp)), dim3(MSM_BLOCK), 0, nullptr, mp.d, n, tp, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>());
+    hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 1, der.as<uint32_t>(), dout.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_xy_be, dout.p, (size_t)n * 96, hipMemcpyDeviceToHost));
+    return H2V_OK;
+}
+extern "C" int h2v_probe_pairing(const h2v_plan *p, uint32_t n, const uint8_t *p1c, const uint8_t *p2c, uint8_t *out) {
+    if (!p || !p1c || !p2c || !out || n == 0) return fail(H2V_E_ARG, "bad argument");
+    HIPCHK(hipSetDevice(p->device));
+    MiniPlan mp;
+    DevBuf din, doff, dsc, dpts, dvalid, der, dst, dacc;
+    if (mp.build(2, 1, p->d.lines_sg2, p->d.lines_g2) || upload_offsets(doff, n, 96) || din.alloc((size_t)n * 96) || dsc.alloc((size_t)n * 32) ||
+        dpts.alloc((size_t)n * 192) || dvalid.alloc((size_t)n * 2) || der.alloc((size_t)n * 144) || dst.alloc((size_t)n * 4) || dacc.alloc(n))
+        return fail(H2V_E_DEVICE, "probe setup failed");
+    // MSM "sum" is 1 * p2 (term 0 must read slot 1): patch the single term
+    uint32_t term[2] = {H2V_TERM_PROOF_POINT, 1};
+    HIPCHK(hipMemcpy(mp.terms.p, term, 8, hipMemcpyHostToDevice));
+    std::vector<uint8_t> in((size_t)n * 96), one((size_t)n * 32, 0);
+    for (uint32_t i = 0; i < n; i++) { memcpy(&in[(size_t)i * 96], p1c + (size_t)i * 48, 48); memcpy(&in[(size_t)i * 96 + 48], p2c + (size_t)i * 48, 48); one[(size_t)i * 32] = 1; }
+    HIPCHK(hipMemcpy(din.p, in.data(), in.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dsc.p, one.data(), one.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dst.p, 0, (size_t)n * 4));
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(64), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
+    hipLaunchKernelGGL(k_g1_msm, dim3((n + 63) / 64), dim3(MSM_BLOCK), 0, nullptr, mp.d, n, 1u, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>());
+    hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, nullptr, mp.d, n, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), der.as<uint32_t>(), dst.as<uint32_t>(), dacc.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dacc.p, n, hipMemcpyDeviceToHost));
+    return H2V_OK;
+}

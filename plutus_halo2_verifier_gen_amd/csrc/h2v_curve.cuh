@@ -1,0 +1,115 @@
+// G1 group law for BLS12-381 (y^2 = x^3 + 4) on gfx950: Jacobian coordinates, Z == 0 <=> infinity.
+// Affine points travel as (x, y) Montgomery limbs with (0, 0) standing for the point at infinity
+// ((0,0) is not on the curve, so the sentinel is unambiguous).
+// Complete behaviour (P+P, P+(-P), infinity operands) is implemented explicitly: proof bytes are adversarial
+// input and the accept/reject result must match the reference's exact group law (the Plutus builtins
+// bls12_381_G1_add / scalarMul used by aiken-verifier/aiken_halo2/lib/bls_utils.ak:77-86).
+#pragma once
+#include "h2v_field.cuh"
+
+struct G1A { Fp x, y; };       // affine; (0,0) = infinity
+struct G1J { Fp x, y, z; };    // Jacobian
+
+H2V_DI bool g1a_is_inf(const G1A &p) { return fp_is_zero(p.x) && fp_is_zero(p.y); }
+H2V_DI void g1a_set_inf(G1A &p) { fp_set_zero(p.x); fp_set_zero(p.y); }
+H2V_DI bool g1j_is_inf(const G1J &p) { return fp_is_zero(p.z); }
+H2V_DI void g1j_set_inf(G1J &p) { fp_set_one(p.x); fp_set_one(p.y); fp_set_zero(p.z); }
+H2V_DI void g1j_from_affine(G1J &r, const G1A &a) {
+    if (g1a_is_inf(a)) { g1j_set_inf(r); return; }
+    r.x = a.x; r.y = a.y; fp_set_one(r.z);
+}
+// dbl-2009-l (a = 0): 2M + 5S
+H2V_DN void g1j_dbl(G1J &r, const G1J &p) {
+    if (g1j_is_inf(p) || fp_is_zero(p.y)) { g1j_set_inf(r); return; }
+    Fp A, B, C, D, E, F, t, x3, y3, z3;
+    fp_sqr(A, p.x);
+    fp_sqr(B, p.y);
+    fp_sqr(C, B);
+    fp_add(t, p.x, B); fp_sqr(t, t); fp_sub(t, t, A); fp_sub(t, t, C); fp_dbl(D, t);
+    fp_dbl(E, A); fp_add(E, E, A);
+    fp_sqr(F, E);
+    fp_mul(z3, p.y, p.z); fp_dbl(z3, z3);
+    fp_dbl(t, D); fp_sub(x3, F, t);
+    fp_sub(t, D, x3); fp_mul(y3, E, t);
+    fp_dbl(C, C); fp_dbl(C, C); fp_dbl(C, C);
+    fp_sub(y3, y3, C);
+    r.x = x3; r.y = y3; r.z = z3;
+}
+// mixed addition r = p + q (q affine, may be infinity): 8M + 3S on the generic path
+H2V_DN void g1j_add_affine(G1J &r, const G1J &p, const G1A &q) {
+    if (g1a_is_inf(q)) { r = p; return; }
+    if (g1j_is_inf(p)) { r.x = q.x; r.y = q.y; fp_set_one(r.z); return; }
+    Fp z1z1, u2, s2, h, rr, hh, hhh, v, t, x3, y3, z3;
+    fp_sqr(z1z1, p.z);
+    fp_mul(u2, q.x, z1z1);
+    fp_mul(s2, q.y, p.z); fp_mul(s2, s2, z1z1);
+    fp_sub(h, u2, p.x);
+    fp_sub(rr, s2, p.y);
+    if (fp_is_zero(h)) {
+        if (fp_is_zero(rr)) { g1j_dbl(r, p); return; }
+        g1j_set_inf(r); return;
+    }
+    fp_sqr(hh, h); fp_mul(hhh, hh, h); fp_mul(v, p.x, hh);
+    fp_sqr(x3, rr); fp_sub(x3, x3, hhh); fp_dbl(t, v); fp_sub(x3, x3, t);
+    fp_sub(t, v, x3); fp_mul(y3, rr, t); fp_mul(t, p.y, hhh); fp_sub(y3, y3, t);
+    fp_mul(z3, p.z, h);
+    r.x = x3; r.y = y3; r.z = z3;
+}
+// full addition: 12M + 4S on the generic path
+H2V_DN void g1j_add(G1J &r, const G1J &p, const G1J &q) {
+    if (g1j_is_inf(p)) { r = q; return; }
+    if (g1j_is_inf(q)) { r = p; return; }
+    Fp z1z1, z2z2, u1, u2, s1, s2, h, rr, hh, hhh, v, t, x3, y3, z3;
+    fp_sqr(z1z1, p.z); fp_sqr(z2z2, q.z);
+    fp_mul(u1, p.x, z2z2); fp_mul(u2, q.x, z1z1);
+    fp_mul(s1, p.y, q.z); fp_mul(s1, s1, z2z2);
+    fp_mul(s2, q.y, p.z); fp_mul(s2, s2, z1z1);
+    fp_sub(h, u2, u1); fp_sub(rr, s2, s1);
+    if (fp_is_zero(h)) {
+        if (fp_is_zero(rr)) { g1j_dbl(r, p); return; }
+        g1j_set_inf(r); return;
+    }
+    fp_sqr(hh, h); fp_mul(hhh, hh, h); fp_mul(v, u1, hh);
+    fp_sqr(x3, rr); fp_sub(x3, x3, hhh); fp_dbl(t, v); fp_sub(x3, x3, t);
+    fp_sub(t, v, x3); fp_mul(y3, rr, t); fp_mul(t, s1, hhh); fp_sub(y3, y3, t);
+    fp_mul(z3, p.z, q.z); fp_mul(z3, z3, h);
+    r.x = x3; r.y = y3; r.z = z3;
+}
+H2V_DN void g1j_to_affine(G1A &r, const G1J &p) {
+    if (g1j_is_inf(p)) { g1a_set_inf(r); return; }
+    Fp zi, zi2;
+    fp_inv(zi, p.z);
+    fp_sqr(zi2, zi);
+    fp_mul(r.x, p.x, zi2);
+    fp_mul(zi2, zi2, zi);
+    fp_mul(r.y, p.y, zi2);
+}
+// [|x|]P for the BLS parameter |x| = 0xd201000000010000 (uniform control flow)
+H2V_DN void g1j_mul_x_abs(G1J &r, const G1J &p) {
+    G1J acc = p;
+    for (int i = 62; i >= 0; i--) {
+        g1j_dbl(acc, acc);
+        if ((BLS_X_ABS >> i) & 1) g1j_add(acc, acc, p);
+    }
+    r = acc;
+}
+// Is the affine, on-curve, finite point in the r-torsion?  sigma(P) = (beta x, y) == [-x^2]P
+// (forces (sigma^2+sigma+1)P = [r]P = O; r does not divide the cofactor, so the test is exact).
+H2V_DN bool g1a_in_subgroup(const G1A &a) {
+    G1J p, t;
+    g1j_from_affine(p, a);
+    g1j_mul_x_abs(t, p);
+    g1j_mul_x_abs(t, t);  // [x^2]P
+    if (g1j_is_inf(t)) return false;
+    // compare (beta x, y) with -t = (X, -Y, Z):  beta x Z^2 == X  and  y Z^3 == -Y
+    Fp beta, z2, z3, l, ny;
+#pragma unroll
+    for (int i = 0; i < 12; i++) beta.v[i] = FP_BETA[i];
+    fp_sqr(z2, t.z);
+    fp_mul(z3, z2, t.z);
+    fp_mul(l, a.x, beta); fp_mul(l, l, z2);
+    if (!fp_eq(l, t.x)) return false;
+    fp_mul(l, a.y, z3);
+    fp_neg(ny, t.y);
+    return fp_eq(l, ny);
+}

@@ -1,0 +1,575 @@
+// gfx950 kernels of the Halo2/KZG batch verifier (one independent proof per lane / lane group).
+//
+//   k_transcript_combiner   P1-P6 scalars: blake2b transcript replay + Fr combiner + final MSM scalar vector
+//                           (interprets the plan's straight-line program; wave-uniform control flow)
+//   k_g1_decompress         48-byte zcash G1 -> affine Montgomery, with on-curve + subgroup validation
+//   k_g1_msm                er = sum_t s_t * B_t per proof: one lane per term, wave/LDS segmented reduction
+//   k_pairing_check         accept <=> e(pi, s_g2) == e(er, G2): 2 Miller loops over precomputed lines of the
+//                           FIXED G2 arguments + one final exponentiation, fused in one kernel
+//
+// Algorithm of record: /root/reference/aiken-verifier/templates/verification_h2.hbs:21-129 and the library it
+// calls (aiken-verifier/aiken_halo2/lib/{transcript,lagrange,halo2_kzg,bls_utils}.ak); hash plug-in
+// /root/reference/src/plutus_gen/adjusted_types/mod.rs:30-72.
+#include <hip/hip_runtime.h>
+#include "h2v_curve.cuh"
+#include "h2v_plan.h"
+#include "h2v_tower.cuh"
+
+// ============================================================================ blake2b-256 (RFC 7693)
+__device__ static constexpr uint64_t B2_IV[8] = {
+    0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
+    0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull};
+__device__ static constexpr uint8_t B2_SIGMA[12][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+
+H2V_DI uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+
+struct B2Msg { uint64_t m[16]; };
+
+H2V_DN void b2_compress(uint64_t (&h)[8], const B2Msg &blk, uint64_t t, bool last) {
+    uint64_t v[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = B2_IV[i]; }
+    v[12] ^= t;
+    if (last) v[14] = ~v[14];
+#define B2G(a, b, c, d, x, y)                                                                             \
+    v[a] = v[a] + v[b] + (x); v[d] = rotr64(v[d] ^ v[a], 32); v[c] = v[c] + v[d]; v[b] = rotr64(v[b] ^ v[c], 24); \
+    v[a] = v[a] + v[b] + (y); v[d] = rotr64(v[d] ^ v[a], 16); v[c] = v[c] + v[d]; v[b] = rotr64(v[b] ^ v[c], 63);
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        B2G(0, 4, 8, 12, blk.m[B2_SIGMA[r][0]], blk.m[B2_SIGMA[r][1]])
+        B2G(1, 5, 9, 13, blk.m[B2_SIGMA[r][2]], blk.m[B2_SIGMA[r][3]])
+        B2G(2, 6, 10, 14, blk.m[B2_SIGMA[r][4]], blk.m[B2_SIGMA[r][5]])
+        B2G(3, 7, 11, 15, blk.m[B2_SIGMA[r][6]], blk.m[B2_SIGMA[r][7]])
+        B2G(0, 5, 10, 15, blk.m[B2_SIGMA[r][8]], blk.m[B2_SIGMA[r][9]])
+        B2G(1, 6, 11, 12, blk.m[B2_SIGMA[r][10]], blk.m[B2_SIGMA[r][11]])
+        B2G(2, 7, 8, 13, blk.m[B2_SIGMA[r][12]], blk.m[B2_SIGMA[r][13]])
+        B2G(3, 4, 9, 14, blk.m[B2_SIGMA[r][14]], blk.m[B2_SIGMA[r][15]])
+    }
+#undef B2G
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+}
+
+// Running transcript hash of one lane.  The 128-byte block buffer lives in LDS, dword d of lane l at
+// sbuf[d*64 + l] (conflict-free); fill level and byte counter are identical in every lane (the proof layout is
+// static), so they are wave-uniform scalars.
+struct Transcript {
+    uint64_t h[8];
+    uint32_t t;       // bytes already compressed
+    uint32_t buflen;  // bytes waiting in the LDS block
+};
+
+H2V_DI void tr_load_block(B2Msg &blk, const uint32_t *sbuf, int lane, uint32_t valid_bytes) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        uint32_t lo = sbuf[(2 * k) * 64 + lane], hi = sbuf[(2 * k + 1) * 64 + lane];
+        uint32_t b0 = 8 * k, b1 = 8 * k + 4;
+        if (valid_bytes < b0 + 4) lo = valid_bytes <= b0 ? 0u : (lo & ((1u << (8 * (valid_bytes - b0))) - 1u));
+        if (valid_bytes < b1 + 4) hi = valid_bytes <= b1 ? 0u : (hi & ((1u << (8 * (valid_bytes - b1))) - 1u));
+        blk.m[k] = (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+}
+H2V_DI void tr_init(Transcript &s) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.h[i] = B2_IV[i];
+    s.h[0] ^= 0x01010000ull ^ 32ull;  // digest 32, key 0, fanout 1, depth 1 (blake2b_simd Params::new().hash_length(32))
+    s.t = 0;
+    s.buflen = 0;
+}
+H2V_DI void tr_put(Transcript &s, uint32_t *sbuf, int lane, uint32_t byte) {
+    if (s.buflen == 128) {  // full and more input follows: not the last block
+        B2Msg blk;
+        tr_load_block(blk, sbuf, lane, 128);
+        s.t += 128;
+        b2_compress(s.h, blk, s.t, false);
+        s.buflen = 0;
+    }
+    reinterpret_cast<uint8_t *>(&sbuf[(s.buflen >> 2) * 64 + lane])[s.buflen & 3] = (uint8_t)byte;
+    s.buflen++;
+}
+// digest of everything absorbed so far, leaving the running state untouched (State::finalize on a clone)
+H2V_DI void tr_digest(const Transcript &s, const uint32_t *sbuf, int lane, uint64_t (&out)[4]) {
+    uint64_t h[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = s.h[i];
+    B2Msg blk;
+    tr_load_block(blk, sbuf, lane, s.buflen);
+    b2_compress(h, blk, (uint64_t)s.t + s.buflen, true);
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = h[i];
+}
+H2V_DI void b2_hash32(const uint64_t (&in)[4], uint64_t (&out)[4]) {
+    uint64_t h[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = B2_IV[i];
+    h[0] ^= 0x01010000ull ^ 32ull;
+    B2Msg blk;
+#pragma unroll
+    for (int k = 0; k < 16; k++) blk.m[k] = k < 4 ? in[k] : 0ull;
+    b2_compress(h, blk, 32, true);
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = h[i];
+}
+
+// ============================================================================ K1+K3: transcript + Fr combiner
+// Register file in global memory: limb l of register r of proof i at regs[(r*8 + l)*stride + i]
+// (lanes of a wave touch consecutive dwords).
+H2V_DI void reg_load(Fr &v, const uint32_t *regs, uint32_t r, uint32_t stride, uint32_t i) {
+#pragma unroll
+    for (int l = 0; l < 8; l++) v.v[l] = regs[(size_t)(r * 8 + l) * stride + i];
+}
+H2V_DI void reg_store(uint32_t *regs, uint32_t r, uint32_t stride, uint32_t i, const Fr &v) {
+#pragma unroll
+    for (int l = 0; l < 8; l++) regs[(size_t)(r * 8 + l) * stride + i] = v.v[l];
+}
+H2V_DI void fr_const(Fr &v, const uint32_t *c) {
+#pragma unroll
+    for (int l = 0; l < 8; l++) v.v[l] = c[l];
+}
+// absorb 0x01 || 32 little-endian bytes of a canonical (non-Montgomery) scalar
+H2V_DI void tr_absorb_scalar(Transcript &s, uint32_t *sbuf, int lane, const Fr &plain) {
+    tr_put(s, sbuf, lane, 1);
+#pragma unroll 1
+    for (int k = 0; k < 32; k++) tr_put(s, sbuf, lane, (plain.v[k >> 2] >> (8 * (k & 3))) & 0xff);
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_t *__restrict__ proofs,
+                      const uint64_t *__restrict__ proof_off, const uint8_t *__restrict__ instances,
+                      const uint8_t *__restrict__ committed, uint32_t *__restrict__ regs,
+                      uint32_t *__restrict__ scalars, uint32_t *__restrict__ status, uint32_t *__restrict__ trace) {
+    __shared__ uint32_t sbuf[32 * 64];
+    const int lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * 64 + lane;
+    const bool live = i < n;
+    const uint32_t ii = live ? i : n - 1;  // dead lanes shadow the last proof (keeps control flow uniform), never write
+    const uint64_t off0 = proof_off[ii];
+    const uint64_t plen = proof_off[ii + 1] - off0;
+    uint32_t st = 0;
+    const bool short_proof = plen < plan.proof_len;
+    if (short_proof) st |= H2V_ST_SHORT_PROOF;
+    // a short proof is rejected up front; its lane replays a zero-length-safe window (no out-of-bounds reads)
+    const uint8_t *proof = proofs + off0;
+    Transcript tr;
+    tr_init(tr);
+    Fr a, b, r;
+    for (uint32_t pc = 0; pc < plan.n_instr; pc++) {
+        const H2vInstr ins = plan.instr[pc];
+        if (ins.op == H2V_OP_END) break;
+        switch (ins.op) {
+        case H2V_OP_ABSORB_REG: {
+            reg_load(a, regs, ins.a, stride, ii);
+            FrF::from_mont(b, a);
+            tr_absorb_scalar(tr, sbuf, lane, b);
+        } break;
+        case H2V_OP_ABSORB_CI: {
+            tr_put(tr, sbuf, lane, 1);
+#pragma unroll 1
+            for (int k = 0; k < 48; k++) tr_put(tr, sbuf, lane, committed[(size_t)ii * 48 + k]);
+        } break;
+        case H2V_OP_LOAD_INSTANCE: {
+            const uint8_t *p = instances + ((size_t)ii * plan.n_pi + ins.a) * 32;
+#pragma unroll
+            for (int l = 0; l < 8; l++)
+                b.v[l] = (uint32_t)p[4 * l] | ((uint32_t)p[4 * l + 1] << 8) | ((uint32_t)p[4 * l + 2] << 16) | ((uint32_t)p[4 * l + 3] << 24);
+            FrF::to_mont(r, b);  // public inputs are field elements handed over by the caller: reduced mod r
+            if (live) reg_store(regs, ins.dst, stride, i, r);
+        } break;
+        case H2V_OP_READ_POINT: {
+            const uint32_t off = (uint32_t)ins.a | ((uint32_t)ins.b << 16);
+            tr_put(tr, sbuf, lane, 1);
+#pragma unroll 1
+            for (int k = 0; k < 48; k++) tr_put(tr, sbuf, lane, short_proof ? 0u : proof[off + k]);
+        } break;
+        case H2V_OP_READ_SCALAR: {
+            const uint32_t off = (uint32_t)ins.a | ((uint32_t)ins.b << 16);
+            tr_put(tr, sbuf, lane, 1);
+#pragma unroll
+            for (int l = 0; l < 8; l++) b.v[l] = 0;
+#pragma unroll 1
+            for (int k = 0; k < 32; k++) {
+                const uint32_t byte = short_proof ? 0u : proof[off + k];
+                tr_put(tr, sbuf, lane, byte);
+                b.v[k >> 2] |= byte << (8 * (k & 3));
+            }
+            // canonical encodings only: the Rust reader (and Plinth's mkScalar, BlsTypes.hs:129-132) rejects >= r
+            if (FrF::geq_mod(b.v)) st |= H2V_ST_BAD_SCALAR;
+            FrF::to_mont(r, b);
+            if (live) reg_store(regs, ins.dst, stride, i, r);
+        } break;
+        case H2V_OP_SQUEEZE: {
+            // adjusted_types/mod.rs:44-71: update(0x00); h = finalize; h2 = blake2b256(h);
+            // challenge = from_uniform_bytes(h || h2) = LE(h) + LE(h2) * 2^256 mod r   (transcript.ak:85-106)
+            tr_put(tr, sbuf, lane, 0);
+            uint64_t h[4], h2[4];
+            tr_digest(tr, sbuf, lane, h);
+            b2_hash32(h, h2);
+            Fr lo, hi, k;
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                lo.v[2 * l] = (uint32_t)h[l]; lo.v[2 * l + 1] = (uint32_t)(h[l] >> 32);
+                hi.v[2 * l] = (uint32_t)h2[l]; hi.v[2 * l + 1] = (uint32_t)(h2[l] >> 32);
+            }
+            FrF::to_mont(a, lo);
+            fr_const(k, FR_R3);
+            fr_mul(b, hi, k);  // hi * 2^768 / 2^256 = (hi * 2^256) * R
+            fr_add(r, a, b);
+            if (live) reg_store(regs, ins.dst, stride, i, r);
+        } break;
+        case H2V_OP_CONST: {
+            fr_const(r, plan.consts + (size_t)ins.a * 8);
+            if (live) reg_store(regs, ins.dst, stride, i, r);
+        } break;
+        case H2V_OP_ADD: case H2V_OP_SUB: case H2V_OP_MUL: {
+            reg_load(a, regs, ins.a, stride, ii);
+            reg_load(b, regs, ins.b, stride, ii);
+            if (ins.op == H2V_OP_ADD) fr_add(r, a, b);
+            else if (ins.op == H2V_OP_SUB) fr_sub(r, a, b);
+            else fr_mul(r, a, b);
+            if (live) reg_store(regs, ins.dst, stride, i, r);
+        } break;
+        case H2V_OP_NEG: {
+            reg_load(a, regs, ins.a, stride, ii);
+            FrF::neg(r, a);
+            if (live) reg_store(regs, ins.dst, stride, i, r);
+        } break;
+        case H2V_OP_INV: {
+            reg_load(a, regs, ins.a, stride, ii);
+            // recip_eea of zero divides by zero in the reference (bls_utils.ak:151-154) => reject
+            if (!fr_inv(r, a)) st |= H2V_ST_INVERSE_OF_ZERO;
+            if (live) reg_store(regs, ins.dst, stride, i, r);
+        } break;
+        case H2V_OP_OUT_SCALAR: {
+            reg_load(a, regs, ins.a, stride, ii);
+            FrF::from_mont(r, a);
+            if (live) {
+#pragma unroll
+                for (int l = 0; l < 8; l++) scalars[((size_t)i * plan.n_terms + ins.dst) * 8 + l] = r.v[l];
+            }
+        } break;
+        default: break;
+        }
+    }
+    if (live) {
+        status[i] = st;
+        if (trace) {
+            for (uint32_t k = 0; k < plan.n_trace; k++) {
+                reg_load(a, regs, plan.trace[2 * k + 1], stride, i);
+                FrF::from_mont(r, a);
+#pragma unroll
+                for (int l = 0; l < 8; l++) trace[((size_t)i * plan.n_trace + k) * 8 + l] = r.v[l];
+            }
+        }
+    }
+}
+
+// ============================================================================ K2: G1 decompression
+// zcash compressed encoding (bls_utils.ak:17-49, CompressUncompress.hs:53-100): bit7 compressed, bit6 infinity,
+// bit5 "y is the lexicographically larger root"; y = (x^3+4)^((p+1)/4).
+// One lane per (proof, point).  Slot n_points is the committed instance when the circuit has one.
+// out: affine Montgomery x||y (24 dwords, (0,0) = infinity); valid[...] = 1 iff the encoding is a point of G1.
+extern "C" __global__ void __launch_bounds__(64)
+k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
+                const uint8_t *__restrict__ committed, uint32_t *__restrict__ pts, uint8_t *__restrict__ valid) {
+    const uint32_t slots = plan.n_points + plan.n_ci;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * slots) return;
+    const uint32_t i = gid / slots, j = gid - i * slots;
+    const uint8_t *src;
+    if (j < plan.n_points) {
+        const uint64_t off0 = proof_off[i];
+        if (proof_off[i + 1] - off0 < plan.proof_len) { valid[gid] = 0; return; }  // short proof: nothing to read
+        src = proofs + off0 + plan.points[j];
+    } else {
+        src = committed + (size_t)i * 48;
+    }
+    uint32_t w[12];  // big-endian bytes -> little-endian limbs
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const uint8_t *p = src + 44 - 4 * k;
+        w[k] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+    }
+    const uint32_t flags = w[11] >> 29;
+    w[11] &= 0x1fffffffu;
+    G1A out;
+    g1a_set_inf(out);
+    bool ok = (flags & 4) != 0;
+    if (ok && (flags & 2)) {
+        // infinity: all other bits must be clear
+        uint32_t any = flags & 1;
+#pragma unroll
+        for (int k = 0; k < 12; k++) any |= w[k];
+        ok = any == 0;
+    } else if (ok) {
+        ok = !FpF::geq_mod(w);
+        if (ok) {
+            Fp x, y, t, b4;
+#pragma unroll
+            for (int k = 0; k < 12; k++) { t.v[k] = w[k]; b4.v[k] = FP_B[k]; }
+            FpF::to_mont(x, t);
+            fp_sqr(t, x); fp_mul(t, t, x); fp_add(t, t, b4);
+            fp_pow_const<12>(y, t, FP_SQRT_EXP);
+            Fp chk;
+            fp_sqr(chk, y);
+            ok = fp_eq(chk, t);
+            if (ok) {
+                if (fp_is_lex_larger(y) != ((flags & 1) != 0)) fp_neg(y, y);
+                out.x = x; out.y = y;
+                ok = g1a_in_subgroup(out);
+            }
+        }
+    }
+    if (!ok) g1a_set_inf(out);
+#pragma unroll
+    for (int k = 0; k < 12; k++) { pts[(size_t)gid * 24 + k] = out.x.v[k]; pts[(size_t)gid * 24 + 12 + k] = out.y.v[k]; }
+    valid[gid] = ok ? 1 : 0;
+}
+
+// ============================================================================ K4: per-proof G1 MSM
+// er = sum_t s_t * B_t with T = n_terms (16 ... ~60) 255-bit scalars per proof.  T is far too small for bucket
+// (Pippenger) accumulation to pay - 2^c buckets per window would outnumber the terms - so the mapping is:
+// one lane per (proof, term), MSB-first double-and-add with mixed additions on the affine base, then a
+// segmented tree reduction of the TP = 2^ceil(log2 T) partial sums of each proof through LDS.
+// Bytes per term: 32 (scalar) + 96 (affine base) in, 144 per proof out (Jacobian).
+#define MSM_BLOCK 64
+extern "C" __global__ void __launch_bounds__(MSM_BLOCK)
+k_g1_msm(H2vDevPlan plan, uint32_t n, uint32_t tp /* pow2 >= n_terms, <= 64 */, const uint32_t *__restrict__ scalars,
+         const uint32_t *__restrict__ pts, uint32_t *__restrict__ out) {
+    __shared__ uint32_t red[36 * MSM_BLOCK];  // Jacobian partial sums, dword d of lane l at red[d*64 + l]
+    const int tid = threadIdx.x;
+    const uint32_t per_block = MSM_BLOCK / tp;
+    const uint32_t term = tid % tp;
+    const uint32_t i = blockIdx.x * per_block + tid / tp;
+    const bool active = i < n && term < plan.n_terms;
+    G1J acc;
+    g1j_set_inf(acc);
+    if (active) {
+        // terms[] as uploaded by h2v_plan_load: kind is VK base (1) or per-proof slot (0); the committed instance has
+        // been rewritten to slot n_points there.  Two-way integer selects only: a nested three-way pointer select was
+        // miscompiled by ROCm 7.2 (the copy of i feeding the scalar address was left undefined on the third path).
+        const uint32_t kind = plan.terms[2 * term], idx = plan.terms[2 * term + 1];
+        const uint32_t slots = plan.n_points + plan.n_ci;
+        const bool is_vk = kind == H2V_TERM_VK_BASE;
+        const uint32_t *src = is_vk ? plan.vk_bases : pts;
+        const size_t elem = is_vk ? (size_t)idx : (size_t)i * slots + idx;
+        const uint32_t *bp = src + elem * 24;
+        G1A base;
+#pragma unroll
+        for (int k = 0; k < 12; k++) { base.x.v[k] = bp[k]; base.y.v[k] = bp[12 + k]; }
+        uint32_t s[8];
+        const uint32_t *sp = scalars + ((size_t)i * plan.n_terms + term) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = sp[k];
+        if (!g1a_is_inf(base)) {
+            for (int bit = 254; bit >= 0; bit--) {
+                g1j_dbl(acc, acc);
+                if ((s[bit >> 5] >> (bit & 31)) & 1) g1j_add_affine(acc, acc, base);
+            }
+        }
+    }
+    // segmented reduction over the tp lanes of each proof
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        red[k * 64 + tid] = acc.x.v[k];
+        red[(12 + k) * 64 + tid] = acc.y.v[k];
+        red[(24 + k) * 64 + tid] = acc.z.v[k];
+    }
+    __syncthreads();
+    for (uint32_t s = tp >> 1; s >= 1; s >>= 1) {
+        if (term < s) {
+            G1J other;
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                other.x.v[k] = red[k * 64 + tid + s];
+                other.y.v[k] = red[(12 + k) * 64 + tid + s];
+                other.z.v[k] = red[(24 + k) * 64 + tid + s];
+            }
+            g1j_add(acc, acc, other);
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                red[k * 64 + tid] = acc.x.v[k];
+                red[(12 + k) * 64 + tid] = acc.y.v[k];
+                red[(24 + k) * 64 + tid] = acc.z.v[k];
+            }
+        }
+        __syncthreads();
+    }
+    if (term == 0 && i < n) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            out[(size_t)i * 36 + k] = acc.x.v[k];
+            out[(size_t)i * 36 + 12 + k] = acc.y.v[k];
+            out[(size_t)i * 36 + 24 + k] = acc.z.v[k];
+        }
+    }
+}
+
+// ============================================================================ K5: pairing check
+// accept <=> e(el, s_g2) == e(er, G2)  (verification_h2.hbs:125-128), evaluated as
+//   FE( ML(el; lines(s_g2)) * ML(-er; lines(G2)) ) == 1 .
+// Both G2 arguments are fixed per plan, so their Miller-loop line coefficients (lambda, c) are precomputed at
+// plan-compile time; with the untwist (x,y)->(x/w^2, y/w^3) a line at P=(xP,yP), scaled by w^3 (subfield
+// element, killed by the final exponentiation), is  c + (-lambda xP) w^2 + yP w^3.
+// Final exponentiation: easy part (p^6-1)(p^2+1); hard part via
+//   3 (p^4-p^2+1)/r = (x-1)^2 (x+p)(x^2+p^2-1) + 3      (factor 3 is coprime to r: "== 1" unchanged).
+H2V_DI void load_line(Fp2 &lam, Fp2 &c, const uint32_t *tab, int idx) {
+    const uint32_t *p = tab + (size_t)idx * 48;
+#pragma unroll
+    for (int k = 0; k < 12; k++) { lam.c0.v[k] = p[k]; lam.c1.v[k] = p[12 + k]; c.c0.v[k] = p[24 + k]; c.c1.v[k] = p[36 + k]; }
+}
+H2V_DN void miller_loop(Fp12 &f, const G1A &p1, const uint32_t *lines1, bool skip1, const G1A &p2, const uint32_t *lines2, bool skip2) {
+    fp12_set_one(f);
+    int n = 0;
+    Fp2 lam, c, b;
+    for (int i = 62; i >= 0; i--) {
+        fp12_sqr(f, f);
+        const int steps = ((BLS_X_ABS >> i) & 1) ? 2 : 1;
+        for (int s = 0; s < steps; s++) {
+            if (!skip1) {
+                load_line(lam, c, lines1, n);
+                fp2_mul_fp(b, lam, p1.x); fp2_neg(b, b);
+                fp12_mul_line(f, c, b, p1.y);
+            }
+            if (!skip2) {
+                load_line(lam, c, lines2, n);
+                fp2_mul_fp(b, lam, p2.x); fp2_neg(b, b);
+                fp12_mul_line(f, c, b, p2.y);
+            }
+            n++;
+        }
+    }
+    fp12_conj(f, f);  // x < 0
+}
+// a^x for a in the cyclotomic subgroup (x negative: conjugate)
+H2V_DN void fp12_exp_x(Fp12 &r, const Fp12 &a) {
+    Fp12 acc = a;
+    for (int i = 62; i >= 0; i--) {
+        fp12_sqr(acc, acc);
+        if ((BLS_X_ABS >> i) & 1) fp12_mul(acc, acc, a);
+    }
+    fp12_conj(r, acc);
+}
+H2V_DN bool final_exp_is_one(const Fp12 &f) {
+    Fp12 t, a, u, t0, t1, t2, t3;
+    if (!fp12_inv(a, f)) return false;
+    fp12_conj(t, f); fp12_mul(t, t, a);                       // f^(p^6-1)
+    fp12_frob(a, t); fp12_frob(a, a); fp12_mul(t, a, t);      // ^(p^2+1)
+    fp12_exp_x(a, t); fp12_conj(u, t); fp12_mul(t0, a, u);    // t^(x-1)
+    fp12_exp_x(a, t0); fp12_conj(u, t0); fp12_mul(t1, a, u);  // ^(x-1)
+    fp12_exp_x(a, t1); fp12_frob(u, t1); fp12_mul(t2, a, u);  // ^(x+p)
+    fp12_exp_x(a, t2); fp12_exp_x(a, a);
+    fp12_frob(u, t2); fp12_frob(u, u); fp12_mul(t3, a, u);
+    fp12_conj(u, t2); fp12_mul(t3, t3, u);                    // ^(x^2+p^2-1)
+    fp12_sqr(u, t); fp12_mul(u, u, t);                        // t^3
+    fp12_mul(t3, t3, u);
+    return fp12_is_one(t3);
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+k_pairing_check(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid,
+                const uint32_t *__restrict__ er_jac, uint32_t *__restrict__ status, uint8_t *__restrict__ accept) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slots = plan.n_points + plan.n_ci;
+    uint32_t st = status[i];
+    for (uint32_t j = 0; j < slots; j++)
+        if (!valid[(size_t)i * slots + j]) st |= H2V_ST_BAD_POINT;
+    if (st == 0) {
+        G1A el, er;
+        G1J ej;
+        const uint32_t *pp = pts + ((size_t)i * slots + plan.pi_point) * 24;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            el.x.v[k] = pp[k]; el.y.v[k] = pp[12 + k];
+            ej.x.v[k] = er_jac[(size_t)i * 36 + k]; ej.y.v[k] = er_jac[(size_t)i * 36 + 12 + k]; ej.z.v[k] = er_jac[(size_t)i * 36 + 24 + k];
+        }
+        g1j_to_affine(er, ej);
+        const bool el_inf = g1a_is_inf(el), er_inf = g1a_is_inf(er);
+        fp_neg(er.y, er.y);  // -er (harmless on the infinity sentinel: skipped below)
+        Fp12 f;
+        miller_loop(f, el, plan.lines_sg2, el_inf, er, plan.lines_g2, er_inf);
+        if (!final_exp_is_one(f)) st |= H2V_ST_PAIRING;
+    }
+    status[i] = st;
+    accept[i] = st == 0 ? 1 : 0;
+}
+
+// ============================================================================ primitive probes (parity tests)
+// op: 0 fp_mul, 1 fp_add, 2 fp_sub, 3 fp_inv, 4 fr_mul, 5 fr_inv (a, b canonical little-endian limbs; 12 or 8)
+extern "C" __global__ void k_probe_field(int op, uint32_t n, const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                         uint32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (op < 4) {
+        Fp x, y, r;
+#pragma unroll
+        for (int k = 0; k < 12; k++) { x.v[k] = a[(size_t)i * 12 + k]; y.v[k] = b[(size_t)i * 12 + k]; }
+        FpF::to_mont(x, x); FpF::to_mont(y, y);
+        if (op == 0) fp_mul(r, x, y);
+        else if (op == 1) fp_add(r, x, y);
+        else if (op == 2) fp_sub(r, x, y);
+        else fp_inv(r, x);
+        FpF::from_mont(r, r);
+#pragma unroll
+        for (int k = 0; k < 12; k++) out[(size_t)i * 12 + k] = r.v[k];
+    } else {
+        Fr x, y, r;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { x.v[k] = a[(size_t)i * 8 + k]; y.v[k] = b[(size_t)i * 8 + k]; }
+        FrF::to_mont(x, x); FrF::to_mont(y, y);
+        if (op == 4) fr_mul(r, x, y);
+        else fr_inv(r, x);
+        FrF::from_mont(r, r);
+#pragma unroll
+        for (int k = 0; k < 8; k++) out[(size_t)i * 8 + k] = r.v[k];
+    }
+}
+// blake2b-256 of n messages of `len` bytes each through the LDS transcript path (one message per lane)
+extern "C" __global__ void __launch_bounds__(64)
+k_probe_blake2b(uint32_t n, uint32_t len, const uint8_t *__restrict__ msgs, uint32_t *__restrict__ out) {
+    __shared__ uint32_t sbuf[32 * 64];
+    const int lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * 64 + lane;
+    const uint32_t ii = i < n ? i : n - 1;
+    Transcript tr;
+    tr_init(tr);
+    for (uint32_t k = 0; k < len; k++) tr_put(tr, sbuf, lane, msgs[(size_t)ii * len + k]);
+    uint64_t h[4];
+    tr_digest(tr, sbuf, lane, h);
+    if (i < n) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { out[(size_t)i * 8 + 2 * k] = (uint32_t)h[k]; out[(size_t)i * 8 + 2 * k + 1] = (uint32_t)(h[k] >> 32); }
+    }
+}
+
+// affine (24 dwords) or Jacobian (36 dwords) Montgomery points -> 96 bytes x||y big-endian canonical (zero = infinity)
+extern "C" __global__ void k_export_points(uint32_t n, int jacobian, const uint32_t *__restrict__ in, uint8_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1A a;
+    if (jacobian) {
+        G1J j;
+#pragma unroll
+        for (int k = 0; k < 12; k++) { j.x.v[k] = in[(size_t)i * 36 + k]; j.y.v[k] = in[(size_t)i * 36 + 12 + k]; j.z.v[k] = in[(size_t)i * 36 + 24 + k]; }
+        g1j_to_affine(a, j);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; k++) { a.x.v[k] = in[(size_t)i * 24 + k]; a.y.v[k] = in[(size_t)i * 24 + 12 + k]; }
+    }
+    Fp x, y;
+    FpF::from_mont(x, a.x);
+    FpF::from_mont(y, a.y);
+    uint8_t *o = out + (size_t)i * 96;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const uint32_t wx = x.v[11 - k], wy = y.v[11 - k];
+        o[4 * k] = wx >> 24; o[4 * k + 1] = wx >> 16; o[4 * k + 2] = wx >> 8; o[4 * k + 3] = wx;
+        o[48 + 4 * k] = wy >> 24; o[48 + 4 * k + 1] = wy >> 16; o[48 + 4 * k + 2] = wy >> 8; o[48 + 4 * k + 3] = wy;
+    }
+}

@@ -1,0 +1,55 @@
+// Binary verifier-plan layout shared by the plan compiler (plan.py: Plan.to_bytes) and the HIP backend.
+// The plan is this build's "VerifyingKey surface": the reference's InstantiationSpecificData
+// (/root/reference/src/plutus_gen/extraction/data/circuit_types/instantiation_data.rs:26-41) plus the
+// straight-line verifier program that `extract_circuit` + the emitters would have rendered as source text.
+#pragma once
+#include <stdint.h>
+
+#define H2V_PLAN_MAGIC "H2VPLAN1"
+#define H2V_PLAN_VERSION 1u
+#define H2V_PLAN_HDR_WORDS 24
+#define H2V_MILLER_LINES 68  // 63 doublings + 5 additions for |x| = 0xd201000000010000
+
+// header words (uint32 little-endian) after the 8-byte magic
+enum {
+    H2V_HW_VERSION = 0, H2V_HW_PROOF_LEN, H2V_HW_N_PI, H2V_HW_N_CI, H2V_HW_N_REGS, H2V_HW_N_INSTR, H2V_HW_N_CONSTS,
+    H2V_HW_N_POINTS, H2V_HW_N_VK_BASES, H2V_HW_N_TERMS, H2V_HW_N_TRACE, H2V_HW_PI_POINT, H2V_HW_N_SQUEEZES,
+    H2V_HW_STREAM_LEN,
+    H2V_HW_OFF_INSTR, H2V_HW_OFF_CONSTS, H2V_HW_OFF_POINTS, H2V_HW_OFF_VK_BASES, H2V_HW_OFF_TERMS, H2V_HW_OFF_LINES_SG2,
+    H2V_HW_OFF_LINES_G2, H2V_HW_OFF_TRACE, H2V_HW_TOTAL_LEN
+};
+
+// opcodes of the transcript + Fr-combiner program (8-byte instructions: op, pad, dst, a, b)
+enum {
+    H2V_OP_END = 0, H2V_OP_ABSORB_REG, H2V_OP_ABSORB_CI, H2V_OP_LOAD_INSTANCE, H2V_OP_READ_POINT, H2V_OP_READ_SCALAR,
+    H2V_OP_SQUEEZE, H2V_OP_CONST, H2V_OP_ADD, H2V_OP_SUB, H2V_OP_MUL, H2V_OP_NEG, H2V_OP_INV, H2V_OP_OUT_SCALAR,
+    H2V_OP_COUNT
+};
+enum { H2V_TERM_PROOF_POINT = 0, H2V_TERM_VK_BASE = 1, H2V_TERM_COMMITTED_INSTANCE = 2 };
+
+// per-proof status bits produced on the device: H2V_ST_* of include/h2v.h (0 = nothing wrong so far)
+#ifndef H2V_ST_BAD_SCALAR
+#define H2V_ST_BAD_SCALAR 1u
+#define H2V_ST_INVERSE_OF_ZERO 2u
+#define H2V_ST_SHORT_PROOF 4u
+#define H2V_ST_BAD_POINT 8u
+#define H2V_ST_PAIRING 16u
+#endif
+
+struct H2vInstr {
+    uint8_t op, pad;
+    uint16_t dst, a, b;
+};
+
+// device view of a loaded plan (all pointers are device pointers)
+struct H2vDevPlan {
+    uint32_t proof_len, n_pi, n_ci, n_regs, n_instr, n_consts, n_points, n_vk_bases, n_terms, n_trace, pi_point;
+    const H2vInstr *instr;
+    const uint32_t *consts;    // n_consts * 8   (Fr, Montgomery)
+    const uint32_t *points;    // n_points       (byte offset in the proof)
+    const uint32_t *vk_bases;  // n_vk_bases * 24 (affine x||y, Montgomery; all-zero = infinity)
+    const uint32_t *terms;     // n_terms * 2    (kind, index)
+    const uint32_t *lines_sg2; // 68 * 48        (lambda.c0, lambda.c1, c.c0, c.c1)
+    const uint32_t *lines_g2;
+    const uint32_t *trace;     // n_trace * 2    (slot id, register)
+};

@@ -1,0 +1,186 @@
+"""GPU parity tests (run with -m gpu on the MI355X box).  Everything goes through the C-ABI (libh2v_hip.so) and is
+compared bit-for-bit with the CPU oracle / the reference golden vectors.  /root/reference is NOT needed."""
+import hashlib
+import json
+import random
+
+import pytest
+
+from plutus_halo2_verifier_gen_amd import bls12_381 as bls
+
+pytestmark = pytest.mark.gpu
+P, R = bls.P, bls.R
+
+
+@pytest.fixture(scope="module")
+def be():
+    from plutus_halo2_verifier_gen_amd import backend
+    assert backend.device_count() >= 1, "no GPU visible"
+    return backend
+
+
+@pytest.fixture(scope="module")
+def circuits():
+    """name -> (vk, trapdoor, plan, device plan, oracle vk)"""
+    from plutus_halo2_verifier_gen_amd import backend, plan as PL, vk as V
+    from oracle import binding as orc
+    out = {}
+    for name, build in V.BUILDERS.items():
+        vk, td = build()
+        pl = PL.compile_plan(vk)
+        dp = backend.DevicePlan(pl.to_bytes(), 0)
+        ov = orc.OracleVK(orc.vk_desc(json.loads(vk.to_json()), vk.omega, vk.omega_inv, vk.barycentric_weight))
+        out[name] = (vk, td, pl, dp, ov)
+    return out
+
+
+def test_field_ops(be):
+    rng = random.Random(1)
+    edge = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, (1 << 380), (1 << 381) - 1 - ((1 << 381) - 1 >= P) * ((1 << 381) - P)]
+    a = edge + [rng.randrange(P) for _ in range(200)]
+    b = list(reversed(edge)) + [rng.randrange(P) for _ in range(200)]
+    assert be.probe_field(0, a, b) == [x * y % P for x, y in zip(a, b)]
+    assert be.probe_field(1, a, b) == [(x + y) % P for x, y in zip(a, b)]
+    assert be.probe_field(2, a, b) == [(x - y) % P for x, y in zip(a, b)]
+    inv = be.probe_field(3, a, b)
+    assert inv == [pow(x, P - 2, P) if x else 0 for x in a]
+    edge_r = [0, 1, 2, R - 1, R - 2, (R - 1) // 2, 1 << 254]
+    a = edge_r + [rng.randrange(R) for _ in range(200)]
+    b = list(reversed(edge_r)) + [rng.randrange(R) for _ in range(200)]
+    assert be.probe_field(4, a, b) == [x * y % R for x, y in zip(a, b)]
+    assert be.probe_field(5, a, b) == [pow(x, R - 2, R) if x else 0 for x in a]
+
+
+def test_blake2b(be):
+    rng = random.Random(2)
+    for ln in [0, 1, 31, 32, 33, 64, 127, 128, 129, 255, 256, 257, 1000, 1325]:
+        msgs = [bytes(rng.randrange(256) for _ in range(ln)) for _ in range(70)]
+        assert be.probe_blake2b(msgs) == [hashlib.blake2b(m, digest_size=32).digest() for m in msgs]
+
+
+def test_g1_decompress(be, orc, kats):
+    rng = random.Random(3)
+    cases = [bytes.fromhex(kats[k]) for k in ("point_generator", "point_neg_generator", "point_42g")]
+    proof = bytes.fromhex(kats["simple_mul_full"]["proof"])
+    cases += [proof[48 * i:48 * i + 48] for i in range(8)]           # the golden proof's leading G1 elements
+    cases += [bls.g1_compress(bls.g1_mul(bls.G1_GEN, rng.randrange(1, R))) for _ in range(20)]
+    gen = bls.g1_compress(bls.G1_GEN)
+    cases += [bytes([gen[0] & 0x7F]) + gen[1:], bytes([0xC0]) + bytes(47), bytes([0xE0]) + bytes(47),
+              bytes([0xC0]) + bytes(46) + b"\x01", bytes([0x9F]) + b"\xff" * 47, bytes([0x80]) + bytes(47)]
+    for _ in range(40):                                               # random x: off-curve / on-curve-not-in-subgroup
+        raw = bytearray(rng.randrange(P).to_bytes(48, "big"))
+        raw[0] |= 0x80 | (0x20 if rng.random() < 0.5 else 0)
+        cases.append(bytes(raw))
+    got = be.probe_g1_decompress(cases)
+    for c, (ok, pt) in zip(cases, got):
+        ook, opt = orc.g1_decompress(c)
+        assert ok == ook, c.hex()
+        if ok:
+            assert pt == opt, c.hex()
+
+
+def test_g1_msm(be, orc):
+    rng = random.Random(4)
+    for T in (1, 2, 5, 16, 34, 58, 64):
+        groups_s, groups_b, pts = [], [], []
+        for g in range(5):
+            ps = [bls.g1_mul(bls.G1_GEN, rng.randrange(1, R)) for _ in range(T)]
+            ss = [rng.randrange(R) for _ in range(T)]
+            if g == 1:
+                ss[0] = 0
+                ss[-1] = R - 1
+            if g == 2 and T >= 2:
+                ps[1] = ps[0]                     # equal bases: the reduction must double
+                ss[1] = ss[0]
+            if g == 3 and T >= 2:
+                ps[1] = bls.g1_neg(ps[0])         # opposite bases with equal scalars: partial sums cancel
+                ss[1] = ss[0]
+            if g == 4:
+                ps[0] = None                      # infinity base
+            groups_s.append(ss)
+            pts.append(ps)
+            groups_b.append([bls.g1_compress(p) for p in ps])
+        got = be.probe_g1_msm(groups_s, groups_b)
+        for ss, ps, r in zip(groups_s, pts, got):
+            assert r == orc.g1_msm(ss, ps)
+
+
+def test_pairing(be, orc, circuits):
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    rng = random.Random(5)
+    s = td.s
+    p1, p2, want = [], [], []
+    for k in range(6):
+        a = rng.randrange(1, R)
+        A = bls.g1_mul(bls.G1_GEN, a)
+        sA = bls.g1_mul(A, s)
+        if k % 3 == 2:
+            sA = bls.g1_add(sA, bls.G1_GEN)
+        p1.append(bls.g1_compress(A))
+        p2.append(bls.g1_compress(sA))
+        want.append(orc.pairing_check(A, bytes.fromhex(vk.s_g2), sA, orc.g2_generator_compressed()))
+    p1 += [bls.g1_compress(None), bls.g1_compress(bls.G1_GEN), bls.g1_compress(None)]
+    p2 += [bls.g1_compress(None), bls.g1_compress(None), bls.g1_compress(bls.G1_GEN)]
+    want += [1, 0, 0]
+    assert be.probe_pairing(dp, p1, p2) == want
+    assert want[:6] == [1, 1, 0, 1, 1, 0]
+
+
+TRACE_NAMES = ["theta", "beta", "gamma", "trash", "y", "x", "x1", "x2", "x3", "x4", "x_prev", "x_next", "x_last", "xn",
+               "l_last", "l_0", "active_rows", "h_eval", "vanishing_s", "f_eval", "v"]
+
+
+@pytest.mark.parametrize("name", ["simple_mul", "lookup_table", "atms_with_lookups", "sha256", "secp256k1"])
+def test_end_to_end_vs_oracle(be, circuits, name):
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits[name]
+    n = 48
+    batch = synth.forge_batch(vk, td, n, seed=21, plan=pl, workers=1)
+    batch = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.4, seed=9, kinds=list(synth.CORRUPTIONS))
+    got = dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed)
+    want = ov.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, threads=8)
+    assert list(got) == list(want) == batch.expected
+    assert 0 < sum(got) < n
+    # intermediate values (the reference's plutus_debug trace surface) for one accepting and one rejecting proof
+    for i in (batch.expected.index(1), batch.expected.index(0)):
+        proof = batch.proof(i)
+        inst = batch.instances[32 * vk.n_public_inputs * i:32 * vk.n_public_inputs * (i + 1)]
+        ok, otr = ov.verify(proof, batch.instance_ints(i, vk.n_public_inputs), batch.ci(i), trace=True)
+        tr = dp.trace(proof, inst, batch.ci(i))
+        assert tr["accept"] == int(ok)
+        if otr.status in (0, 1):  # the oracle fills its trace only when it reaches the pairing
+            for slot, val in tr["scalars"].items():
+                if slot < 32:
+                    assert val == otr.scalar(TRACE_NAMES[slot]), TRACE_NAMES[slot]
+                else:
+                    assert val == otr.expression(slot - 32), "expression %d" % (slot - 32)
+            assert tr["el"] == otr.point("el") and tr["er"] == otr.point("er")
+
+
+def test_golden_transcript_on_gpu(be, kats, circuits):
+    """The reference's full simple_mul proof (transcript.ak:241-382) replayed by the GPU transcript kernel.  The golden
+    proof predates the `trash` squeeze (proof.rs:68), so only the challenges squeezed before it are comparable:
+    theta/beta/gamma depend on repr, inputs and the first two commitments alone."""
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    k = kats["simple_mul_full"]
+    proof = bytes.fromhex(k["proof"])
+    inst = b"".join((42).to_bytes(32, "little") for _ in range(3))
+    tr = dp.trace(proof, inst, None)
+    assert tr["scalars"][TRACE_NAMES.index("gamma")] == int(k["gamma"], 16)
+    assert tr["accept"] == 0   # (different VK / layout: must not verify)
+
+
+def test_api_errors(be, circuits):
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    blob = pl.to_bytes()
+    with pytest.raises(be.H2VError):
+        be.DevicePlan(blob[:-8], 0)
+    with pytest.raises(be.H2VError):
+        be.DevicePlan(b"XXXXXXXX" + blob[8:], 0)
+    bad = bytearray(blob)
+    bad[8 + 4 * 4] = 1  # n_regs = 1: instructions out of range
+    bad[8 + 4 * 4 + 1] = 0
+    with pytest.raises(be.H2VError):
+        be.DevicePlan(bytes(bad), 0)
+    # empty batch is fine
+    assert dp.verify_batch(b"", [0], b"", None) == b""
