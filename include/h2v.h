@@ -72,6 +72,9 @@ int h2v_plan_info(const h2v_plan *plan, uint32_t *proof_len, uint32_t *n_public_
 
 int h2v_workspace_create(const h2v_plan *plan, uint64_t max_batch, h2v_workspace **out);
 void h2v_workspace_free(h2v_workspace *ws);
+/* Per-kernel device times of a past call that used `ws` (calls_back = 0: the most recent; up to 63 back), from HIP
+ * events recorded on the streams the kernels ran on.  Synchronise the launch stream before asking. */
+int h2v_workspace_timings(h2v_workspace *ws, uint32_t calls_back, h2v_timings *out);
 
 /* ---- verification (replaces prepare + Guard::verify / DualMSM::check) --------------------------------------
  * Host-buffer form: copies the batch to the device, verifies, copies accept[] (n bytes, 1 = accept) back.

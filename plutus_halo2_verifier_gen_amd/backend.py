@@ -31,6 +31,7 @@ class Timings(C.Structure):
 
 EXPORTS = [
     "h2v_plan_load", "h2v_plan_free", "h2v_plan_info", "h2v_workspace_create", "h2v_workspace_free",
+    "h2v_workspace_timings",
     "h2v_verify_batch", "h2v_verify_batch_device", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
     "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_pairing", "h2v_last_error",
     "h2v_device_count",
@@ -53,6 +54,7 @@ def lib():
         L.h2v_plan_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4
         L.h2v_workspace_create.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         L.h2v_workspace_free.argtypes = [C.c_void_p]
+        L.h2v_workspace_timings.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Timings)]
         L.h2v_verify_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
         L.h2v_verify_batch_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.POINTER(Timings)]
@@ -159,6 +161,11 @@ class Workspace:
     @property
     def handle(self):
         return self._h
+
+    def timings(self, calls_back: int = 0) -> Timings:
+        tm = Timings()
+        check(lib().h2v_workspace_timings(self._h, calls_back, C.byref(tm)))
+        return tm
 
     def close(self):
         if getattr(self, "_h", None):

@@ -51,7 +51,12 @@ struct h2v_workspace {
     uint64_t *in_off = nullptr;
     size_t in_proofs_cap = 0, in_inst_cap = 0, in_ci_cap = 0, in_off_cap = 0;
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // ring of per-call event sets: [0]/[1] around the transcript+combiner kernel (main stream), [2]/[3] around the
+    // decompression kernel (side stream), [4]/[5] around the MSM, [5]/[6] around the pairing kernel (main stream)
+    static constexpr int RING = 64, NEV = 7;
+    hipEvent_t ring[RING][NEV] = {};
+    uint64_t calls = 0;
 };
 
 static uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -195,7 +200,7 @@ static void ws_release(h2v_workspace *w) {
     if (w->side) (void)hipStreamDestroy(w->side);
     if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
     if (w->ev_join) (void)hipEventDestroy(w->ev_join);
-    for (hipEvent_t e : w->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &set : w->ring) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
 }
 static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bool with_trace, h2v_workspace **out) {
     if (max_batch == 0 || max_batch > (1ull << 24)) return fail(H2V_E_ARG, "max_batch out of range");
@@ -218,8 +223,8 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
 #undef WSALLOC
     if (hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess) { ws_release(w); delete w; return fail(H2V_E_DEVICE, "stream/event creation failed"); }
-    for (int k = 0; k < 5; k++)
-        if (hipEventCreate(&w->ev[k]) != hipSuccess) { ws_release(w); delete w; return fail(H2V_E_DEVICE, "event creation failed"); }
+    for (auto &set : w->ring) for (hipEvent_t &e : set)
+        if (hipEventCreate(&e) != hipSuccess) { ws_release(w); delete w; return fail(H2V_E_DEVICE, "event creation failed"); }
     *out = w;
     return H2V_OK;
 }
@@ -263,33 +268,33 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         if (status_out) HIPCHK(hipMemcpyAsync(status_out, status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         return H2V_OK;
     }
-    if (tm) {
-        HIPCHK(hipEventRecord(w->ev[0], st));
-        hipLaunchKernelGGL(k_transcript_combiner, dim3(vm_blocks), dim3(64), 0, st, d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace);
-        HIPCHK(hipEventRecord(w->ev[1], st));
-        hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(64), 0, st, d, n, proofs, off, ci, w->pts, w->valid);
-        HIPCHK(hipEventRecord(w->ev[2], st));
-    } else {
-        HIPCHK(hipEventRecord(w->ev_fork, st));
-        HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
-        hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(64), 0, w->side, d, n, proofs, off, ci, w->pts, w->valid);
-        HIPCHK(hipEventRecord(w->ev_join, w->side));
-        hipLaunchKernelGGL(k_transcript_combiner, dim3(vm_blocks), dim3(64), 0, st, d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace);
-        HIPCHK(hipStreamWaitEvent(st, w->ev_join, 0));
-    }
+    hipEvent_t *ev = w->ring[w->calls % h2v_workspace::RING];
+    w->calls++;
+    // fork: decompression (many short waves) runs beside the transcript+combiner kernel (few long waves)
+    HIPCHK(hipEventRecord(w->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
+    HIPCHK(hipEventRecord(ev[2], w->side));
+    hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(64), 0, w->side, d, n, proofs, off, ci, w->pts, w->valid);
+    HIPCHK(hipEventRecord(ev[3], w->side));
+    HIPCHK(hipEventRecord(w->ev_join, w->side));
+    HIPCHK(hipEventRecord(ev[0], st));
+    hipLaunchKernelGGL(k_transcript_combiner, dim3(vm_blocks), dim3(64), 0, st, d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace);
+    HIPCHK(hipEventRecord(ev[1], st));
+    HIPCHK(hipStreamWaitEvent(st, w->ev_join, 0));
+    HIPCHK(hipEventRecord(ev[4], st));
     hipLaunchKernelGGL(k_g1_msm, dim3(msm_blocks), dim3(MSM_BLOCK), 0, st, d, n, tp, w->scalars, w->pts, w->er);
-    if (tm) HIPCHK(hipEventRecord(w->ev[3], st));
+    HIPCHK(hipEventRecord(ev[5], st));
     hipLaunchKernelGGL(k_pairing_check, dim3(pair_blocks), dim3(64), 0, st, d, n, w->pts, w->valid, w->er, status, accept);
-    if (tm) HIPCHK(hipEventRecord(w->ev[4], st));
+    HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
     if (status_out) HIPCHK(hipMemcpyAsync(status_out, status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
     if (tm) {
         HIPCHK(hipStreamSynchronize(st));
-        HIPCHK(hipEventElapsedTime(&tm->transcript_combiner_ms, w->ev[0], w->ev[1]));
-        HIPCHK(hipEventElapsedTime(&tm->g1_decompress_ms, w->ev[1], w->ev[2]));
-        HIPCHK(hipEventElapsedTime(&tm->g1_msm_ms, w->ev[2], w->ev[3]));
-        HIPCHK(hipEventElapsedTime(&tm->pairing_ms, w->ev[3], w->ev[4]));
-        HIPCHK(hipEventElapsedTime(&tm->total_ms, w->ev[0], w->ev[4]));
+        HIPCHK(hipEventElapsedTime(&tm->transcript_combiner_ms, ev[0], ev[1]));
+        HIPCHK(hipEventElapsedTime(&tm->g1_decompress_ms, ev[2], ev[3]));
+        HIPCHK(hipEventElapsedTime(&tm->g1_msm_ms, ev[4], ev[5]));
+        HIPCHK(hipEventElapsedTime(&tm->pairing_ms, ev[5], ev[6]));
+        HIPCHK(hipEventElapsedTime(&tm->total_ms, ev[2], ev[6]));
     }
     return H2V_OK;
 }
@@ -316,6 +321,22 @@ extern "C" int h2v_verify_batch_device(const h2v_plan *p, const h2v_batch *b, ui
         h2v_workspace_free(tmp);
     }
     return rc;
+}
+
+// Per-kernel device times of a PAST call on this workspace (0 = the most recent, up to 63 back).  The events were
+// recorded on the streams the kernels ran on; the caller must have synchronised the launch stream first.
+extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_timings *tm) {
+    if (!w || !tm) return fail(H2V_E_ARG, "null argument");
+    if (calls_back >= h2v_workspace::RING || calls_back >= w->calls) return fail(H2V_E_ARG, "no such call in the event ring");
+    HIPCHK(hipSetDevice(w->device));
+    hipEvent_t *ev = w->ring[(w->calls - 1 - calls_back) % h2v_workspace::RING];
+    HIPCHK(hipEventSynchronize(ev[6]));
+    HIPCHK(hipEventElapsedTime(&tm->transcript_combiner_ms, ev[0], ev[1]));
+    HIPCHK(hipEventElapsedTime(&tm->g1_decompress_ms, ev[2], ev[3]));
+    HIPCHK(hipEventElapsedTime(&tm->g1_msm_ms, ev[4], ev[5]));
+    HIPCHK(hipEventElapsedTime(&tm->pairing_ms, ev[5], ev[6]));
+    HIPCHK(hipEventElapsedTime(&tm->total_ms, ev[2], ev[6]));
+    return H2V_OK;
 }
 
 static int stage_inputs(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws) {
