@@ -38,7 +38,7 @@ DELTA = 0x08634D0AA021AAF843CAB354FABB0062F6502437C6A09C006C083479590189D7
 # 2^256 mod r (/root/reference/aiken-verifier/aiken_halo2/lib/transcript.ak:99)
 R_2_256 = 0x1824B159ACC5056F998C4FEFECBC4FF55884B7FA0003480200000001FFFFFFFE
 
-MONT_BITS_FP = 384
+MONT_BITS_FP = 392  # the gfx950 multiplier works on 14 x 28-bit limbs: R = 2^392
 MONT_BITS_FR = 256
 
 
@@ -520,7 +520,7 @@ def to_mont_fr(x: int) -> int:
 
 
 def fp_mont_bytes(x: int) -> bytes:
-    """48-byte little-endian Montgomery form (12 x u32 == 6 x u64 limbs, R = 2^384)."""
+    """48-byte little-endian Montgomery form (12 x u32 storage limbs, R = 2^392)."""
     return to_mont_fp(x % P).to_bytes(48, "little")
 
 

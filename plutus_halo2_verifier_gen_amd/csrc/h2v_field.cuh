@@ -173,9 +173,113 @@ struct Field {
 using FpF = Field<FpParams>;
 using FrF = Field<FrParams>;
 
-// ---- out-of-line wrappers: keep the big kernels' code size and compile time in check.
-H2V_DN void fp_mul(Fp &r, const Fp &a, const Fp &b) { FpF::mul(r, a, b); }
-H2V_DI void fp_sqr(Fp &r, const Fp &a) { fp_mul(r, a, a); }
+// ------------------------------------------------------------------ Fp multiplier: 14 x 28-bit product scanning
+// Measured on MI355X (tools/ubench/imad.hip): v_mad_u64_u32 5.4 cycles per wave-instruction, 64-bit add 5.2,
+// add-with-carry pairs 5 each, plain 32-bit ALU 2.7.  A saturated 32-bit CIOS row therefore pays as much for the
+// carry/add plumbing as for the multiplies.  With 28-bit limbs a whole product-scanning column
+//     acc += a_i*b_(k-i)  (k+1 terms)  ;  acc += m_i*p_(k-i)  (k terms)
+// fits a 64-bit accumulator (28 terms * 2^56 < 2^61), so every inner step is ONE v_mad_u64_u32 accumulating into
+// the same register pair and carries are handled once per column (FIPS Montgomery, R = 2^392).
+// Storage stays 12 x 32-bit (cheap add/sub, compact buffers); limbs are re-cut at the multiplier's edges.
+#define FP28_MASK 0x0fffffffu
+H2V_DI void fp_to28(uint32_t (&o)[14], const Fp &a) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const int bit = 28 * i, w = bit >> 5, sh = bit & 31;
+        const uint32_t lo = a.v[w];
+        const uint32_t hi = (w + 1 < 12) ? a.v[w + 1] : 0u;
+        const uint32_t v = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+        o[i] = v & FP28_MASK;
+    }
+}
+H2V_DI void fp_from28(uint32_t (&r)[12], const uint32_t (&t)[14]) {
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const int bit = 32 * j, i = bit / 28, sh = bit % 28;
+        uint32_t v = t[i] >> sh;
+        if (i + 1 < 14) v |= t[i + 1] << (28 - sh);
+        if (i + 2 < 14 && 56 - sh < 32) v |= t[i + 2] << (56 - sh);
+        r[j] = v;
+    }
+}
+// t = a*b/2^392 mod p in 28-bit limbs (value < 2p; limbs normalised, top limb may carry the excess)
+H2V_DI void fp_mont28(uint32_t (&t)[14], const uint32_t (&a)[14], const uint32_t (&b)[14]) {
+    uint32_t m[14];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a[i] * b[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * FP_MOD28[k - i];
+        m[k] = ((uint32_t)acc * FP_N0_28) & FP28_MASK;
+        acc += (uint64_t)m[k] * FP_MOD28[0];
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int k = 14; k < 27; k++) {
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) acc += (uint64_t)a[i] * b[k - i];
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) acc += (uint64_t)m[i] * FP_MOD28[k - i];
+        t[k - 14] = (uint32_t)acc & FP28_MASK;
+        acc >>= 28;
+    }
+    t[13] = (uint32_t)acc;
+}
+// a^2: the off-diagonal products are computed once against the doubled operand
+H2V_DI void fp_montsqr28(uint32_t (&t)[14], const uint32_t (&a)[14]) {
+    uint32_t m[14], d[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) d[i] = a[i] << 1;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) acc += (uint64_t)d[i] * a[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a[k / 2] * a[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * FP_MOD28[k - i];
+        m[k] = ((uint32_t)acc * FP_N0_28) & FP28_MASK;
+        acc += (uint64_t)m[k] * FP_MOD28[0];
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int k = 14; k < 27; k++) {
+#pragma unroll
+        for (int i = k - 13; 2 * i < k; i++) acc += (uint64_t)d[i] * a[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a[k / 2] * a[k / 2];
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) acc += (uint64_t)m[i] * FP_MOD28[k - i];
+        t[k - 14] = (uint32_t)acc & FP28_MASK;
+        acc >>= 28;
+    }
+    t[13] = (uint32_t)acc;
+}
+H2V_DI Fp fp_mul_inl(const Fp &a, const Fp &b) {
+    uint32_t a28[14], b28[14], t[14], w[12];
+    fp_to28(a28, a);
+    fp_to28(b28, b);
+    fp_mont28(t, a28, b28);
+    fp_from28(w, t);
+    Fp r;
+    FpF::cond_sub(r, w, 0);
+    return r;
+}
+H2V_DI Fp fp_sqr_inl(const Fp &a) {
+    uint32_t a28[14], t[14], w[12];
+    fp_to28(a28, a);
+    fp_montsqr28(t, a28);
+    fp_from28(w, t);
+    Fp r;
+    FpF::cond_sub(r, w, 0);
+    return r;
+}
+// ---- out-of-line entry points (operands and result travel in VGPRs): keep code size and compile time in check.
+H2V_DN Fp fp_mul_v(Fp a, Fp b) { return fp_mul_inl(a, b); }
+H2V_DN Fp fp_sqr_v(Fp a) { return fp_sqr_inl(a); }
+H2V_DI void fp_mul(Fp &r, const Fp &a, const Fp &b) { r = fp_mul_v(a, b); }
+H2V_DI void fp_sqr(Fp &r, const Fp &a) { r = fp_sqr_v(a); }
 H2V_DI void fp_add(Fp &r, const Fp &a, const Fp &b) { FpF::add(r, a, b); }
 H2V_DI void fp_sub(Fp &r, const Fp &a, const Fp &b) { FpF::sub(r, a, b); }
 H2V_DI void fp_neg(Fp &r, const Fp &a) { FpF::neg(r, a); }
@@ -189,6 +293,18 @@ H2V_DN void fr_mul(Fr &r, const Fr &a, const Fr &b) { FrF::mul(r, a, b); }
 H2V_DI void fr_add(Fr &r, const Fr &a, const Fr &b) { FrF::add(r, a, b); }
 H2V_DI void fr_sub(Fr &r, const Fr &a, const Fr &b) { FrF::sub(r, a, b); }
 
+H2V_DI void fp_to_mont(Fp &r, const Fp &plain) {
+    Fp k;
+#pragma unroll
+    for (int i = 0; i < 12; i++) k.v[i] = FP_R2[i];
+    fp_mul(r, plain, k);
+}
+H2V_DI void fp_from_mont(Fp &r, const Fp &a) {
+    Fp one;
+    fp_set_zero(one);
+    one.v[0] = 1;
+    fp_mul(r, a, one);
+}
 // a^e for a fixed public exponent given as limbs (uniform control flow across lanes)
 template <int EL>
 H2V_DN void fp_pow_const(Fp &r, const Fp &a, const uint32_t (&e)[EL]) {
@@ -228,7 +344,7 @@ H2V_DN bool fr_inv(Fr &r, const Fr &a) {
 // y > (p-1)/2 on the canonical integer ("lexicographically larger", bls_utils.ak:35-43)
 H2V_DI bool fp_is_lex_larger(const Fp &a_mont) {
     Fp a;
-    FpF::from_mont(a, a_mont);
+    fp_from_mont(a, a_mont);
     // a > half  <=>  half - a borrows
     uint64_t br = 0;
 #pragma unroll

@@ -312,7 +312,7 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
             Fp x, y, t, b4;
 #pragma unroll
             for (int k = 0; k < 12; k++) { t.v[k] = w[k]; b4.v[k] = FP_B[k]; }
-            FpF::to_mont(x, t);
+            fp_to_mont(x, t);
             fp_sqr(t, x); fp_mul(t, t, x); fp_add(t, t, b4);
             fp_pow_const<12>(y, t, FP_SQRT_EXP);
             Fp chk;
@@ -510,12 +510,12 @@ extern "C" __global__ void k_probe_field(int op, uint32_t n, const uint32_t *__r
         Fp x, y, r;
 #pragma unroll
         for (int k = 0; k < 12; k++) { x.v[k] = a[(size_t)i * 12 + k]; y.v[k] = b[(size_t)i * 12 + k]; }
-        FpF::to_mont(x, x); FpF::to_mont(y, y);
+        fp_to_mont(x, x); fp_to_mont(y, y);
         if (op == 0) fp_mul(r, x, y);
         else if (op == 1) fp_add(r, x, y);
         else if (op == 2) fp_sub(r, x, y);
         else fp_inv(r, x);
-        FpF::from_mont(r, r);
+        fp_from_mont(r, r);
 #pragma unroll
         for (int k = 0; k < 12; k++) out[(size_t)i * 12 + k] = r.v[k];
     } else {
@@ -563,8 +563,8 @@ extern "C" __global__ void k_export_points(uint32_t n, int jacobian, const uint3
         for (int k = 0; k < 12; k++) { a.x.v[k] = in[(size_t)i * 24 + k]; a.y.v[k] = in[(size_t)i * 24 + 12 + k]; }
     }
     Fp x, y;
-    FpF::from_mont(x, a.x);
-    FpF::from_mont(y, a.y);
+    fp_from_mont(x, a.x);
+    fp_from_mont(y, a.y);
     uint8_t *o = out + (size_t)i * 96;
 #pragma unroll
     for (int k = 0; k < 12; k++) {
