@@ -108,6 +108,11 @@ int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_t *scalars,
 /* e(p1, s_g2 of plan) == e(p2, G2) for n pairs of compressed G1 points; out[i] = 1/0 */
 int h2v_probe_pairing(const h2v_plan *plan, uint32_t n, const uint8_t *p1_compressed, const uint8_t *p2_compressed,
                       uint8_t *out);
+/* same with an explicit kernel (impl 0: one lane per proof, 1: cooperative 16 lanes per proof, -1: default) and an
+ * optional dump (n * 24 * 48 bytes): the 12 Fp coefficients (flat order w^k, re/im; canonical LE) of f after the
+ * Miller loop and, for the cooperative kernel, after the final exponentiation */
+int h2v_probe_pairing_ex(const h2v_plan *plan, uint32_t n, const uint8_t *p1_compressed, const uint8_t *p2_compressed,
+                         uint8_t *out, int impl, uint8_t *dbg);
 
 const char *h2v_last_error(void);
 int h2v_device_count(void);

@@ -33,7 +33,8 @@ EXPORTS = [
     "h2v_plan_load", "h2v_plan_free", "h2v_plan_info", "h2v_workspace_create", "h2v_workspace_free",
     "h2v_workspace_timings",
     "h2v_verify_batch", "h2v_verify_batch_device", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
-    "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_pairing", "h2v_last_error",
+    "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_pairing", "h2v_probe_pairing_ex",
+    "h2v_last_error",
     "h2v_device_count",
 ]
 
@@ -66,6 +67,7 @@ def lib():
         L.h2v_probe_g1_decompress.argtypes = [C.c_int, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p]
         L.h2v_probe_g1_msm.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p]
         L.h2v_probe_pairing.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p]
+        L.h2v_probe_pairing_ex.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -231,3 +233,17 @@ def probe_pairing(plan: DevicePlan, p1_list, p2_list):
     out = C.create_string_buffer(n)
     check(lib().h2v_probe_pairing(plan.handle, n, b"".join(p1_list), b"".join(p2_list), out))
     return [out.raw[i] for i in range(n)]
+
+
+def probe_pairing_ex(plan: DevicePlan, p1_list, p2_list, impl: int, dump: bool = True):
+    """returns (accept list, per proof [f_miller (12 ints), f_final (12 ints)]) with the chosen kernel"""
+    n = len(p1_list)
+    out = C.create_string_buffer(n)
+    dbg = C.create_string_buffer(n * 24 * 48) if dump else None
+    check(lib().h2v_probe_pairing_ex(plan.handle, n, b"".join(p1_list), b"".join(p2_list), out, impl, dbg))
+    vals = []
+    if dump:
+        for i in range(n):
+            row = [int.from_bytes(dbg.raw[(i * 24 + q) * 48:(i * 24 + q + 1) * 48], "little") for q in range(24)]
+            vals.append((row[:12], row[12:]))
+    return [out.raw[i] for i in range(n)], vals

@@ -530,3 +530,20 @@ def fr_mont_bytes(x: int) -> bytes:
 
 def f2_mont_bytes(a) -> bytes:
     return fp_mont_bytes(a[0]) + fp_mont_bytes(a[1])
+
+
+def fp_mont28_slot(x: int) -> bytes:
+    """One 64-byte operand slot of the cooperative pairing engine: Montgomery form (R = 2^392) cut into 14 limbs of
+    28 bits, one limb per little-endian dword, padded to 16 dwords."""
+    m = to_mont_fp(x % P)
+    out = b"".join(((m >> (28 * i)) & 0xFFFFFFF).to_bytes(4, "little") for i in range(14))
+    return out + bytes(8)
+
+
+def line_slots(lam, c) -> bytes:
+    """The 8 shared constants of one Miller-loop line in engine order
+    [-lam0, -lam1, (xi*-lam)0, (xi*-lam)1, c0, c1, (xi*c)0, (xi*c)1] (tools/gen_coop_tables.py: LN_*)."""
+    nl = f2_neg(lam)
+    nxl = f2_mul(XI, nl)
+    xc = f2_mul(XI, c)
+    return b"".join(fp_mont28_slot(v) for v in (nl[0], nl[1], nxl[0], nxl[1], c[0], c[1], xc[0], xc[1]))

@@ -83,10 +83,11 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
     const Sec secs[] = {{H2V_HW_OFF_INSTR, 8ull * n_instr}, {H2V_HW_OFF_CONSTS, 32ull * n_consts}, {H2V_HW_OFF_POINTS, 4ull * n_points},
                         {H2V_HW_OFF_VK_BASES, 96ull * n_bases}, {H2V_HW_OFF_TERMS, 8ull * n_terms},
                         {H2V_HW_OFF_LINES_SG2, 192ull * H2V_MILLER_LINES}, {H2V_HW_OFF_LINES_G2, 192ull * H2V_MILLER_LINES},
-                        {H2V_HW_OFF_TRACE, 8ull * n_trace}};
+                        {H2V_HW_OFF_TRACE, 8ull * n_trace},
+                        {H2V_HW_OFF_LINES28_SG2, 512ull * H2V_MILLER_LINES}, {H2V_HW_OFF_LINES28_G2, 512ull * H2V_MILLER_LINES}};
     for (const Sec &s : secs) {
         const uint64_t off = w[s.off_word];
-        if (off < hdr || (off & 7) || off + s.bytes > len) return fail(H2V_E_PLAN, "section out of bounds");
+        if (off < hdr || (off & 15) || off + s.bytes > len) return fail(H2V_E_PLAN, "section out of bounds");
     }
     if (n_instr == 0 || n_instr > (1u << 20) || n_regs == 0 || n_regs > 65535 || n_points == 0 || n_points > 4096 ||
         n_terms == 0 || n_ci > 1 || n_pi > (1u << 16) || proof_len > (1u << 24))
@@ -165,6 +166,8 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
     d.lines_sg2 = (const uint32_t *)(base + w[H2V_HW_OFF_LINES_SG2]);
     d.lines_g2 = (const uint32_t *)(base + w[H2V_HW_OFF_LINES_G2]);
     d.trace = (const uint32_t *)(base + w[H2V_HW_OFF_TRACE]);
+    d.lines28_sg2 = (const uint32_t *)(base + w[H2V_HW_OFF_LINES28_SG2]);
+    d.lines28_g2 = (const uint32_t *)(base + w[H2V_HW_OFF_LINES28_G2]);
     p->n_squeezes = n_sq;
     p->stream_len = w[H2V_HW_STREAM_LEN];
     for (uint32_t k = 0; k < n_trace; k++) p->trace_slots.push_back(rd32(trp + 8 * k));
@@ -238,6 +241,19 @@ extern "C" void h2v_workspace_free(h2v_workspace *w) {
     delete w;
 }
 
+// Pairing kernel selection: the cooperative 16-lanes-per-proof kernel is the product path; the one-lane-per-proof
+// kernel stays as a cross-check (H2V_PAIRING=legacy, or impl = 0 in the probe).
+static void launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint32_t *er,
+                                uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st) {
+    if (impl == 0) hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, er, status, accept, dbg);
+    else hipLaunchKernelGGL(k_pairing_coop, dim3((n + 3) / 4), dim3(64), 0, st, d, n, pts, valid, er, status, accept, dbg);
+}
+static void launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint32_t *er,
+                           uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st) {
+    static const int impl = []() { const char *e = getenv("H2V_PAIRING"); return (e && strcmp(e, "legacy") == 0) ? 0 : 1; }();
+    launch_pairing_impl(impl, d, n, pts, valid, er, status, accept, dbg, st);
+}
+
 // ---------------------------------------------------------------------------------------------- pipeline
 // Enqueues the four kernels.  Without timings the transcript/combiner kernel (few, long waves) and the
 // decompression kernel (many short ones) run concurrently on two streams and join before the MSM.
@@ -249,7 +265,6 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
     const uint32_t vm_blocks = (n + 63) / 64;
     const uint32_t dec_blocks = (n * slots + 63) / 64;
     const uint32_t msm_blocks = (n + (64 / tp) - 1) / (64 / tp);
-    const uint32_t pair_blocks = (n + 63) / 64;
     uint32_t *trace = want_trace ? w->trace : nullptr;
     uint32_t *status = w->status;
     static const bool dbg = getenv("H2V_DEBUG_SYNC") != nullptr;  // serialise + sync after every kernel, say which one ran
@@ -263,7 +278,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(64), 0, st, d, n, proofs, off, ci, w->pts, w->valid))
         DBG_STAGE("k_transcript_combiner", hipLaunchKernelGGL(k_transcript_combiner, dim3(vm_blocks), dim3(64), 0, st, d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace))
         DBG_STAGE("k_g1_msm", hipLaunchKernelGGL(k_g1_msm, dim3(msm_blocks), dim3(MSM_BLOCK), 0, st, d, n, tp, w->scalars, w->pts, w->er))
-        DBG_STAGE("k_pairing_check", hipLaunchKernelGGL(k_pairing_check, dim3(pair_blocks), dim3(64), 0, st, d, n, w->pts, w->valid, w->er, status, accept))
+        DBG_STAGE("k_pairing_check", launch_pairing(d, n, w->pts, w->valid, w->er, status, accept, nullptr, st))
 #undef DBG_STAGE
         if (status_out) HIPCHK(hipMemcpyAsync(status_out, status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         return H2V_OK;
@@ -284,7 +299,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
     HIPCHK(hipEventRecord(ev[4], st));
     hipLaunchKernelGGL(k_g1_msm, dim3(msm_blocks), dim3(MSM_BLOCK), 0, st, d, n, tp, w->scalars, w->pts, w->er);
     HIPCHK(hipEventRecord(ev[5], st));
-    hipLaunchKernelGGL(k_pairing_check, dim3(pair_blocks), dim3(64), 0, st, d, n, w->pts, w->valid, w->er, status, accept);
+    launch_pairing(d, n, w->pts, w->valid, w->er, status, accept, nullptr, st);
     HIPCHK(hipEventRecord(ev[6], st));
     HIPCHK(hipGetLastError());
     if (status_out) HIPCHK(hipMemcpyAsync(status_out, status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
@@ -525,11 +540,20 @@ extern "C" int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_
     HIPCHK(hipMemcpy(out_xy_be, dout.p, (size_t)n * 96, hipMemcpyDeviceToHost));
     return H2V_OK;
 }
+extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t *p1c, const uint8_t *p2c, uint8_t *out, int impl, uint8_t *dbg);
 extern "C" int h2v_probe_pairing(const h2v_plan *p, uint32_t n, const uint8_t *p1c, const uint8_t *p2c, uint8_t *out) {
+    return h2v_probe_pairing_ex(p, n, p1c, p2c, out, -1, nullptr);
+}
+// impl: -1 default, 0 one-lane-per-proof kernel, 1 cooperative kernel; dbg (optional): n * 24 * 48 bytes
+// (f after the Miller loop and - cooperative kernel only - after the final exponentiation; canonical LE limbs)
+extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t *p1c, const uint8_t *p2c, uint8_t *out, int impl, uint8_t *dbg) {
     if (!p || !p1c || !p2c || !out || n == 0) return fail(H2V_E_ARG, "bad argument");
+    DevBuf ddbg;
     HIPCHK(hipSetDevice(p->device));
     MiniPlan mp;
     DevBuf din, doff, dsc, dpts, dvalid, der, dst, dacc;
+    mp.d.lines28_sg2 = p->d.lines28_sg2;
+    mp.d.lines28_g2 = p->d.lines28_g2;
     if (mp.build(2, 1, p->d.lines_sg2, p->d.lines_g2) || upload_offsets(doff, n, 96) || din.alloc((size_t)n * 96) || dsc.alloc((size_t)n * 32) ||
         dpts.alloc((size_t)n * 192) || dvalid.alloc((size_t)n * 2) || der.alloc((size_t)n * 144) || dst.alloc((size_t)n * 4) || dacc.alloc(n))
         return fail(H2V_E_DEVICE, "probe setup failed");
@@ -543,9 +567,11 @@ extern "C" int h2v_probe_pairing(const h2v_plan *p, uint32_t n, const uint8_t *p
     HIPCHK(hipMemset(dst.p, 0, (size_t)n * 4));
     hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(64), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
     hipLaunchKernelGGL(k_g1_msm, dim3((n + 63) / 64), dim3(MSM_BLOCK), 0, nullptr, mp.d, n, 1u, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>());
-    hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, nullptr, mp.d, n, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), der.as<uint32_t>(), dst.as<uint32_t>(), dacc.as<uint8_t>());
+    if (ddbg.alloc(dbg ? (size_t)n * 24 * 48 : 8)) return fail(H2V_E_DEVICE, "hipMalloc failed");
+    launch_pairing_impl(impl, mp.d, n, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), der.as<uint32_t>(), dst.as<uint32_t>(), dacc.as<uint8_t>(), dbg ? ddbg.as<uint32_t>() : nullptr, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, dacc.p, n, hipMemcpyDeviceToHost));
+    if (dbg) HIPCHK(hipMemcpy(dbg, ddbg.p, (size_t)n * 24 * 48, hipMemcpyDeviceToHost));
     return H2V_OK;
 }

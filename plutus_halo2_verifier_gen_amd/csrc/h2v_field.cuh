@@ -1,8 +1,8 @@
 // gfx950 device arithmetic for the BLS12-381 base field Fp (12 x u32) and scalar field Fr (8 x u32).
 //
-// Montgomery form (R = 2^384 / 2^256), values kept fully reduced after every operation so that equality
-// is limb equality.  The multiplier is v_mad_u64_u32 (32x32+64 -> 64): one CIOS row is N of them for the
-// product and N for the reduction, carries ride in the 64-bit accumulator.
+// Montgomery form (R = 2^392 for Fp, 2^256 for Fr), values kept fully reduced after every operation so that
+// equality is limb equality.  Fr uses a saturated 32-bit CIOS; Fp uses the 14 x 28-bit product-scanning multiplier
+// further down (storage stays 12 x 32).
 // These are the operations the reference names at
 //   plinth-verifier/plutus-halo2/src/Plutus/Crypto/BlsTypes.hs:96-300 (Scalar / Fp: add, sub, neg, mul, powMod, recip)
 #pragma once
@@ -320,25 +320,97 @@ H2V_DN void fp_pow_const(Fp &r, const Fp &a, const uint32_t (&e)[EL]) {
     }
     r = acc;
 }
+// ------------------------------------------------------------------ inversion: Kaliski's almost-Montgomery inverse
+// A Fermat chain costs ~570 dependent multiplications (about 3.5 M cycles on a lone lane); the binary
+// extended-Euclid form below is ~bits..2*bits iterations of word-level add / sub / shift.  Phase 1 yields
+// abar^-1 * 2^k mod m with k in [bits, 2*bits]; one Montgomery product by 2^(3*RBITS-k) (table) finishes the job.
+// Any exact inverse is the same field element as the reference's recip (BlsTypes.hs:201-212 / recip_eea, bls_utils.ak:98-117).
+template <int N>
+H2V_DI bool big_is_zero(const uint32_t (&a)[N]) {
+    uint32_t x = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) x |= a[i];
+    return x == 0;
+}
+template <int N>
+H2V_DI bool big_gt(const uint32_t (&a)[N], const uint32_t (&b)[N]) {  // a > b  <=>  b - a borrows
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t d = (uint64_t)b[i] - a[i] - br;
+        br = (d >> 63) & 1;
+    }
+    return br != 0;
+}
+template <int N>
+H2V_DI void big_sub(uint32_t (&r)[N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t d = (uint64_t)a[i] - b[i] - br;
+        r[i] = (uint32_t)d;
+        br = (d >> 63) & 1;
+    }
+}
+template <int N>
+H2V_DI void big_add(uint32_t (&r)[N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        c += (uint64_t)a[i] + b[i];
+        r[i] = (uint32_t)c;
+        c >>= 32;
+    }
+}
+template <int N>
+H2V_DI void big_shr1(uint32_t (&a)[N]) {
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 31);
+    a[N - 1] >>= 1;
+}
+template <int N>
+H2V_DI void big_shl1(uint32_t (&a)[N]) {
+#pragma unroll
+    for (int i = N - 1; i > 0; i--) a[i] = (a[i] << 1) | (a[i - 1] >> 31);
+    a[0] <<= 1;
+}
+// returns k and x = abar^-1 * 2^k mod m (plain integers); abar != 0, abar < m, m odd with `bits` bits
+template <class PR>
+H2V_DI int kaliski_phase1(uint32_t (&x)[PR::N], const uint32_t (&abar)[PR::N]) {
+    constexpr int N = PR::N;
+    uint32_t u[N], v[N], rr[N], s[N], m[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { m[i] = PR::mod(i); u[i] = m[i]; v[i] = abar[i]; rr[i] = 0; s[i] = 0; }
+    s[0] = 1;
+    int k = 0;
+    while (!big_is_zero<N>(v)) {
+        if (!(u[0] & 1)) { big_shr1<N>(u); big_shl1<N>(s); }
+        else if (!(v[0] & 1)) { big_shr1<N>(v); big_shl1<N>(rr); }
+        else if (big_gt<N>(u, v)) { big_sub<N>(u, u, v); big_shr1<N>(u); big_add<N>(rr, rr, s); big_shl1<N>(s); }
+        else { big_sub<N>(v, v, u); big_shr1<N>(v); big_add<N>(s, s, rr); big_shl1<N>(rr); }
+        k++;
+    }
+    if (!big_gt<N>(m, rr)) big_sub<N>(rr, rr, m);  // rr >= m
+    big_sub<N>(x, m, rr);
+    return k;
+}
 // returns false when a == 0
 H2V_DN bool fp_inv(Fp &r, const Fp &a) {
     if (fp_is_zero(a)) { fp_set_zero(r); return false; }
-    fp_pow_const<12>(r, a, FP_INV_EXP);
+    Fp x, c;
+    const int k = kaliski_phase1<FpParams>(x.v, a.v);
+#pragma unroll
+    for (int i = 0; i < 12; i++) c.v[i] = FP_INV_POW2[k - 381][i];
+    fp_mul(r, x, c);
     return true;
 }
 H2V_DN bool fr_inv(Fr &r, const Fr &a) {
     if (FrF::is_zero(a)) { FrF::set_zero(r); return false; }
-    Fr acc;
-    FrF::set_one(acc);
-    bool started = false;
-    for (int i = 255; i >= 0; i--) {
-        if (started) fr_mul(acc, acc, acc);
-        if ((FR_INV_EXP[i >> 5] >> (i & 31)) & 1) {
-            if (started) fr_mul(acc, acc, a);
-            else { acc = a; started = true; }
-        }
-    }
-    r = acc;
+    Fr x, c;
+    const int k = kaliski_phase1<FrParams>(x.v, a.v);
+#pragma unroll
+    for (int i = 0; i < 8; i++) c.v[i] = FR_INV_POW2[k - 255][i];
+    fr_mul(r, x, c);
     return true;
 }
 // y > (p-1)/2 on the canonical integer ("lexicographically larger", bls_utils.ak:35-43)

@@ -14,6 +14,7 @@
 #include "h2v_curve.cuh"
 #include "h2v_plan.h"
 #include "h2v_tower.cuh"
+#include "h2v_pairing_coop.cuh"
 
 // ============================================================================ blake2b-256 (RFC 7693)
 __device__ static constexpr uint64_t B2_IV[8] = {
@@ -473,7 +474,8 @@ H2V_DN bool final_exp_is_one(const Fp12 &f) {
 
 extern "C" __global__ void __launch_bounds__(64)
 k_pairing_check(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid,
-                const uint32_t *__restrict__ er_jac, uint32_t *__restrict__ status, uint8_t *__restrict__ accept) {
+                const uint32_t *__restrict__ er_jac, uint32_t *__restrict__ status, uint8_t *__restrict__ accept,
+                uint32_t *__restrict__ dbg) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t slots = plan.n_points + plan.n_ci;
@@ -494,6 +496,15 @@ k_pairing_check(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, c
         fp_neg(er.y, er.y);  // -er (harmless on the infinity sentinel: skipped below)
         Fp12 f;
         miller_loop(f, el, plan.lines_sg2, el_inf, er, plan.lines_g2, er_inf);
+        if (dbg) {  // flat order (k, part): tower c0 = (w^0, w^2, w^4), c1 = (w^1, w^3, w^5)
+            const Fp2 *co[6] = {&f.c0.c0, &f.c1.c0, &f.c0.c1, &f.c1.c1, &f.c0.c2, &f.c1.c2};
+            for (int k = 0; k < 6; k++) {
+                Fp o0, o1;
+                fp_from_mont(o0, co[k]->c0);
+                fp_from_mont(o1, co[k]->c1);
+                for (int q = 0; q < 12; q++) { dbg[((size_t)i * 24 + 2 * k) * 12 + q] = o0.v[q]; dbg[((size_t)i * 24 + 2 * k + 1) * 12 + q] = o1.v[q]; }
+            }
+        }
         if (!final_exp_is_one(f)) st |= H2V_ST_PAIRING;
     }
     status[i] = st;

@@ -1,0 +1,345 @@
+// Cooperative pairing check: ONE PROOF PER 16-LANE GROUP (4 proofs per wave).
+//
+// Why: a batch of 4096 proofs gives a one-lane-per-proof pairing kernel only 64 waves on a chip with 1024 SIMDs,
+// and every Fp12 operation there is ~54 dependent Fp multiplications.  Here lane g < 12 of a group owns ONE Fp
+// coefficient c_{k,part} (k = g >> 1, part = g & 1) of each Fp12 value (flat basis Fp12 = Fp2[w]/(w^6 - xi)), so an
+// Fp12 value costs 12 VGPRs per lane, and a product is computed by all 12 lanes at once:
+//     c_{k,part} = sum over (i, j = k-i mod 6) of  a_i x b_j  (x xi when wrapped)      -> 12 Fp x Fp terms per lane,
+// accumulated UNREDUCED in 28 64-bit column accumulators (12 terms x 14 products x 2^56 < 2^64) with a single
+// Montgomery reduction at the end: 12*196 + 196 v_mad_u64_u32 per lane instead of 54*392 on one lane.
+// Operands are staged in LDS as 28-bit limbs (64-byte slots); which slots a lane multiplies comes from the
+// generated, big-integer-verified tables of coop_tables.h (tools/gen_coop_tables.py).  Lanes 12..15 of a group
+// compute the NEXT Miller-loop line's per-proof products (-lambda)*xP in the same engine call.
+//
+// Semantics are those of k_pairing_check (h2v_kernels.hip): accept <=> e(el, s_g2) == e(er, G2)
+// (/root/reference/aiken-verifier/templates/verification_h2.hbs:125-128).
+#pragma once
+#include "coop_tables.h"
+#include "h2v_curve.cuh"
+#include "h2v_plan.h"
+#include "h2v_tower.cuh"
+
+#define COOP_SLOT_DW 16                      // dwords per operand slot (14 limbs + 2 pad)
+#define COOP_GROUP_SLOTS 64                  // slots reserved per group (COOP_N_GROUP_SLOTS used)
+#define COOP_GROUP_DW (COOP_GROUP_SLOTS * COOP_SLOT_DW)
+#define COOP_LDS_DW (4 * COOP_GROUP_DW + COOP_N_SHARED_SLOTS * COOP_SLOT_DW)
+
+// File-scope LDS so that every device function addresses it as LDS (ds_read/ds_write), not through flat pointers.
+__shared__ __attribute__((aligned(16))) uint32_t coop_lds[COOP_LDS_DW];
+#define COOP_SHR_OFF (4 * COOP_GROUP_DW)
+
+struct Coop {
+    int grp_off;  // dword offset of this group's slots in coop_lds
+    int g;        // lane within the group
+};
+
+H2V_DI uint32_t *coop_slot(const Coop &c, int s) {
+    const int off = s < COOP_SHARED_BASE ? c.grp_off + s * COOP_SLOT_DW : COOP_SHR_OFF + (s - COOP_SHARED_BASE) * COOP_SLOT_DW;
+    return coop_lds + off;
+}
+H2V_DI void coop_store28(uint32_t *p, const Fp &a) {
+    uint32_t l[14];
+    fp_to28(l, a);
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(l[0], l[1], l[2], l[3]);
+    q[1] = make_uint4(l[4], l[5], l[6], l[7]);
+    q[2] = make_uint4(l[8], l[9], l[10], l[11]);
+    q[3] = make_uint4(l[12], l[13], 0u, 0u);
+}
+H2V_DI void coop_load28(uint32_t (&l)[14], const uint32_t *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    l[0] = a.x; l[1] = a.y; l[2] = a.z; l[3] = a.w; l[4] = b.x; l[5] = b.y; l[6] = b.z; l[7] = b.w;
+    l[8] = c.x; l[9] = c.y; l[10] = c.z; l[11] = c.w; l[12] = d.x; l[13] = d.y;
+}
+
+// out = sum_t X[tab[2t]] * Y[tab[2t+1]]  (mod p), one Montgomery reduction.  NT <= 12 (accumulator headroom).
+template <int NT>
+H2V_DN Fp coop_accumulate(const Coop c, const uint8_t *tab) {
+    static_assert(NT <= 12, "column accumulators hold at most 12 unreduced products");
+    uint64_t acc[28];
+#pragma unroll
+    for (int i = 0; i < 28; i++) acc[i] = 0;
+#pragma unroll 1
+    for (int t = 0; t < NT; t++) {
+        uint32_t x[14], y[14];
+        coop_load28(x, coop_slot(c, tab[2 * t]));
+        coop_load28(y, coop_slot(c, tab[2 * t + 1]));
+#pragma unroll
+        for (int i = 0; i < 14; i++)
+#pragma unroll
+            for (int j = 0; j < 14; j++) acc[i + j] += (uint64_t)x[i] * y[j];
+    }
+    // Montgomery reduction of the 28-column accumulator (operand scanning), R = 2^392
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        const uint32_t m = ((uint32_t)acc[k] * FP_N0_28) & FP28_MASK;
+#pragma unroll
+        for (int j = 0; j < 14; j++) acc[k + j] += (uint64_t)m * FP_MOD28[j];
+        acc[k + 1] += acc[k] >> 28;
+    }
+    uint32_t t28[14], w[12];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        carry += acc[14 + k];
+        t28[k] = (uint32_t)carry & FP28_MASK;
+        carry >>= 28;
+    }
+    carry += acc[27];
+    t28[13] = (uint32_t)carry;
+    fp_from28(w, t28);
+    Fp r;
+    FpF::cond_sub(r, w, 0);
+    return r;
+}
+
+H2V_DI Fp coop_shfl_xor1(const Fp &a) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.v[i] = __shfl_xor(a.v[i], 1);
+    return r;
+}
+H2V_DI Fp coop_bcast(const Fp &a, int src_lane) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.v[i] = __shfl(a.v[i], src_lane);
+    return r;
+}
+// stage a distributed value as the A operand (a_{k,part}, and -a_{k,1})
+H2V_DI void coop_stage_a(const Coop &c, const Fp &a) {
+    if (c.g < 12) {
+        coop_store28(coop_slot(c, COOP_SLOT_A + c.g), a);
+        if (c.g & 1) {
+            Fp n;
+            fp_neg(n, a);
+            coop_store28(coop_slot(c, COOP_SLOT_NA + (c.g >> 1)), n);
+        }
+    }
+}
+// stage a distributed value as the B operand (b and xi*b)
+H2V_DI void coop_stage_b(const Coop &c, const Fp &b) {
+    const Fp pb = coop_shfl_xor1(b);
+    if (c.g < 12) {
+        coop_store28(coop_slot(c, COOP_SLOT_B + c.g), b);
+        Fp xb;
+        if (c.g & 1) fp_add(xb, pb, b);   // (xi b)_1 = b0 + b1
+        else fp_sub(xb, b, pb);           // (xi b)_0 = b0 - b1
+        coop_store28(coop_slot(c, COOP_SLOT_XB + c.g), xb);
+    }
+}
+// c = a * b (all distributed)
+H2V_DI Fp coop_mul(const Coop &c, const Fp &a, const Fp &b) {
+    coop_stage_a(c, a);
+    coop_stage_b(c, b);
+    __syncthreads();
+    Fp r = coop_accumulate<COOP_N_MUL_TERMS>(c, COOP_TAB_MUL[c.g]);
+    __syncthreads();
+    return r;
+}
+H2V_DI Fp coop_conj(const Coop &c, const Fp &a) {  // w -> -w: odd powers change sign
+    Fp r = a;
+    if (c.g < 12 && ((c.g >> 1) & 1)) fp_neg(r, a);
+    return r;
+}
+// a -> a^p: coefficient k becomes conj(a_k) * gamma^k
+H2V_DI Fp coop_frob(const Coop &c, const Fp &a) {
+    const Fp pa = coop_shfl_xor1(a);
+    Fp r = a;
+    if (c.g < 12) {
+        const int k = c.g >> 1;
+        Fp g0, g1, x, y;
+#pragma unroll
+        for (int i = 0; i < 12; i++) { g0.v[i] = FROB_GAMMA[k][0][i]; g1.v[i] = FROB_GAMMA[k][1][i]; }
+        if (c.g & 1) {   // imaginary part: a_k0*g1 - a_k1*g0
+            fp_mul(x, pa, g1); fp_mul(y, a, g0); fp_sub(r, x, y);
+        } else {         // real part: a_k0*g0 + a_k1*g1
+            fp_mul(x, a, g0); fp_mul(y, pa, g1); fp_add(r, x, y);
+        }
+    }
+    return r;
+}
+// copy one line's 8 constant slots (512 B) from the plan into the wave-shared area
+H2V_DI void coop_stage_line(const Coop &c, int shared_slot, const uint32_t *lines28, int line_idx, int lane) {
+    const uint2 *src = reinterpret_cast<const uint2 *>(lines28 + (size_t)line_idx * 8 * COOP_SLOT_DW);
+    uint2 *dst = reinterpret_cast<uint2 *>(coop_lds + COOP_SHR_OFF + (shared_slot - COOP_SHARED_BASE) * COOP_SLOT_DW);
+    dst[lane] = src[lane];  // 64 lanes x 8 B = 512 B
+}
+// f <- f * line (loop 1: el against s_g2's lines; loop 2: -er against G2's lines).  The spare lanes' products go
+// to the OTHER loop's T slots (they belong to that loop's next line).
+template <int LOOP>
+H2V_DI Fp coop_line(const Coop &c, const Fp &f) {
+    coop_stage_a(c, f);
+    __syncthreads();
+    Fp r = coop_accumulate<COOP_N_LINE_TERMS>(c, LOOP == 1 ? COOP_TAB_LINE1[c.g] : COOP_TAB_LINE2[c.g]);
+    __syncthreads();
+    if (c.g >= 12) coop_store28(coop_slot(c, (LOOP == 1 ? COOP_SLOT_T2 : COOP_SLOT_T1) + (c.g - 12)), r);
+    return r;
+}
+// a^x (x = -|x|) for a in the cyclotomic subgroup
+H2V_DN Fp coop_exp_x(const Coop c, const Fp a) {
+    Fp acc = a;
+    for (int i = 62; i >= 0; i--) {
+        acc = coop_mul(c, acc, acc);
+        if ((BLS_X_ABS >> i) & 1) acc = coop_mul(c, acc, a);
+    }
+    return coop_conj(c, acc);
+}
+// 1/f for a distributed f: N = f * conj(f) lies in Fp6 (even powers of w); lane 0 inverts it with the tower code.
+H2V_DN Fp coop_inv(const Coop c, const Fp f, bool &ok) {
+    const Fp fc = coop_conj(c, f);
+    const Fp nrm = coop_mul(c, f, fc);
+    // gather the even coefficients on lane 0 through the (now free) A slots, raw 12 x 32 limbs
+    if (c.g < 12) {
+        uint32_t *p = coop_slot(c, COOP_SLOT_A + c.g);
+#pragma unroll
+        for (int i = 0; i < 12; i++) p[i] = nrm.v[i];
+    }
+    __syncthreads();
+    bool good = true;
+    if (c.g == 0) {
+        Fp6 n6, inv6;
+        const int src[6] = {0, 1, 4, 5, 8, 9};  // (k=0: c0), (k=2: c1), (k=4: c2)
+        Fp *dst[6] = {&n6.c0.c0, &n6.c0.c1, &n6.c1.c0, &n6.c1.c1, &n6.c2.c0, &n6.c2.c1};
+        for (int q = 0; q < 6; q++) {
+            const uint32_t *p = coop_slot(c, COOP_SLOT_A + src[q]);
+#pragma unroll
+            for (int i = 0; i < 12; i++) dst[q]->v[i] = p[i];
+        }
+        good = fp6_inv(inv6, n6);
+        const Fp *res[6] = {&inv6.c0.c0, &inv6.c0.c1, &inv6.c1.c0, &inv6.c1.c1, &inv6.c2.c0, &inv6.c2.c1};
+        for (int q = 0; q < 6; q++) {
+            uint32_t *p = coop_slot(c, COOP_SLOT_A + src[q]);
+#pragma unroll
+            for (int i = 0; i < 12; i++) p[i] = res[q]->v[i];
+        }
+    }
+    __syncthreads();
+    Fp ninv;
+    fp_set_zero(ninv);
+    if (c.g < 12 && !((c.g >> 1) & 1)) {
+        const uint32_t *p = coop_slot(c, COOP_SLOT_A + c.g);
+#pragma unroll
+        for (int i = 0; i < 12; i++) ninv.v[i] = p[i];
+    }
+    __syncthreads();
+    ok = good;
+    return coop_mul(c, fc, ninv);
+}
+
+// dbg (optional): per proof 2 x 12 Fp (canonical, 12 dwords each): f after the Miller loop, f after the final
+// exponentiation; flat order (k, part).
+extern "C" __global__ void __launch_bounds__(64)
+k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid,
+               const uint32_t *__restrict__ er_jac, uint32_t *__restrict__ status, uint8_t *__restrict__ accept,
+               uint32_t *__restrict__ dbg) {
+    const int lane = threadIdx.x, grp = lane >> 4;
+    Coop c;
+    c.g = lane & 15;
+    c.grp_off = grp * COOP_GROUP_DW;
+    const uint32_t i = blockIdx.x * 4 + grp;
+    const bool live = i < n;
+    const uint32_t ii = live ? i : n - 1;  // dead groups shadow the last proof, never write
+    const uint32_t slots = plan.n_points + plan.n_ci;
+
+    // ---- lane 0 of the group: status, the two G1 arguments (el ; -er normalised to affine)
+    uint32_t st = 0;
+    uint32_t flags = 0;  // bit0: el is infinity, bit1: er is infinity
+    if (c.g == 0) {
+        st = status[ii];
+        for (uint32_t j = 0; j < slots; j++)
+            if (!valid[(size_t)ii * slots + j]) st |= H2V_ST_BAD_POINT;
+        G1A el, er;
+        G1J ej;
+        const uint32_t *pp = pts + ((size_t)ii * slots + plan.pi_point) * 24;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            el.x.v[k] = pp[k]; el.y.v[k] = pp[12 + k];
+            ej.x.v[k] = er_jac[(size_t)ii * 36 + k]; ej.y.v[k] = er_jac[(size_t)ii * 36 + 12 + k]; ej.z.v[k] = er_jac[(size_t)ii * 36 + 24 + k];
+        }
+        if (st != 0) { g1a_set_inf(el); g1j_set_inf(ej); }  // rejected already: keep the arithmetic well-defined
+        g1j_to_affine(er, ej);
+        if (g1a_is_inf(el)) flags |= 1;
+        if (g1a_is_inf(er)) flags |= 2;
+        fp_neg(er.y, er.y);
+        coop_store28(coop_slot(c, COOP_SLOT_PX1), el.x);
+        coop_store28(coop_slot(c, COOP_SLOT_PY1), el.y);
+        coop_store28(coop_slot(c, COOP_SLOT_PX2), er.x);
+        coop_store28(coop_slot(c, COOP_SLOT_PY2), er.y);
+        Fp z;
+        fp_set_zero(z);
+        coop_store28(coop_slot(c, COOP_SLOT_ZERO), z);
+    }
+    flags = __shfl(flags, grp * 16);
+    st = __shfl(st, grp * 16);
+    const bool skip1 = (flags & 1) != 0, skip2 = (flags & 2) != 0;
+
+    // ---- Miller loop over the precomputed lines of the two fixed G2 arguments
+    Fp f;
+    fp_set_zero(f);
+    if (c.g == 0) fp_set_one(f);
+    coop_stage_line(c, COOP_SLOT_LN1, plan.lines28_sg2, 0, lane);
+    coop_stage_line(c, COOP_SLOT_LN2, plan.lines28_g2, 0, lane);
+    __syncthreads();
+    (void)coop_line<2>(c, f);  // warm-up call: only its spare lanes matter (T1 of line 0)
+    int line = 0;
+    for (int bit = 62; bit >= 0; bit--) {
+        f = coop_mul(c, f, f);
+        const int steps = ((BLS_X_ABS >> bit) & 1) ? 2 : 1;
+        for (int s = 0; s < steps; s++) {
+            // LN1 = line `line` of loop 1 and T1 are ready; stage loop 2's constants for this line
+            if (line > 0) coop_stage_line(c, COOP_SLOT_LN2, plan.lines28_g2, line, lane);
+            __syncthreads();
+            Fp r = coop_line<1>(c, f);               // spare lanes: T2 of this line
+            if (!skip1 && c.g < 12) f = r;
+            if (line + 1 < H2V_MILLER_LINES) coop_stage_line(c, COOP_SLOT_LN1, plan.lines28_sg2, line + 1, lane);
+            __syncthreads();
+            r = coop_line<2>(c, f);                  // spare lanes: T1 of the next line
+            if (!skip2 && c.g < 12) f = r;
+            line++;
+        }
+    }
+    f = coop_conj(c, f);  // x < 0
+    if (dbg && live && c.g < 12) {
+        Fp o;
+        fp_from_mont(o, f);
+#pragma unroll
+        for (int k = 0; k < 12; k++) dbg[((size_t)i * 24 + c.g) * 12 + k] = o.v[k];
+    }
+
+    // ---- final exponentiation: easy part, then 3(p^4-p^2+1)/r = (x-1)^2 (x+p)(x^2+p^2-1) + 3
+    bool inv_ok = true;
+    Fp a = coop_inv(c, f, inv_ok);
+    Fp t = coop_mul(c, coop_conj(c, f), a);                      // f^(p^6-1)
+    a = coop_frob(c, coop_frob(c, t));
+    t = coop_mul(c, a, t);                                       // ^(p^2+1)
+    a = coop_exp_x(c, t);
+    Fp t0 = coop_mul(c, a, coop_conj(c, t));                     // t^(x-1)
+    a = coop_exp_x(c, t0);
+    Fp t1 = coop_mul(c, a, coop_conj(c, t0));                    // ^(x-1)
+    a = coop_exp_x(c, t1);
+    Fp t2 = coop_mul(c, a, coop_frob(c, t1));                    // ^(x+p)
+    a = coop_exp_x(c, coop_exp_x(c, t2));
+    Fp t3 = coop_mul(c, a, coop_frob(c, coop_frob(c, t2)));
+    t3 = coop_mul(c, t3, coop_conj(c, t2));                      // ^(x^2+p^2-1)
+    a = coop_mul(c, coop_mul(c, t, t), t);                       // t^3
+    t3 = coop_mul(c, t3, a);
+    if (dbg && live && c.g < 12) {
+        Fp o;
+        fp_from_mont(o, t3);
+#pragma unroll
+        for (int k = 0; k < 12; k++) dbg[((size_t)i * 24 + 12 + c.g) * 12 + k] = o.v[k];
+    }
+    // == 1 ?
+    bool mine = true;
+    if (c.g == 0) { Fp one; fp_set_one(one); mine = fp_eq(t3, one); }
+    else if (c.g < 12) mine = fp_is_zero(t3);
+    const unsigned long long b = __ballot(mine);
+    const bool is_one = ((b >> (grp * 16)) & 0xffffull) == 0xffffull;
+    inv_ok = __shfl((int)inv_ok, grp * 16) != 0;
+    if (c.g == 0 && live) {
+        if (st == 0 && !(is_one && inv_ok)) st |= H2V_ST_PAIRING;
+        status[i] = st;
+        accept[i] = st == 0 ? 1 : 0;
+    }
+}

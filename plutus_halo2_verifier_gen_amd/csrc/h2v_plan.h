@@ -6,8 +6,8 @@
 #include <stdint.h>
 
 #define H2V_PLAN_MAGIC "H2VPLAN1"
-#define H2V_PLAN_VERSION 1u
-#define H2V_PLAN_HDR_WORDS 24
+#define H2V_PLAN_VERSION 2u
+#define H2V_PLAN_HDR_WORDS 34
 #define H2V_MILLER_LINES 68  // 63 doublings + 5 additions for |x| = 0xd201000000010000
 
 // header words (uint32 little-endian) after the 8-byte magic
@@ -16,7 +16,7 @@ enum {
     H2V_HW_N_POINTS, H2V_HW_N_VK_BASES, H2V_HW_N_TERMS, H2V_HW_N_TRACE, H2V_HW_PI_POINT, H2V_HW_N_SQUEEZES,
     H2V_HW_STREAM_LEN,
     H2V_HW_OFF_INSTR, H2V_HW_OFF_CONSTS, H2V_HW_OFF_POINTS, H2V_HW_OFF_VK_BASES, H2V_HW_OFF_TERMS, H2V_HW_OFF_LINES_SG2,
-    H2V_HW_OFF_LINES_G2, H2V_HW_OFF_TRACE, H2V_HW_TOTAL_LEN
+    H2V_HW_OFF_LINES_G2, H2V_HW_OFF_TRACE, H2V_HW_TOTAL_LEN, H2V_HW_OFF_LINES28_SG2, H2V_HW_OFF_LINES28_G2
 };
 
 // opcodes of the transcript + Fr-combiner program (8-byte instructions: op, pad, dst, a, b)
@@ -51,5 +51,7 @@ struct H2vDevPlan {
     const uint32_t *terms;     // n_terms * 2    (kind, index)
     const uint32_t *lines_sg2; // 68 * 48        (lambda.c0, lambda.c1, c.c0, c.c1)
     const uint32_t *lines_g2;
+    const uint32_t *lines28_sg2; // 68 * 8 operand slots of 16 dwords (28-bit limbs): cooperative pairing engine
+    const uint32_t *lines28_g2;
     const uint32_t *trace;     // n_trace * 2    (slot id, register)
 };

@@ -58,7 +58,8 @@ MAX_TRACE_EXPR = 256
 
 MILLER_LINES = 68
 PLAN_MAGIC = b"H2VPLAN1"
-PLAN_VERSION = 1
+PLAN_VERSION = 2
+PLAN_HDR_WORDS = 34  # 8 + 4*34 = 144 bytes: keeps every 16-byte-padded section 16-byte aligned
 
 ROT_LAST = "last"  # rotation key of x_last = w^-(bf+1) x
 
@@ -89,8 +90,8 @@ class Plan:
         return len(self.terms)
 
     def to_bytes(self) -> bytes:
-        def pad8(b: bytearray):
-            while len(b) % 8:
+        def pad8(b: bytearray):  # (16-byte alignment: the engine reads operand slots with 128-bit loads)
+            while len(b) % 16:
                 b.append(0)
 
         body = bytearray()
@@ -113,16 +114,20 @@ class Plan:
             assert len(tab) == MILLER_LINES
             section(name, b"".join(bls.f2_mont_bytes(lam) + bls.f2_mont_bytes(c) for lam, c in tab))
         section("trace", b"".join(struct.pack("<II", s, r) for s, r in self.trace))
+        # the same line tables as operand slots of the cooperative pairing engine (8 x 64 B per line)
+        for name, tab in (("lines28_sg2", self.lines_sg2), ("lines28_g2", self.lines_g2)):
+            section(name, b"".join(bls.line_slots(lam, c) for lam, c in tab))
         pad8(body)
-        hdr_len = 8 + 4 * 24
+        hdr_len = 8 + 4 * PLAN_HDR_WORDS
         fields = [PLAN_VERSION, self.proof_len, self.n_pi, self.n_ci, self.n_regs, len(self.instrs), len(self.consts),
                   len(self.points), len(self.vk_bases), len(self.terms), len(self.trace), self.pi_point,
                   self.n_squeezes, self.stream_len]
         sect = [hdr_len + offs[k] for k in ("instr", "consts", "points", "vk_bases", "terms", "lines_sg2", "lines_g2",
                                             "trace")]
         fields += sect + [hdr_len + len(body)]
-        fields += [0] * (24 - len(fields))
-        return PLAN_MAGIC + struct.pack("<24I", *fields) + bytes(body)
+        fields += [hdr_len + offs["lines28_sg2"], hdr_len + offs["lines28_g2"]]
+        fields += [0] * (PLAN_HDR_WORDS - len(fields))
+        return PLAN_MAGIC + struct.pack("<%dI" % PLAN_HDR_WORDS, *fields) + bytes(body)
 
 
 class _Builder:

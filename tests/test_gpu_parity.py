@@ -126,6 +126,30 @@ def test_pairing(be, orc, circuits):
     assert want[:6] == [1, 1, 0, 1, 1, 0]
 
 
+def test_pairing_cooperative_matches_one_lane_kernel(be, orc, circuits):
+    """The 16-lanes-per-proof pairing kernel against the one-lane-per-proof kernel: same Miller-loop value (all 12
+    Fp coefficients), same accept; final value == 1 exactly when accepted."""
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    rng = random.Random(6)
+    p1, p2 = [], []
+    for k in range(9):
+        A = bls.g1_mul(bls.G1_GEN, rng.randrange(1, R))
+        sA = bls.g1_mul(A, td.s)
+        if k % 3 == 2:
+            sA = bls.g1_add(sA, bls.G1_GEN)
+        p1.append(bls.g1_compress(A))
+        p2.append(bls.g1_compress(sA))
+    p1 += [bls.g1_compress(None), bls.g1_compress(bls.G1_GEN), bls.g1_compress(None)]
+    p2 += [bls.g1_compress(None), bls.g1_compress(None), bls.g1_compress(bls.G1_GEN)]
+    acc0, dump0 = be.probe_pairing_ex(dp, p1, p2, impl=0)
+    acc1, dump1 = be.probe_pairing_ex(dp, p1, p2, impl=1)
+    assert acc0 == acc1 == [1, 1, 0] * 3 + [1, 0, 0]
+    for i in range(len(p1)):
+        assert dump0[i][0] == dump1[i][0], "Miller loop value differs for pair %d" % i
+        is_one = dump1[i][1] == [1] + [0] * 11
+        assert is_one == bool(acc1[i])
+
+
 TRACE_NAMES = ["theta", "beta", "gamma", "trash", "y", "x", "x1", "x2", "x3", "x4", "x_prev", "x_next", "x_last", "xn",
                "l_last", "l_0", "active_rows", "h_eval", "vanishing_s", "f_eval", "v"]
 

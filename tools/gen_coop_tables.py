@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Generates plutus_halo2_verifier_gen_amd/csrc/coop_tables.h: the per-lane operand tables of the cooperative
+(16 lanes per proof) Fp12 engine used by the pairing kernel, and checks them against the package's big-integer
+Fp12 arithmetic before writing anything.
+
+Model.  Fp12 = Fp2[w]/(w^6 - xi), element = 6 Fp2 coefficients c_k = c_k0 + c_k1 u.  Lane g < 12 of a group owns the
+Fp value c_{k,part} with k = g >> 1, part = g & 1; lanes 12..15 are spare and compute the next line's per-proof
+products.  An engine call computes, in every lane,   out = sum_t  X[xs_t] * Y[ys_t]  (mod p)
+with ONE Montgomery reduction, X/Y being operand slots staged in LDS (28-bit limbs).  This file defines the slot map
+and the (xs, ys) lists of the two operations:
+   MUL   c = a * b          (12 terms)   slots A, NA (= -a_k1), B, XB (= xi * b)
+   LINE  f = f * (c + b w^2 + yP w^3)   (6 terms)   sparse Miller-loop line, c shared per step, b = (-lambda) xP
+"""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from plutus_halo2_verifier_gen_amd import bls12_381 as bls  # noqa: E402
+
+P = bls.P
+
+# ---- slot map (group-local slots < 64; wave-shared constant slots >= 64)
+SLOT_A = 0        # 12: a_{k,part} at A + 2k + part
+SLOT_NA = 12      # 6 : -a_{k,1}
+SLOT_B = 18       # 12
+SLOT_XB = 30      # 12: (xi * b)_{k,part}
+SLOT_T1 = 42      # 4 : loop-1 line products  b0, b1, (xi b)0, (xi b)1   with b = (-lambda) * xP1
+SLOT_T2 = 46      # 4 : same for loop 2
+SLOT_PX1, SLOT_PY1, SLOT_PX2, SLOT_PY2 = 50, 51, 52, 53
+SLOT_ZERO = 54
+N_GROUP_SLOTS = 56
+SH = 64           # shared slots: per line 8 constants  [nl0, nl1, nxl0, nxl1, c0, c1, xc0, xc1]
+SLOT_LN1 = SH + 0
+SLOT_LN2 = SH + 8
+N_SHARED_SLOTS = 16
+LN_NL0, LN_NL1, LN_NXL0, LN_NXL1, LN_C0, LN_C1, LN_XC0, LN_XC1 = range(8)
+
+N_MUL_TERMS = 12
+N_LINE_TERMS = 6
+
+
+def mul_table():
+    tab = []
+    for g in range(16):
+        terms = []
+        if g < 12:
+            k, part = g >> 1, g & 1
+            for i in range(6):
+                j = (k - i) % 6
+                wrapped = i > k
+                bj = SLOT_XB if wrapped else SLOT_B
+                if part == 0:
+                    terms.append((SLOT_A + 2 * i, bj + 2 * j))          # a_i0 * b_j0
+                    terms.append((SLOT_NA + i, bj + 2 * j + 1))         # (-a_i1) * b_j1
+                else:
+                    terms.append((SLOT_A + 2 * i, bj + 2 * j + 1))      # a_i0 * b_j1
+                    terms.append((SLOT_A + 2 * i + 1, bj + 2 * j))      # a_i1 * b_j0
+        while len(terms) < N_MUL_TERMS:
+            terms.append((SLOT_ZERO, SLOT_ZERO))
+        tab.append(terms)
+    return tab
+
+
+def line_table(loop):
+    """loop 1: constants LN1, products T1, point PY1 ; spare lanes compute the loop-2 products T2 (from LN2, PX2).
+    loop 2: constants LN2, products T2, point PY2 ; spare lanes compute the NEXT loop-1 products T1 (from LN1, PX1)."""
+    ln = SLOT_LN1 if loop == 1 else SLOT_LN2
+    tt = SLOT_T1 if loop == 1 else SLOT_T2
+    py = SLOT_PY1 if loop == 1 else SLOT_PY2
+    oln = SLOT_LN2 if loop == 1 else SLOT_LN1
+    opx = SLOT_PX2 if loop == 1 else SLOT_PX1
+    tab = []
+    for g in range(16):
+        terms = []
+        if g < 12:
+            k, part = g >> 1, g & 1
+            # j = 0: b_0 = c (never wrapped: i = k)
+            i = k
+            if part == 0:
+                terms += [(SLOT_A + 2 * i, ln + LN_C0), (SLOT_NA + i, ln + LN_C1)]
+            else:
+                terms += [(SLOT_A + 2 * i, ln + LN_C1), (SLOT_A + 2 * i + 1, ln + LN_C0)]
+            # j = 2: b_2 = b = (-lambda) xP  (products T: b0, b1, xb0, xb1)
+            i = (k - 2) % 6
+            wrapped = i > k
+            b0, b1 = (tt + 2, tt + 3) if wrapped else (tt + 0, tt + 1)
+            if part == 0:
+                terms += [(SLOT_A + 2 * i, b0), (SLOT_NA + i, b1)]
+            else:
+                terms += [(SLOT_A + 2 * i, b1), (SLOT_A + 2 * i + 1, b0)]
+            # j = 3: b_3 = (yP, 0); xi * (yP, 0) = (yP, yP)
+            i = (k - 3) % 6
+            wrapped = i > k
+            if not wrapped:
+                terms += [(SLOT_A + 2 * i + part, py)]
+            elif part == 0:
+                terms += [(SLOT_A + 2 * i, py), (SLOT_NA + i, py)]
+            else:
+                terms += [(SLOT_A + 2 * i, py), (SLOT_A + 2 * i + 1, py)]
+        else:
+            # spare lane s computes one product of the other loop's next line: [nl0, nl1, nxl0, nxl1][s] * xP
+            terms.append((oln + (g - 12), opx))
+        assert len(terms) <= N_LINE_TERMS
+        while len(terms) < N_LINE_TERMS:
+            terms.append((SLOT_ZERO, SLOT_ZERO))
+        tab.append(terms)
+    return tab
+
+
+# ----------------------------------------------------------------------------- big-integer simulation
+def stage_mul(a, b):
+    """a, b: flat Fp12 (6 Fp2).  Returns slot dict."""
+    s = {SLOT_ZERO: 0}
+    for k in range(6):
+        s[SLOT_A + 2 * k], s[SLOT_A + 2 * k + 1] = a[k]
+        s[SLOT_NA + k] = (-a[k][1]) % P
+        s[SLOT_B + 2 * k], s[SLOT_B + 2 * k + 1] = b[k]
+        xb = bls.f2_mul(bls.XI, b[k])
+        s[SLOT_XB + 2 * k], s[SLOT_XB + 2 * k + 1] = xb
+    return s
+
+
+def run(tab, slots):
+    out = []
+    for g in range(16):
+        acc = 0
+        for xs, ys in tab[g]:
+            acc += slots[xs] * slots[ys]
+        out.append(acc % P)
+    return out
+
+
+def to_flat(lanes):
+    return [(lanes[2 * k], lanes[2 * k + 1]) for k in range(6)]
+
+
+def line_consts(lam, c):
+    nl = bls.f2_neg(lam)
+    nxl = bls.f2_mul(bls.XI, nl)
+    xc = bls.f2_mul(bls.XI, c)
+    return [nl[0], nl[1], nxl[0], nxl[1], c[0], c[1], xc[0], xc[1]]
+
+
+def self_check():
+    rng = random.Random(1)
+    rf2 = lambda: (rng.randrange(P), rng.randrange(P))
+    mt = mul_table()
+    for _ in range(10):
+        a = [rf2() for _ in range(6)]
+        b = [rf2() for _ in range(6)]
+        assert to_flat(run(mt, stage_mul(a, b))) == bls.f12_mul(a, b)
+    for loop in (1, 2):
+        lt = line_table(loop)
+        for _ in range(10):
+            f = [rf2() for _ in range(6)]
+            lam, c, lam_o = rf2(), rf2(), rf2()
+            xp, yp, xo = rng.randrange(P), rng.randrange(P), rng.randrange(P)
+            s = stage_mul(f, [bls.F2_ZERO] * 6)
+            ln = SLOT_LN1 if loop == 1 else SLOT_LN2
+            oln = SLOT_LN2 if loop == 1 else SLOT_LN1
+            tt = SLOT_T1 if loop == 1 else SLOT_T2
+            for q, v in enumerate(line_consts(lam, c)):
+                s[ln + q] = v
+            for q, v in enumerate(line_consts(lam_o, (0, 0))):
+                s[oln + q] = v
+            for q in range(4):
+                s[tt + q] = s[ln + q] * xp % P
+            s[SLOT_PY1 if loop == 1 else SLOT_PY2] = yp
+            s[SLOT_PX2 if loop == 1 else SLOT_PX1] = xo
+            out = run(lt, s)
+            line = [c, bls.F2_ZERO, bls.f2_scale(bls.f2_neg(lam), xp), (yp, 0), bls.F2_ZERO, bls.F2_ZERO]
+            assert to_flat(out) == bls.f12_mul(f, line)
+            # spare lanes: products for the other loop's next line
+            exp = [v * xo % P for v in line_consts(lam_o, (0, 0))[:4]]
+            assert out[12:16] == exp
+    return True
+
+
+def emit():
+    assert self_check()
+    o = ["// GENERATED by tools/gen_coop_tables.py (tables verified against big-integer Fp12 arithmetic) - do not edit.",
+         "#pragma once", "#include <stdint.h>"]
+    for name in ("SLOT_A", "SLOT_NA", "SLOT_B", "SLOT_XB", "SLOT_T1", "SLOT_T2", "SLOT_PX1", "SLOT_PY1", "SLOT_PX2",
+                 "SLOT_PY2", "SLOT_ZERO", "N_GROUP_SLOTS", "SLOT_LN1", "SLOT_LN2", "N_SHARED_SLOTS", "N_MUL_TERMS",
+                 "N_LINE_TERMS"):
+        o.append("#define COOP_%s %d" % (name, globals()[name]))
+    o.append("#define COOP_SHARED_BASE %d" % SH)
+
+    def arr(name, tab, n):
+        rows = []
+        for g in range(16):
+            rows.append("{" + ", ".join("%d, %d" % t for t in tab[g]) + "}")
+        o.append("__device__ static constexpr uint8_t %s[16][%d] = {\n    %s};" % (name, 2 * n, ",\n    ".join(rows)))
+
+    arr("COOP_TAB_MUL", mul_table(), N_MUL_TERMS)
+    arr("COOP_TAB_LINE1", line_table(1), N_LINE_TERMS)
+    arr("COOP_TAB_LINE2", line_table(2), N_LINE_TERMS)
+    path = os.path.join(ROOT, "plutus_halo2_verifier_gen_amd", "csrc", "coop_tables.h")
+    with open(path, "w") as f:
+        f.write("\n".join(o) + "\n")
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    emit()
