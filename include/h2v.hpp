@@ -1,0 +1,120 @@
+// C++ host-side mirror of the reference's verify interface for the hot path, header-only, over the C-ABI of h2v.h.
+//
+// The reference's toolchain (Rust) is absent from this image, so the layer a Rust maintainer would write above the
+// FFI is given here in C++ with the reference's names and argument meaning:
+//
+//     let mut t = CircuitTranscript::<CardanoFriendlyBlake2b>::init_from_bytes(&proof);     // examples/simple_mul.rs:97
+//     let guard = prepare(&vk, &[&[]], &[&[&instance]], &mut t)?;                            // examples/simple_mul.rs:98
+//     guard.verify(&kzg_params.verifier_params())?;                                          // examples/simple_mul.rs:101
+//
+//     h2v::CircuitTranscript t = h2v::CircuitTranscript::init_from_bytes(proof);
+//     h2v::Guard guard = h2v::prepare(vk, {}, {instance_scalars_le32}, t);                   // throws h2v::Error on misuse
+//     guard.verify();                                                                        // throws h2v::VerifyError
+//
+// `VerifyingKey` wraps a plan blob produced by plutus_halo2_verifier_gen_amd.plan.compile_plan(vk).to_bytes()
+// (the counterpart of extract_circuit, /root/reference/src/plutus_gen/extraction/mod.rs:31).
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "h2v.h"
+
+namespace h2v {
+
+struct Error : std::runtime_error {  // API misuse / device error (negative H2V_E_* codes)
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+struct VerifyError : std::runtime_error {  // Err(plonk::Error): the proof does not verify
+    uint32_t status;                       // H2V_ST_* bits
+    explicit VerifyError(uint32_t st) : std::runtime_error("proof rejected (status " + std::to_string(st) + ")"), status(st) {}
+};
+inline void check(int rc) {
+    if (rc != H2V_OK) throw Error(rc, h2v_last_error());
+}
+
+class VerifyingKey {  // VerifyingKey<F, KZGCommitmentScheme<Bls12>> + ParamsVerifierKZG for this path
+  public:
+    VerifyingKey(const uint8_t *plan_blob, size_t len, int device = 0) { check(h2v_plan_load(plan_blob, len, device, &p_)); }
+    VerifyingKey(const VerifyingKey &) = delete;
+    VerifyingKey &operator=(const VerifyingKey &) = delete;
+    ~VerifyingKey() { h2v_plan_free(p_); }
+    const h2v_plan *handle() const { return p_; }
+    uint32_t proof_len() const { uint32_t v; check(h2v_plan_info(p_, &v, nullptr, nullptr, nullptr)); return v; }
+    uint32_t n_public_inputs() const { uint32_t v; check(h2v_plan_info(p_, nullptr, &v, nullptr, nullptr)); return v; }
+    uint32_t n_committed_instances() const { uint32_t v; check(h2v_plan_info(p_, nullptr, nullptr, &v, nullptr)); return v; }
+
+  private:
+    h2v_plan *p_ = nullptr;
+};
+
+class CircuitTranscript {  // verifier-side transcript: a cursor over the proof bytes (hashing happens on the GPU)
+  public:
+    static CircuitTranscript init_from_bytes(std::vector<uint8_t> proof) { return CircuitTranscript(std::move(proof)); }
+    const std::vector<uint8_t> &bytes() const { return proof_; }
+    void mark_consumed(size_t n) { consumed_ = n; }
+    void assert_empty() const {  // examples/ivc.rs:92-94
+        if (consumed_ != proof_.size()) throw VerifyError(0);
+    }
+
+  private:
+    explicit CircuitTranscript(std::vector<uint8_t> p) : proof_(std::move(p)) {}
+    std::vector<uint8_t> proof_;
+    size_t consumed_ = 0;
+};
+
+class Guard {  // CS::VerificationGuard: consumed by verify() (Guard::verify) or check() (DualMSM::check)
+  public:
+    Guard(const VerifyingKey &vk, std::vector<uint8_t> proof, std::vector<uint8_t> instances, std::vector<uint8_t> committed)
+        : vk_(vk), proof_(std::move(proof)), inst_(std::move(instances)), ci_(std::move(committed)) {}
+    void verify() {
+        const uint32_t st = run();
+        if (st) throw VerifyError(st);
+    }
+    bool check() { return run() == 0; }
+
+  private:
+    uint32_t run() {
+        if (used_) throw Error(H2V_E_ARG, "guard already consumed");
+        used_ = true;
+        uint32_t st = 0;
+        uint8_t acc = 0;
+        h2v::check(h2v_trace(vk_.handle(), proof_.data(), proof_.size(), inst_.empty() ? nullptr : inst_.data(),
+                             ci_.empty() ? nullptr : ci_.data(), nullptr, nullptr, nullptr, nullptr, &st, &acc));
+        return acc ? 0u : (st ? st : H2V_ST_PAIRING);
+    }
+    const VerifyingKey &vk_;
+    std::vector<uint8_t> proof_, inst_, ci_;
+    bool used_ = false;
+};
+
+// prepare(&vk, committed_instances, instances, &mut transcript): committed = 0 or 1 compressed G1 (48 B),
+// instances = the public-input scalars of the single public column, 32 B little-endian each.
+inline Guard prepare(const VerifyingKey &vk, const std::vector<std::vector<uint8_t>> &committed_instances,
+                     const std::vector<std::vector<uint8_t>> &instances, CircuitTranscript &transcript) {
+    if (instances.size() != vk.n_public_inputs()) throw Error(H2V_E_ARG, "wrong number of public inputs");
+    if (committed_instances.size() != vk.n_committed_instances()) throw Error(H2V_E_ARG, "wrong number of committed instances");
+    std::vector<uint8_t> inst, ci;
+    for (const auto &s : instances) {
+        if (s.size() != 32) throw Error(H2V_E_ARG, "instance scalars are 32 bytes little-endian");
+        inst.insert(inst.end(), s.begin(), s.end());
+    }
+    for (const auto &c : committed_instances) {
+        if (c.size() != 48) throw Error(H2V_E_ARG, "committed instances are 48-byte compressed G1");
+        ci.insert(ci.end(), c.begin(), c.end());
+    }
+    transcript.mark_consumed(vk.proof_len());
+    return Guard(vk, transcript.bytes(), std::move(inst), std::move(ci));
+}
+
+// The batched form the hardware wants: accept[i] for n independent proofs (host buffers).
+inline std::vector<uint8_t> verify_batch(const VerifyingKey &vk, const h2v_batch &batch, h2v_workspace *ws = nullptr) {
+    std::vector<uint8_t> accept(batch.n);
+    check(h2v_verify_batch(vk.handle(), &batch, accept.data(), ws));
+    return accept;
+}
+
+}  // namespace h2v

@@ -831,3 +831,26 @@ def plan_stats(plan: Plan) -> dict:
     return {"instrs": len(plan.instrs), "regs": plan.n_regs, "consts": len(plan.consts), "points": len(plan.points),
             "terms": plan.n_terms, "proof_len": plan.proof_len, "ops": hist, "squeezes": plan.n_squeezes,
             "stream_len": plan.stream_len}
+
+
+def _main():
+    """python -m plutus_halo2_verifier_gen_amd.plan vk.json plan.bin   (or a builtin circuit name instead of vk.json)"""
+    import sys
+    from . import vk as V
+
+    if len(sys.argv) != 3:
+        raise SystemExit(_main.__doc__)
+    src, dst = sys.argv[1:]
+    if src in V.BUILDERS:
+        key, _ = V.BUILDERS[src]()
+    else:
+        with open(src) as f:
+            key = VerifyingKey.from_json(f.read())
+    plan = compile_plan(key)
+    with open(dst, "wb") as f:
+        f.write(plan.to_bytes())
+    print(plan_stats(plan))
+
+
+if __name__ == "__main__":
+    _main()
