@@ -547,3 +547,22 @@ def line_slots(lam, c) -> bytes:
     nxl = f2_mul(XI, nl)
     xc = f2_mul(XI, c)
     return b"".join(fp_mont28_slot(v) for v in (nl[0], nl[1], nxl[0], nxl[1], c[0], c[1], xc[0], xc[1]))
+
+
+# ----------------------------------------------------------------------------- GLV (model of the device code)
+GLV_LAMBDA = BLS_X * BLS_X - 1
+GLV_MU = (1 << 383) // GLV_LAMBDA
+
+
+def glv_split(k: int):
+    """k = k2*lambda + k1 with 0 <= k1 < lambda, exactly as csrc/h2v_curve.cuh: glv_split computes it
+    (Barrett estimate floor(k*mu / 2^383), at most two corrections)."""
+    q = (k * GLV_MU) >> 383
+    rem = k - q * GLV_LAMBDA
+    n_corr = 0
+    while rem >= GLV_LAMBDA:
+        rem -= GLV_LAMBDA
+        q += 1
+        n_corr += 1
+    assert n_corr <= 2
+    return rem, q

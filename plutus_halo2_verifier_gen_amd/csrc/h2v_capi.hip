@@ -241,6 +241,15 @@ extern "C" void h2v_workspace_free(h2v_workspace *w) {
     delete w;
 }
 
+// MSM launch geometry: 2 lanes per (proof, term); block = max(64, 2*tp) threads, LDS 144 B per thread.
+static void launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, uint32_t *er, hipStream_t st) {
+    const uint32_t tp = next_pow2(d.n_terms);
+    const uint32_t bs = 2 * tp < 64 ? 64 : 2 * tp;
+    const uint32_t per_block = bs / (2 * tp);
+    const uint32_t blocks = (n + per_block - 1) / per_block;
+    hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 144, st, d, n, tp, scalars, pts, er);
+}
+
 // Pairing kernel selection: the cooperative 16-lanes-per-proof kernel is the product path; the one-lane-per-proof
 // kernel stays as a cross-check (H2V_PAIRING=legacy, or impl = 0 in the probe).
 static void launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint32_t *er,
@@ -261,10 +270,8 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
                         const uint8_t *ci, uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st,
                         h2v_timings *tm, bool want_trace) {
     const uint32_t slots = d.n_points + d.n_ci;
-    const uint32_t tp = next_pow2(d.n_terms);
     const uint32_t vm_blocks = (n + 63) / 64;
     const uint32_t dec_blocks = (n * slots + 63) / 64;
-    const uint32_t msm_blocks = (n + (64 / tp) - 1) / (64 / tp);
     uint32_t *trace = want_trace ? w->trace : nullptr;
     uint32_t *status = w->status;
     static const bool dbg = getenv("H2V_DEBUG_SYNC") != nullptr;  // serialise + sync after every kernel, say which one ran
@@ -277,7 +284,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         fprintf(stderr, "[h2v] %s done\n", name); fflush(stderr);
         DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(64), 0, st, d, n, proofs, off, ci, w->pts, w->valid))
         DBG_STAGE("k_transcript_combiner", hipLaunchKernelGGL(k_transcript_combiner, dim3(vm_blocks), dim3(64), 0, st, d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace))
-        DBG_STAGE("k_g1_msm", hipLaunchKernelGGL(k_g1_msm, dim3(msm_blocks), dim3(MSM_BLOCK), 0, st, d, n, tp, w->scalars, w->pts, w->er))
+        DBG_STAGE("k_g1_msm", launch_msm(d, n, w->scalars, w->pts, w->er, st))
         DBG_STAGE("k_pairing_check", launch_pairing(d, n, w->pts, w->valid, w->er, status, accept, nullptr, st))
 #undef DBG_STAGE
         if (status_out) HIPCHK(hipMemcpyAsync(status_out, status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
@@ -297,7 +304,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
     HIPCHK(hipEventRecord(ev[1], st));
     HIPCHK(hipStreamWaitEvent(st, w->ev_join, 0));
     HIPCHK(hipEventRecord(ev[4], st));
-    hipLaunchKernelGGL(k_g1_msm, dim3(msm_blocks), dim3(MSM_BLOCK), 0, st, d, n, tp, w->scalars, w->pts, w->er);
+    launch_msm(d, n, w->scalars, w->pts, w->er, st);
     HIPCHK(hipEventRecord(ev[5], st));
     launch_pairing(d, n, w->pts, w->valid, w->er, status, accept, nullptr, st);
     HIPCHK(hipEventRecord(ev[6], st));
@@ -531,9 +538,8 @@ extern "C" int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_
         return fail(H2V_E_DEVICE, "probe setup failed");
     HIPCHK(hipMemcpy(din.p, bases_compressed, (size_t)n * T * 48, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dsc.p, scalars, (size_t)n * T * 32, hipMemcpyHostToDevice));
-    const uint32_t tp = next_pow2(T);
     hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(64), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
-    hipLaunchKernelGGL(k_g1_msm, dim3((n + (64 / tp) - 1) / (64 / tp)), dim3(MSM_BLOCK), 0, nullptr, mp.d, n, tp, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>());
+    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), nullptr);
     hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 1, der.as<uint32_t>(), dout.as<uint8_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
@@ -566,7 +572,7 @@ extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t
     HIPCHK(hipMemcpy(dsc.p, one.data(), one.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dst.p, 0, (size_t)n * 4));
     hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(64), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
-    hipLaunchKernelGGL(k_g1_msm, dim3((n + 63) / 64), dim3(MSM_BLOCK), 0, nullptr, mp.d, n, 1u, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>());
+    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), nullptr);
     if (ddbg.alloc(dbg ? (size_t)n * 24 * 48 : 8)) return fail(H2V_E_DEVICE, "hipMalloc failed");
     launch_pairing_impl(impl, mp.d, n, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), der.as<uint32_t>(), dst.as<uint32_t>(), dacc.as<uint8_t>(), dbg ? ddbg.as<uint32_t>() : nullptr, nullptr);
     HIPCHK(hipGetLastError());

@@ -113,3 +113,80 @@ H2V_DN bool g1a_in_subgroup(const G1A &a) {
     fp_neg(ny, t.y);
     return fp_eq(l, ny);
 }
+
+// ------------------------------------------------------------------ GLV scalar split
+// phi(x, y) = (beta' x, y) is [lambda] on G1 with lambda = x^2 - 1 ~ sqrt(r), so an Fr scalar k < r splits by plain
+// division k = k2*lambda + k1 into two halves below 2^128: [k]P = [k1]P + [k2]phi(P).  Barrett estimate
+// q = floor(k * floor(2^383/lambda) / 2^383), then at most two corrections (model: bls12_381.py: glv_split).
+H2V_DI void glv_split(uint32_t (&k1)[4], uint32_t (&k2)[4], const uint32_t (&k)[8]) {
+    // prod = k * MU (16 words), column-wise with a 64-bit accumulator + overflow word
+    uint32_t prod[16];
+    uint64_t acc = 0;
+    uint32_t over = 0;
+#pragma unroll
+    for (int c = 0; c < 15; c++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int j = c - i;
+            if (j < 0 || j > 7) continue;
+            const uint64_t t = (uint64_t)k[i] * GLV_MU[j];
+            acc += t;
+            over += acc < t ? 1u : 0u;
+        }
+        prod[c] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)over << 32);
+        over = 0;
+    }
+    prod[15] = (uint32_t)acc;
+    // q = prod >> 383  (word 11, bit 31)
+    uint32_t q[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = (prod[11 + i] >> 31) | (prod[12 + i] << 1);
+    // rem = k - q*lambda  (fits 5 words: rem < 3*lambda)
+    uint32_t ql[8];
+    acc = 0;
+    over = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int j = c - i;
+            if (j < 0 || j > 3) continue;
+            const uint64_t t = (uint64_t)q[i] * GLV_LAMBDA[j];
+            acc += t;
+            over += acc < t ? 1u : 0u;
+        }
+        ql[c] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)over << 32);
+        over = 0;
+    }
+    uint32_t rem[5];
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const uint64_t d = (uint64_t)k[i] - ql[i] - br;
+        rem[i] = (uint32_t)d;
+        br = (d >> 63) & 1;
+    }
+#pragma unroll 1
+    for (int it = 0; it < 2; it++) {
+        // rem >= lambda ?
+        uint32_t d[5];
+        uint64_t b2 = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const uint64_t t = (uint64_t)rem[i] - (i < 4 ? GLV_LAMBDA[i] : 0u) - b2;
+            d[i] = (uint32_t)t;
+            b2 = (t >> 63) & 1;
+        }
+        if (b2 == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) rem[i] = d[i];
+            uint64_t c = 1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { c += q[i]; q[i] = (uint32_t)c; c >>= 32; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { k1[i] = rem[i]; k2[i] = q[i]; }
+}

@@ -74,45 +74,35 @@ struct Field {
     // r = a - mod if a >= mod (a < 2*mod), with optional extra top carry
     H2V_DI static void cond_sub(T &r, const uint32_t *a, uint32_t top) {
         uint32_t d[N];
-        uint64_t br = 0;
+        uint32_t br = 0, bo;
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            uint64_t t = (uint64_t)a[i] - PR::mod(i) - br;
-            d[i] = (uint32_t)t;
-            br = (t >> 63) & 1;
-        }
-        bool use = (top != 0) || (br == 0);
+        for (int i = 0; i < N; i++) { d[i] = __builtin_subc(a[i], PR::mod(i), br, &bo); br = bo; }
+        const bool use = (top != 0) || (br == 0);
 #pragma unroll
         for (int i = 0; i < N; i++) r.v[i] = use ? d[i] : a[i];
     }
+    // add / sub as v_add_co / v_addc_co carry chains (the u64-emulated forms cost ~4x the instructions)
     H2V_DI static void add(T &r, const T &a, const T &b) {
-        uint32_t s[N];
-        uint64_t c = 0;
+        uint32_t s[N], d[N];
+        uint32_t c = 0, co;
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            c += (uint64_t)a.v[i] + b.v[i];
-            s[i] = (uint32_t)c;
-            c >>= 32;
-        }
-        cond_sub(r, s, (uint32_t)c);
+        for (int i = 0; i < N; i++) { s[i] = __builtin_addc(a.v[i], b.v[i], c, &co); c = co; }
+        uint32_t br = 0, bo;
+#pragma unroll
+        for (int i = 0; i < N; i++) { d[i] = __builtin_subc(s[i], PR::mod(i), br, &bo); br = bo; }
+        const bool use = (c != 0) || (br == 0);
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = use ? d[i] : s[i];
     }
     H2V_DI static void sub(T &r, const T &a, const T &b) {
         uint32_t d[N];
-        uint64_t br = 0;
+        uint32_t br = 0, bo;
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            uint64_t t = (uint64_t)a.v[i] - b.v[i] - br;
-            d[i] = (uint32_t)t;
-            br = (t >> 63) & 1;
-        }
-        uint32_t mask = (uint32_t)0 - (uint32_t)br;
-        uint64_t c = 0;
+        for (int i = 0; i < N; i++) { d[i] = __builtin_subc(a.v[i], b.v[i], br, &bo); br = bo; }
+        const uint32_t mask = 0u - br;
+        uint32_t c = 0, co;
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            c += (uint64_t)d[i] + (PR::mod(i) & mask);
-            r.v[i] = (uint32_t)c;
-            c >>= 32;
-        }
+        for (int i = 0; i < N; i++) { r.v[i] = __builtin_addc(d[i], PR::mod(i) & mask, c, &co); c = co; }
     }
     H2V_DI static void neg(T &r, const T &a) {
         T z;

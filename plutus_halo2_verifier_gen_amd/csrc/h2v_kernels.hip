@@ -275,7 +275,7 @@ k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_
 // bit5 "y is the lexicographically larger root"; y = (x^3+4)^((p+1)/4).
 // One lane per (proof, point).  Slot n_points is the committed instance when the circuit has one.
 // out: affine Montgomery x||y (24 dwords, (0,0) = infinity); valid[...] = 1 iff the encoding is a point of G1.
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, 2)
 k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
                 const uint8_t *__restrict__ committed, uint32_t *__restrict__ pts, uint8_t *__restrict__ valid) {
     const uint32_t slots = plan.n_points + plan.n_ci;
@@ -335,18 +335,22 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
 // ============================================================================ K4: per-proof G1 MSM
 // er = sum_t s_t * B_t with T = n_terms (16 ... ~60) 255-bit scalars per proof.  T is far too small for bucket
 // (Pippenger) accumulation to pay - 2^c buckets per window would outnumber the terms - so the mapping is:
-// one lane per (proof, term), MSB-first double-and-add with mixed additions on the affine base, then a
-// segmented tree reduction of the TP = 2^ceil(log2 T) partial sums of each proof through LDS.
+//   * TWO lanes per (proof, term): the GLV split k = k1 + k2*lambda gives lane 0 the pair (k1, P) and lane 1
+//     (k2, phi(P) = (beta' x, y)), both scalars below 2^128 (half the doubling chain, twice the waves);
+//   * per lane a signed 4-bit window ladder: table [1..8]*P in private memory (Jacobian), 32 windows of
+//     4 doublings + one table addition (digits in [-8, 8]);
+//   * a segmented tree reduction of the 2*TP partial sums of each proof through LDS (TP = 2^ceil(log2 T)).
 // Bytes per term: 32 (scalar) + 96 (affine base) in, 144 per proof out (Jacobian).
-#define MSM_BLOCK 64
-extern "C" __global__ void __launch_bounds__(MSM_BLOCK)
+extern "C" __global__ void __launch_bounds__(128, 2)
 k_g1_msm(H2vDevPlan plan, uint32_t n, uint32_t tp /* pow2 >= n_terms, <= 64 */, const uint32_t *__restrict__ scalars,
          const uint32_t *__restrict__ pts, uint32_t *__restrict__ out) {
-    __shared__ uint32_t red[36 * MSM_BLOCK];  // Jacobian partial sums, dword d of lane l at red[d*64 + l]
-    const int tid = threadIdx.x;
-    const uint32_t per_block = MSM_BLOCK / tp;
-    const uint32_t term = tid % tp;
-    const uint32_t i = blockIdx.x * per_block + tid / tp;
+    extern __shared__ uint32_t red[];  // Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t]
+    const uint32_t tid = threadIdx.x, bs = blockDim.x;
+    const uint32_t lanes_per_proof = 2 * tp;
+    const uint32_t per_block = bs / lanes_per_proof;
+    const uint32_t sub = tid % lanes_per_proof;       // position inside the proof's segment
+    const uint32_t term = sub >> 1, half = sub & 1;
+    const uint32_t i = blockIdx.x * per_block + tid / lanes_per_proof;
     const bool active = i < n && term < plan.n_terms;
     G1J acc;
     g1j_set_inf(acc);
@@ -363,45 +367,82 @@ k_g1_msm(H2vDevPlan plan, uint32_t n, uint32_t tp /* pow2 >= n_terms, <= 64 */, 
         G1A base;
 #pragma unroll
         for (int k = 0; k < 12; k++) { base.x.v[k] = bp[k]; base.y.v[k] = bp[12 + k]; }
-        uint32_t s[8];
+        uint32_t s[8], k1[4], k2[4], kk[4];
         const uint32_t *sp = scalars + ((size_t)i * plan.n_terms + term) * 8;
 #pragma unroll
         for (int k = 0; k < 8; k++) s[k] = sp[k];
-        if (!g1a_is_inf(base)) {
-            for (int bit = 254; bit >= 0; bit--) {
-                g1j_dbl(acc, acc);
-                if ((s[bit >> 5] >> (bit & 31)) & 1) g1j_add_affine(acc, acc, base);
+        glv_split(k1, k2, s);
+#pragma unroll
+        for (int k = 0; k < 4; k++) kk[k] = half ? k2[k] : k1[k];
+        if (!g1a_is_inf(base) && (kk[0] | kk[1] | kk[2] | kk[3]) != 0) {
+            if (half) {  // phi(P)
+                Fp beta;
+#pragma unroll
+                for (int k = 0; k < 12; k++) beta.v[k] = FP_BETA_GLV[k];
+                fp_mul(base.x, base.x, beta);
+            }
+            // signed 4-bit recoding, least significant digit first: digit = dg[q] in [-8, 8]
+            int8_t dg[33];
+            uint32_t carry = 0;
+#pragma unroll 1
+            for (int q = 0; q < 32; q++) {
+                uint32_t d = ((kk[q >> 3] >> (4 * (q & 7))) & 15u) + carry;
+                carry = d > 8 ? 1u : 0u;
+                dg[q] = (int8_t)(carry ? (int)d - 16 : (int)d);
+            }
+            dg[32] = (int8_t)carry;
+            // table[m-1] = m*P, m = 1..8
+            G1J tab[8];
+            g1j_from_affine(tab[0], base);
+            g1j_dbl(tab[1], tab[0]);
+            g1j_add_affine(tab[2], tab[1], base);
+            g1j_dbl(tab[3], tab[1]);
+            g1j_add_affine(tab[4], tab[3], base);
+            g1j_dbl(tab[5], tab[2]);
+            g1j_add_affine(tab[6], tab[5], base);
+            g1j_dbl(tab[7], tab[3]);
+#pragma unroll 1
+            for (int q = 32; q >= 0; q--) {
+                if (q != 32) {
+                    g1j_dbl(acc, acc); g1j_dbl(acc, acc); g1j_dbl(acc, acc); g1j_dbl(acc, acc);
+                }
+                const int d = dg[q];
+                if (d != 0) {
+                    G1J t = tab[(d < 0 ? -d : d) - 1];
+                    if (d < 0) fp_neg(t.y, t.y);
+                    g1j_add(acc, acc, t);
+                }
             }
         }
     }
-    // segmented reduction over the tp lanes of each proof
+    // segmented reduction over the 2*tp lanes of each proof
 #pragma unroll
     for (int k = 0; k < 12; k++) {
-        red[k * 64 + tid] = acc.x.v[k];
-        red[(12 + k) * 64 + tid] = acc.y.v[k];
-        red[(24 + k) * 64 + tid] = acc.z.v[k];
+        red[k * bs + tid] = acc.x.v[k];
+        red[(12 + k) * bs + tid] = acc.y.v[k];
+        red[(24 + k) * bs + tid] = acc.z.v[k];
     }
     __syncthreads();
-    for (uint32_t s = tp >> 1; s >= 1; s >>= 1) {
-        if (term < s) {
+    for (uint32_t s = lanes_per_proof >> 1; s >= 1; s >>= 1) {
+        if (sub < s) {
             G1J other;
 #pragma unroll
             for (int k = 0; k < 12; k++) {
-                other.x.v[k] = red[k * 64 + tid + s];
-                other.y.v[k] = red[(12 + k) * 64 + tid + s];
-                other.z.v[k] = red[(24 + k) * 64 + tid + s];
+                other.x.v[k] = red[k * bs + tid + s];
+                other.y.v[k] = red[(12 + k) * bs + tid + s];
+                other.z.v[k] = red[(24 + k) * bs + tid + s];
             }
             g1j_add(acc, acc, other);
 #pragma unroll
             for (int k = 0; k < 12; k++) {
-                red[k * 64 + tid] = acc.x.v[k];
-                red[(12 + k) * 64 + tid] = acc.y.v[k];
-                red[(24 + k) * 64 + tid] = acc.z.v[k];
+                red[k * bs + tid] = acc.x.v[k];
+                red[(12 + k) * bs + tid] = acc.y.v[k];
+                red[(24 + k) * bs + tid] = acc.z.v[k];
             }
         }
         __syncthreads();
     }
-    if (term == 0 && i < n) {
+    if (sub == 0 && i < n) {
 #pragma unroll
         for (int k = 0; k < 12; k++) {
             out[(size_t)i * 36 + k] = acc.x.v[k];

@@ -229,7 +229,7 @@ H2V_DN Fp coop_inv(const Coop c, const Fp f, bool &ok) {
 
 // dbg (optional): per proof 2 x 12 Fp (canonical, 12 dwords each): f after the Miller loop, f after the final
 // exponentiation; flat order (k, part).
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, 2)
 k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid,
                const uint32_t *__restrict__ er_jac, uint32_t *__restrict__ status, uint8_t *__restrict__ accept,
                uint32_t *__restrict__ dbg) {
