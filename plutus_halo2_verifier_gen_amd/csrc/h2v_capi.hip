@@ -255,7 +255,7 @@ static void launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars,
 static void launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint32_t *er,
                                 uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st) {
     if (impl == 0) hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, er, status, accept, dbg);
-    else hipLaunchKernelGGL(k_pairing_coop, dim3((n + 3) / 4), dim3(64), 0, st, d, n, pts, valid, er, status, accept, dbg);
+    else hipLaunchKernelGGL(k_pairing_coop, dim3((n + 1) / 2), dim3(64), 0, st, d, n, pts, valid, er, status, accept, dbg);
 }
 static void launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint32_t *er,
                            uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st) {

@@ -364,22 +364,47 @@ H2V_DI void big_shl1(uint32_t (&a)[N]) {
     for (int i = N - 1; i > 0; i--) a[i] = (a[i] << 1) | (a[i - 1] >> 31);
     a[0] <<= 1;
 }
-// returns k and x = abar^-1 * 2^k mod m (plain integers); abar != 0, abar < m, m odd with `bits` bits
+// returns k and x = abar^-1 * 2^k mod m (plain integers); abar != 0, abar < m, m odd with `bits` bits.
+// Kaliski's four cases    u even: u/=2, s*=2 | v even: v/=2, r*=2 | u>v: u=(u-v)/2, r+=s, s*=2 | else: v=(v-u)/2, s+=r, r*=2
+// are ONE body after a conditional swap of (u,r) with (v,s):   [if both odd: U -= V, R += S] ; U /= 2 ; S *= 2.
+// Branch-free (masks), so the compiler keeps the four numbers in registers (a four-way branchy version spilled
+// ~185 words per iteration and dominated the pairing kernel's wait time).
 template <class PR>
 H2V_DI int kaliski_phase1(uint32_t (&x)[PR::N], const uint32_t (&abar)[PR::N]) {
     constexpr int N = PR::N;
-    uint32_t u[N], v[N], rr[N], s[N], m[N];
+    uint32_t u[N], v[N], rr[N], s[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) { m[i] = PR::mod(i); u[i] = m[i]; v[i] = abar[i]; rr[i] = 0; s[i] = 0; }
+    for (int i = 0; i < N; i++) { u[i] = PR::mod(i); v[i] = abar[i]; rr[i] = 0; s[i] = 0; }
     s[0] = 1;
     int k = 0;
+#pragma unroll 1
     while (!big_is_zero<N>(v)) {
-        if (!(u[0] & 1)) { big_shr1<N>(u); big_shl1<N>(s); }
-        else if (!(v[0] & 1)) { big_shr1<N>(v); big_shl1<N>(rr); }
-        else if (big_gt<N>(u, v)) { big_sub<N>(u, u, v); big_shr1<N>(u); big_add<N>(rr, rr, s); big_shl1<N>(s); }
-        else { big_sub<N>(v, v, u); big_shr1<N>(v); big_add<N>(s, s, rr); big_shl1<N>(rr); }
+        const bool ue = !(u[0] & 1), ve = !(v[0] & 1);
+        const bool gt = big_gt<N>(u, v);
+        const uint32_t swap = (!ue && (ve || !gt)) ? 0xffffffffu : 0u;
+        const uint32_t sub = (!ue && !ve) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t t = (u[i] ^ v[i]) & swap; u[i] ^= t; v[i] ^= t;
+            const uint32_t w = (rr[i] ^ s[i]) & swap; rr[i] ^= w; s[i] ^= w;
+        }
+        uint32_t br = 0, bo, c = 0, co;
+#pragma unroll
+        for (int i = 0; i < N; i++) { u[i] = __builtin_subc(u[i], v[i] & sub, br, &bo); br = bo; }
+#pragma unroll
+        for (int i = 0; i < N; i++) { rr[i] = __builtin_addc(rr[i], s[i] & sub, c, &co); c = co; }
+        big_shr1<N>(u);
+        big_shl1<N>(s);
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t t = (u[i] ^ v[i]) & swap; u[i] ^= t; v[i] ^= t;
+            const uint32_t w = (rr[i] ^ s[i]) & swap; rr[i] ^= w; s[i] ^= w;
+        }
         k++;
     }
+    uint32_t m[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) m[i] = PR::mod(i);
     if (!big_gt<N>(m, rr)) big_sub<N>(rr, rr, m);  // rr >= m
     big_sub<N>(x, m, rr);
     return k;

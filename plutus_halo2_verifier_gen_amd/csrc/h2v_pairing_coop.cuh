@@ -1,4 +1,4 @@
-// Cooperative pairing check: ONE PROOF PER 16-LANE GROUP (4 proofs per wave).
+// Cooperative pairing check: ONE PROOF PER 32-LANE GROUP (2 proofs per wave).
 //
 // Why: a batch of 4096 proofs gives a one-lane-per-proof pairing kernel only 64 waves on a chip with 1024 SIMDs,
 // and every Fp12 operation there is ~54 dependent Fp multiplications.  Here lane g < 12 of a group owns ONE Fp
@@ -10,27 +10,40 @@
 // Operands are staged in LDS as 28-bit limbs (64-byte slots); which slots a lane multiplies comes from the
 // generated, big-integer-verified tables of coop_tables.h (tools/gen_coop_tables.py).  Lanes 12..15 of a group
 // compute the NEXT Miller-loop line's per-proof products (-lambda)*xP in the same engine call.
+// Each coefficient is shared by TWO lanes (g, g+16): they take alternate terms of the sum and exchange their
+// unreduced column accumulators with one cross-lane shuffle before the reduction, which halves the dependent chain
+// and doubles the number of waves (4096 proofs -> 2048 waves = 2 per SIMD, where v_mad_u64_u32 issues at full rate).
 //
 // Semantics are those of k_pairing_check (h2v_kernels.hip): accept <=> e(el, s_g2) == e(er, G2)
 // (/root/reference/aiken-verifier/templates/verification_h2.hbs:125-128).
 #pragma once
+#include "coop_program.h"
 #include "coop_tables.h"
 #include "h2v_curve.cuh"
 #include "h2v_plan.h"
 #include "h2v_tower.cuh"
 
-#define COOP_SLOT_DW 16                      // dwords per operand slot (14 limbs + 2 pad)
+#define COOP_SLOT_DW 20                      // dwords per operand slot: 14 limbs + pad; 20 keeps 16-byte alignment and
+                                             // spreads 16 consecutive slots over 16 distinct bank groups (stride 16
+                                             // measured 41 % bank-conflict cycles)
 #define COOP_GROUP_SLOTS 64                  // slots reserved per group (COOP_N_GROUP_SLOTS used)
 #define COOP_GROUP_DW (COOP_GROUP_SLOTS * COOP_SLOT_DW)
-#define COOP_LDS_DW (4 * COOP_GROUP_DW + COOP_N_SHARED_SLOTS * COOP_SLOT_DW)
+#define COOP_GROUPS_PER_WAVE 2
+#define COOP_TAB_DW ((16 * 2 * COOP_N_MUL_TERMS + 2 * 16 * 2 * COOP_N_LINE_TERMS) / 4)  // operand tables, copied at start
+#define COOP_LDS_DW (COOP_GROUPS_PER_WAVE * COOP_GROUP_DW + COOP_N_SHARED_SLOTS * COOP_SLOT_DW + COOP_TAB_DW)
 
 // File-scope LDS so that every device function addresses it as LDS (ds_read/ds_write), not through flat pointers.
 __shared__ __attribute__((aligned(16))) uint32_t coop_lds[COOP_LDS_DW];
-#define COOP_SHR_OFF (4 * COOP_GROUP_DW)
+#define COOP_SHR_OFF (COOP_GROUPS_PER_WAVE * COOP_GROUP_DW)
+#define COOP_TAB_OFF (COOP_SHR_OFF + COOP_N_SHARED_SLOTS * COOP_SLOT_DW)
+#define COOP_TAB_MUL_B 0                                   // byte offsets of the three tables inside the LDS copy
+#define COOP_TAB_LINE1_B (16 * 2 * COOP_N_MUL_TERMS)
+#define COOP_TAB_LINE2_B (COOP_TAB_LINE1_B + 16 * 2 * COOP_N_LINE_TERMS)
 
 struct Coop {
     int grp_off;  // dword offset of this group's slots in coop_lds
-    int g;        // lane within the group
+    int g;        // coefficient role 0..15 (lane & 15)
+    int h;        // which half of the terms this lane sums (lane >> 4) & 1
 };
 
 H2V_DI uint32_t *coop_slot(const Coop &c, int s) {
@@ -55,13 +68,15 @@ H2V_DI void coop_load28(uint32_t (&l)[14], const uint32_t *p) {
 
 // out = sum_t X[tab[2t]] * Y[tab[2t+1]]  (mod p), one Montgomery reduction.  NT <= 12 (accumulator headroom).
 template <int NT>
-H2V_DN Fp coop_accumulate(const Coop c, const uint8_t *tab) {
+H2V_DN Fp coop_accumulate(const Coop c, const int tab_row_byte) {
+    const uint8_t *tab = reinterpret_cast<const uint8_t *>(coop_lds + COOP_TAB_OFF) + tab_row_byte;
     static_assert(NT <= 12, "column accumulators hold at most 12 unreduced products");
     uint64_t acc[28];
 #pragma unroll
     for (int i = 0; i < 28; i++) acc[i] = 0;
+    static_assert((NT & 1) == 0, "terms are split over two lanes");
 #pragma unroll 1
-    for (int t = 0; t < NT; t++) {
+    for (int t = c.h; t < NT; t += 2) {
         uint32_t x[14], y[14];
         coop_load28(x, coop_slot(c, tab[2 * t]));
         coop_load28(y, coop_slot(c, tab[2 * t + 1]));
@@ -69,6 +84,12 @@ H2V_DN Fp coop_accumulate(const Coop c, const uint8_t *tab) {
         for (int i = 0; i < 14; i++)
 #pragma unroll
             for (int j = 0; j < 14; j++) acc[i + j] += (uint64_t)x[i] * y[j];
+    }
+    // add the partner lane's half of the sum (lane ^ 16), still unreduced
+#pragma unroll
+    for (int i = 0; i < 28; i++) {
+        const uint32_t lo = __shfl_xor((uint32_t)acc[i], 16), hi = __shfl_xor((uint32_t)(acc[i] >> 32), 16);
+        acc[i] += (uint64_t)lo | ((uint64_t)hi << 32);
     }
     // Montgomery reduction of the 28-column accumulator (operand scanning), R = 2^392
 #pragma unroll
@@ -108,7 +129,7 @@ H2V_DI Fp coop_bcast(const Fp &a, int src_lane) {
 }
 // stage a distributed value as the A operand (a_{k,part}, and -a_{k,1})
 H2V_DI void coop_stage_a(const Coop &c, const Fp &a) {
-    if (c.g < 12) {
+    if (c.g < 12 && c.h == 0) {
         coop_store28(coop_slot(c, COOP_SLOT_A + c.g), a);
         if (c.g & 1) {
             Fp n;
@@ -120,7 +141,7 @@ H2V_DI void coop_stage_a(const Coop &c, const Fp &a) {
 // stage a distributed value as the B operand (b and xi*b)
 H2V_DI void coop_stage_b(const Coop &c, const Fp &b) {
     const Fp pb = coop_shfl_xor1(b);
-    if (c.g < 12) {
+    if (c.g < 12 && c.h == 1) {
         coop_store28(coop_slot(c, COOP_SLOT_B + c.g), b);
         Fp xb;
         if (c.g & 1) fp_add(xb, pb, b);   // (xi b)_1 = b0 + b1
@@ -133,7 +154,7 @@ H2V_DI Fp coop_mul(const Coop &c, const Fp &a, const Fp &b) {
     coop_stage_a(c, a);
     coop_stage_b(c, b);
     __syncthreads();
-    Fp r = coop_accumulate<COOP_N_MUL_TERMS>(c, COOP_TAB_MUL[c.g]);
+    Fp r = coop_accumulate<COOP_N_MUL_TERMS>(c, COOP_TAB_MUL_B + c.g * 2 * COOP_N_MUL_TERMS);
     __syncthreads();
     return r;
 }
@@ -161,9 +182,11 @@ H2V_DI Fp coop_frob(const Coop &c, const Fp &a) {
 }
 // copy one line's 8 constant slots (512 B) from the plan into the wave-shared area
 H2V_DI void coop_stage_line(const Coop &c, int shared_slot, const uint32_t *lines28, int line_idx, int lane) {
-    const uint2 *src = reinterpret_cast<const uint2 *>(lines28 + (size_t)line_idx * 8 * COOP_SLOT_DW);
-    uint2 *dst = reinterpret_cast<uint2 *>(coop_lds + COOP_SHR_OFF + (shared_slot - COOP_SHARED_BASE) * COOP_SLOT_DW);
-    dst[lane] = src[lane];  // 64 lanes x 8 B = 512 B
+    // plan: 8 slots x 16 dwords per line; lane copies 2 dwords: slot = lane / 8, dwords 2*(lane % 8) ..
+    const uint2 v = reinterpret_cast<const uint2 *>(lines28 + (size_t)line_idx * 8 * 16)[lane];
+    uint32_t *dst = coop_lds + COOP_SHR_OFF + (shared_slot - COOP_SHARED_BASE + (lane >> 3)) * COOP_SLOT_DW + 2 * (lane & 7);
+    dst[0] = v.x;
+    dst[1] = v.y;
 }
 // f <- f * line (loop 1: el against s_g2's lines; loop 2: -er against G2's lines).  The spare lanes' products go
 // to the OTHER loop's T slots (they belong to that loop's next line).
@@ -171,33 +194,24 @@ template <int LOOP>
 H2V_DI Fp coop_line(const Coop &c, const Fp &f) {
     coop_stage_a(c, f);
     __syncthreads();
-    Fp r = coop_accumulate<COOP_N_LINE_TERMS>(c, LOOP == 1 ? COOP_TAB_LINE1[c.g] : COOP_TAB_LINE2[c.g]);
+    Fp r = coop_accumulate<COOP_N_LINE_TERMS>(c, (LOOP == 1 ? COOP_TAB_LINE1_B : COOP_TAB_LINE2_B) + c.g * 2 * COOP_N_LINE_TERMS);
     __syncthreads();
-    if (c.g >= 12) coop_store28(coop_slot(c, (LOOP == 1 ? COOP_SLOT_T2 : COOP_SLOT_T1) + (c.g - 12)), r);
+    if (c.g >= 12 && c.h == 0) coop_store28(coop_slot(c, (LOOP == 1 ? COOP_SLOT_T2 : COOP_SLOT_T1) + (c.g - 12)), r);
     return r;
-}
-// a^x (x = -|x|) for a in the cyclotomic subgroup
-H2V_DN Fp coop_exp_x(const Coop c, const Fp a) {
-    Fp acc = a;
-    for (int i = 62; i >= 0; i--) {
-        acc = coop_mul(c, acc, acc);
-        if ((BLS_X_ABS >> i) & 1) acc = coop_mul(c, acc, a);
-    }
-    return coop_conj(c, acc);
 }
 // 1/f for a distributed f: N = f * conj(f) lies in Fp6 (even powers of w); lane 0 inverts it with the tower code.
 H2V_DN Fp coop_inv(const Coop c, const Fp f, bool &ok) {
     const Fp fc = coop_conj(c, f);
     const Fp nrm = coop_mul(c, f, fc);
     // gather the even coefficients on lane 0 through the (now free) A slots, raw 12 x 32 limbs
-    if (c.g < 12) {
+    if (c.g < 12 && c.h == 0) {
         uint32_t *p = coop_slot(c, COOP_SLOT_A + c.g);
 #pragma unroll
         for (int i = 0; i < 12; i++) p[i] = nrm.v[i];
     }
     __syncthreads();
     bool good = true;
-    if (c.g == 0) {
+    if (c.g == 0 && c.h == 0) {
         Fp6 n6, inv6;
         const int src[6] = {0, 1, 4, 5, 8, 9};  // (k=0: c0), (k=2: c1), (k=4: c2)
         Fp *dst[6] = {&n6.c0.c0, &n6.c0.c1, &n6.c1.c0, &n6.c1.c1, &n6.c2.c0, &n6.c2.c1};
@@ -229,23 +243,39 @@ H2V_DN Fp coop_inv(const Coop c, const Fp f, bool &ok) {
 
 // dbg (optional): per proof 2 x 12 Fp (canonical, 12 dwords each): f after the Miller loop, f after the final
 // exponentiation; flat order (k, part).
+// The kernel interprets COOP_PROGRAM (coop_program.h: 577 Fp12-level operations, generated and simulated against the
+// big-integer pairing by tools/gen_coop_program.py).  Fp12 variables live in a private array, so no vector state is
+// live across the engine call (the first version kept them in VGPRs and spent 65 % of its wave-cycles waiting on
+// the spills around every call).
 extern "C" __global__ void __launch_bounds__(64, 2)
 k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid,
                const uint32_t *__restrict__ er_jac, uint32_t *__restrict__ status, uint8_t *__restrict__ accept,
                uint32_t *__restrict__ dbg) {
-    const int lane = threadIdx.x, grp = lane >> 4;
+    const int lane = threadIdx.x, grp = lane >> 5;
     Coop c;
     c.g = lane & 15;
+    c.h = (lane >> 4) & 1;
     c.grp_off = grp * COOP_GROUP_DW;
-    const uint32_t i = blockIdx.x * 4 + grp;
+    const int leader = grp * 32;  // lane (g = 0, h = 0) of the group
+    const bool is_leader = lane == leader;
+    const uint32_t i = blockIdx.x * COOP_GROUPS_PER_WAVE + grp;
     const bool live = i < n;
     const uint32_t ii = live ? i : n - 1;  // dead groups shadow the last proof, never write
     const uint32_t slots = plan.n_points + plan.n_ci;
 
-    // ---- lane 0 of the group: status, the two G1 arguments (el ; -er normalised to affine)
+    // operand tables -> LDS
+    {
+        const uint32_t *t0 = reinterpret_cast<const uint32_t *>(&COOP_TAB_MUL[0][0]);
+        const uint32_t *t1 = reinterpret_cast<const uint32_t *>(&COOP_TAB_LINE1[0][0]);
+        const uint32_t *t2 = reinterpret_cast<const uint32_t *>(&COOP_TAB_LINE2[0][0]);
+        constexpr int n0 = 16 * 2 * COOP_N_MUL_TERMS / 4, n1 = 16 * 2 * COOP_N_LINE_TERMS / 4;
+        for (int q = lane; q < n0; q += 64) coop_lds[COOP_TAB_OFF + q] = t0[q];
+        for (int q = lane; q < n1; q += 64) { coop_lds[COOP_TAB_OFF + n0 + q] = t1[q]; coop_lds[COOP_TAB_OFF + n0 + n1 + q] = t2[q]; }
+    }
+    // ---- leader: status, the two G1 arguments (el ; -er normalised to affine)
     uint32_t st = 0;
     uint32_t flags = 0;  // bit0: el is infinity, bit1: er is infinity
-    if (c.g == 0) {
+    if (is_leader) {
         st = status[ii];
         for (uint32_t j = 0; j < slots; j++)
             if (!valid[(size_t)ii * slots + j]) st |= H2V_ST_BAD_POINT;
@@ -270,74 +300,79 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
         fp_set_zero(z);
         coop_store28(coop_slot(c, COOP_SLOT_ZERO), z);
     }
-    flags = __shfl(flags, grp * 16);
-    st = __shfl(st, grp * 16);
+    flags = __shfl(flags, leader);
+    st = __shfl(st, leader);
     const bool skip1 = (flags & 1) != 0, skip2 = (flags & 2) != 0;
+    bool inv_ok = true;
 
-    // ---- Miller loop over the precomputed lines of the two fixed G2 arguments
-    Fp f;
-    fp_set_zero(f);
-    if (c.g == 0) fp_set_one(f);
-    coop_stage_line(c, COOP_SLOT_LN1, plan.lines28_sg2, 0, lane);
-    coop_stage_line(c, COOP_SLOT_LN2, plan.lines28_g2, 0, lane);
-    __syncthreads();
-    (void)coop_line<2>(c, f);  // warm-up call: only its spare lanes matter (T1 of line 0)
-    int line = 0;
-    for (int bit = 62; bit >= 0; bit--) {
-        f = coop_mul(c, f, f);
-        const int steps = ((BLS_X_ABS >> bit) & 1) ? 2 : 1;
-        for (int s = 0; s < steps; s++) {
-            // LN1 = line `line` of loop 1 and T1 are ready; stage loop 2's constants for this line
-            if (line > 0) coop_stage_line(c, COOP_SLOT_LN2, plan.lines28_g2, line, lane);
+    Fp vars[COOP_N_VARS];
+    for (int pc = 0; pc < COOP_PROGRAM_LEN; pc++) {
+        const uint32_t ins = COOP_PROGRAM[pc];
+        const int op = ins & 0xff, d = (ins >> 8) & 0xff, a = (ins >> 16) & 0xff, b = ins >> 24;
+        if (op == COOP_OP_END) break;
+        switch (op) {
+        case COOP_OP_MUL: {
+            const Fp x = vars[a], y = vars[b];
+            vars[d] = coop_mul(c, x, y);
+        } break;
+        case COOP_OP_LINE: {
+            // d = loop, a = line index.  Invariants (see coop_tables.h / gen_coop_tables.py): before LINE1(n) the
+            // shared slots hold LN1(n) and T1(n); LINE1's spare lanes produce T2(n) from LN2(n); LINE2's spare lanes
+            // produce T1(n+1) from LN1(n+1).
+            const Fp f = vars[COOP_VAR_F];
+            Fp r;
+            if (d == 1) {
+                if (a > 0) coop_stage_line(c, COOP_SLOT_LN2, plan.lines28_g2, a, lane);
+                __syncthreads();
+                r = coop_line<1>(c, f);
+                if (!skip1 && c.g < 12) vars[COOP_VAR_F] = r;
+            } else {
+                if (a + 1 < H2V_MILLER_LINES) coop_stage_line(c, COOP_SLOT_LN1, plan.lines28_sg2, a + 1, lane);
+                __syncthreads();
+                r = coop_line<2>(c, f);
+                if (!skip2 && c.g < 12) vars[COOP_VAR_F] = r;
+            }
+        } break;
+        case COOP_OP_WARMUP: {
+            coop_stage_line(c, COOP_SLOT_LN1, plan.lines28_sg2, 0, lane);
+            coop_stage_line(c, COOP_SLOT_LN2, plan.lines28_g2, 0, lane);
             __syncthreads();
-            Fp r = coop_line<1>(c, f);               // spare lanes: T2 of this line
-            if (!skip1 && c.g < 12) f = r;
-            if (line + 1 < H2V_MILLER_LINES) coop_stage_line(c, COOP_SLOT_LN1, plan.lines28_sg2, line + 1, lane);
-            __syncthreads();
-            r = coop_line<2>(c, f);                  // spare lanes: T1 of the next line
-            if (!skip2 && c.g < 12) f = r;
-            line++;
+            (void)coop_line<2>(c, vars[COOP_VAR_F]);  // only its spare lanes matter: T1 of line 0
+        } break;
+        case COOP_OP_CONJ: vars[d] = coop_conj(c, vars[a]); break;
+        case COOP_OP_FROB: vars[d] = coop_frob(c, vars[a]); break;
+        case COOP_OP_INV: {
+            bool ok = true;
+            vars[d] = coop_inv(c, vars[a], ok);
+            inv_ok = ok;
+        } break;
+        case COOP_OP_MOV: vars[d] = vars[a]; break;
+        case COOP_OP_SETONE: {
+            Fp o;
+            fp_set_zero(o);
+            if (c.g == 0) fp_set_one(o);
+            vars[d] = o;
+        } break;
+        case COOP_OP_DUMP: {
+            if (dbg && live && c.g < 12 && c.h == 0) {
+                Fp o;
+                fp_from_mont(o, vars[a]);
+#pragma unroll
+                for (int k = 0; k < 12; k++) dbg[((size_t)i * 24 + 12 * d + c.g) * 12 + k] = o.v[k];
+            }
+        } break;
+        default: break;
         }
     }
-    f = coop_conj(c, f);  // x < 0
-    if (dbg && live && c.g < 12) {
-        Fp o;
-        fp_from_mont(o, f);
-#pragma unroll
-        for (int k = 0; k < 12; k++) dbg[((size_t)i * 24 + c.g) * 12 + k] = o.v[k];
-    }
-
-    // ---- final exponentiation: easy part, then 3(p^4-p^2+1)/r = (x-1)^2 (x+p)(x^2+p^2-1) + 3
-    bool inv_ok = true;
-    Fp a = coop_inv(c, f, inv_ok);
-    Fp t = coop_mul(c, coop_conj(c, f), a);                      // f^(p^6-1)
-    a = coop_frob(c, coop_frob(c, t));
-    t = coop_mul(c, a, t);                                       // ^(p^2+1)
-    a = coop_exp_x(c, t);
-    Fp t0 = coop_mul(c, a, coop_conj(c, t));                     // t^(x-1)
-    a = coop_exp_x(c, t0);
-    Fp t1 = coop_mul(c, a, coop_conj(c, t0));                    // ^(x-1)
-    a = coop_exp_x(c, t1);
-    Fp t2 = coop_mul(c, a, coop_frob(c, t1));                    // ^(x+p)
-    a = coop_exp_x(c, coop_exp_x(c, t2));
-    Fp t3 = coop_mul(c, a, coop_frob(c, coop_frob(c, t2)));
-    t3 = coop_mul(c, t3, coop_conj(c, t2));                      // ^(x^2+p^2-1)
-    a = coop_mul(c, coop_mul(c, t, t), t);                       // t^3
-    t3 = coop_mul(c, t3, a);
-    if (dbg && live && c.g < 12) {
-        Fp o;
-        fp_from_mont(o, t3);
-#pragma unroll
-        for (int k = 0; k < 12; k++) dbg[((size_t)i * 24 + 12 + c.g) * 12 + k] = o.v[k];
-    }
     // == 1 ?
+    const Fp res = vars[COOP_VAR_F];
     bool mine = true;
-    if (c.g == 0) { Fp one; fp_set_one(one); mine = fp_eq(t3, one); }
-    else if (c.g < 12) mine = fp_is_zero(t3);
-    const unsigned long long b = __ballot(mine);
-    const bool is_one = ((b >> (grp * 16)) & 0xffffull) == 0xffffull;
-    inv_ok = __shfl((int)inv_ok, grp * 16) != 0;
-    if (c.g == 0 && live) {
+    if (c.g == 0) { Fp one; fp_set_one(one); mine = fp_eq(res, one); }
+    else if (c.g < 12) mine = fp_is_zero(res);
+    const unsigned long long bal = __ballot(mine);
+    const bool is_one = ((bal >> leader) & 0xffffffffull) == 0xffffffffull;
+    inv_ok = __shfl((int)inv_ok, leader) != 0;
+    if (is_leader && live) {
         if (st == 0 && !(is_one && inv_ok)) st |= H2V_ST_PAIRING;
         status[i] = st;
         accept[i] = st == 0 ? 1 : 0;

@@ -192,7 +192,7 @@ def emit():
         rows = []
         for g in range(16):
             rows.append("{" + ", ".join("%d, %d" % t for t in tab[g]) + "}")
-        o.append("__device__ static constexpr uint8_t %s[16][%d] = {\n    %s};" % (name, 2 * n, ",\n    ".join(rows)))
+        o.append("__device__ alignas(16) static constexpr uint8_t %s[16][%d] = {\n    %s};" % (name, 2 * n, ",\n    ".join(rows)))
 
     arr("COOP_TAB_MUL", mul_table(), N_MUL_TERMS)
     arr("COOP_TAB_LINE1", line_table(1), N_LINE_TERMS)
