@@ -29,7 +29,7 @@
 #define COOP_GROUP_SLOTS 64                  // slots reserved per group (COOP_N_GROUP_SLOTS used)
 #define COOP_GROUP_DW (COOP_GROUP_SLOTS * COOP_SLOT_DW)
 #define COOP_GROUPS_PER_WAVE 2
-#define COOP_TAB_DW ((16 * 2 * COOP_N_MUL_TERMS + 2 * 16 * 2 * COOP_N_LINE_TERMS) / 4)  // operand tables, copied at start
+#define COOP_TAB_DW ((16 * 2 * COOP_N_MUL_TERMS + 2 * 16 * 2 * COOP_N_LINE_TERMS + 16 * 2 * COOP_N_CSQR_TERMS) / 4)  // operand tables, copied at start
 #define COOP_LDS_DW (COOP_GROUPS_PER_WAVE * COOP_GROUP_DW + COOP_N_SHARED_SLOTS * COOP_SLOT_DW + COOP_TAB_DW)
 
 // File-scope LDS so that every device function addresses it as LDS (ds_read/ds_write), not through flat pointers.
@@ -39,6 +39,7 @@ __shared__ __attribute__((aligned(16))) uint32_t coop_lds[COOP_LDS_DW];
 #define COOP_TAB_MUL_B 0                                   // byte offsets of the three tables inside the LDS copy
 #define COOP_TAB_LINE1_B (16 * 2 * COOP_N_MUL_TERMS)
 #define COOP_TAB_LINE2_B (COOP_TAB_LINE1_B + 16 * 2 * COOP_N_LINE_TERMS)
+#define COOP_TAB_CSQR_B (COOP_TAB_LINE2_B + 16 * 2 * COOP_N_LINE_TERMS)
 
 struct Coop {
     int grp_off;  // dword offset of this group's slots in coop_lds
@@ -158,6 +159,31 @@ H2V_DI Fp coop_mul(const Coop &c, const Fp &a, const Fp &b) {
     __syncthreads();
     return r;
 }
+// a^2 for a in the cyclotomic subgroup (Granger-Scott; formulas and table: tools/gen_coop_tables.py: csqr_table).
+// Operands: A = a, NA = -a_im (half 0 lanes), D = 2a and ND = -2 a_im (half 1 lanes); the engine returns the core Q_k
+// and the lane finishes with 3 Q_k -/+ 2 a_k (minus for even k).
+H2V_DI Fp coop_csqr(const Coop &c, const Fp &a) {
+    coop_stage_a(c, a);
+    Fp d2;
+    fp_dbl(d2, a);
+    if (c.g < 12 && c.h == 1) {
+        coop_store28(coop_slot(c, COOP_SLOT_D + c.g), d2);
+        if (c.g & 1) {
+            Fp n;
+            fp_neg(n, d2);
+            coop_store28(coop_slot(c, COOP_SLOT_ND + (c.g >> 1)), n);
+        }
+    }
+    __syncthreads();
+    const Fp q = coop_accumulate<COOP_N_CSQR_TERMS>(c, COOP_TAB_CSQR_B + c.g * 2 * COOP_N_CSQR_TERMS);
+    __syncthreads();
+    Fp t, r;
+    fp_dbl(t, q);
+    fp_add(t, t, q);
+    if ((c.g >> 1) & 1) fp_add(r, t, d2);
+    else fp_sub(r, t, d2);
+    return r;
+}
 H2V_DI Fp coop_conj(const Coop &c, const Fp &a) {  // w -> -w: odd powers change sign
     Fp r = a;
     if (c.g < 12 && ((c.g >> 1) & 1)) fp_neg(r, a);
@@ -268,9 +294,11 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
         const uint32_t *t0 = reinterpret_cast<const uint32_t *>(&COOP_TAB_MUL[0][0]);
         const uint32_t *t1 = reinterpret_cast<const uint32_t *>(&COOP_TAB_LINE1[0][0]);
         const uint32_t *t2 = reinterpret_cast<const uint32_t *>(&COOP_TAB_LINE2[0][0]);
-        constexpr int n0 = 16 * 2 * COOP_N_MUL_TERMS / 4, n1 = 16 * 2 * COOP_N_LINE_TERMS / 4;
+        const uint32_t *t3 = reinterpret_cast<const uint32_t *>(&COOP_TAB_CSQR[0][0]);
+        constexpr int n0 = 16 * 2 * COOP_N_MUL_TERMS / 4, n1 = 16 * 2 * COOP_N_LINE_TERMS / 4, n3 = 16 * 2 * COOP_N_CSQR_TERMS / 4;
         for (int q = lane; q < n0; q += 64) coop_lds[COOP_TAB_OFF + q] = t0[q];
         for (int q = lane; q < n1; q += 64) { coop_lds[COOP_TAB_OFF + n0 + q] = t1[q]; coop_lds[COOP_TAB_OFF + n0 + n1 + q] = t2[q]; }
+        for (int q = lane; q < n3; q += 64) coop_lds[COOP_TAB_OFF + n0 + 2 * n1 + q] = t3[q];
     }
     // ---- leader: status, the two G1 arguments (el ; -er normalised to affine)
     uint32_t st = 0;
@@ -314,6 +342,10 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
         case COOP_OP_MUL: {
             const Fp x = vars[a], y = vars[b];
             vars[d] = coop_mul(c, x, y);
+        } break;
+        case COOP_OP_CSQR: {
+            const Fp x = vars[a];
+            vars[d] = coop_csqr(c, x);
         } break;
         case COOP_OP_LINE: {
             // d = loop, a = line index.  Invariants (see coop_tables.h / gen_coop_tables.py): before LINE1(n) the

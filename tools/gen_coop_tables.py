@@ -39,6 +39,10 @@ LN_NL0, LN_NL1, LN_NXL0, LN_NXL1, LN_C0, LN_C1, LN_XC0, LN_XC1 = range(8)
 
 N_MUL_TERMS = 12
 N_LINE_TERMS = 6
+N_CSQR_TERMS = 6
+# cyclotomic squaring reuses the B / XB areas for the doubled operand: D = 2*g (12 slots), ND = -2*g_k1 (6 slots)
+SLOT_D = SLOT_B
+SLOT_ND = SLOT_XB
 
 
 def mul_table():
@@ -109,6 +113,64 @@ def line_table(loop):
     return tab
 
 
+def csqr_table():
+    """Granger-Scott squaring in the cyclotomic subgroup, flat basis, pairs (g0,g3), (g1,g4), (g2,g5):
+         h0 = 3(g0^2 + xi g3^2) - 2g0   h3 = 3(2 g0 g3) + 2g3
+         h1 = 3 xi (2 g2 g5)    + 2g1   h4 = 3(g2^2 + xi g5^2) - 2g4
+         h2 = 3(g1^2 + xi g4^2) - 2g2   h5 = 3(2 g1 g4) + 2g5
+    The engine computes the core Q_k; the lane finishes with h = 3 Q_k -/+ 2 g_k (minus for even k)."""
+    A = lambda k, part: SLOT_A + 2 * k + part
+    NA = lambda k: SLOT_NA + k
+    D = lambda k, part: SLOT_D + 2 * k + part
+    ND = lambda k: SLOT_ND + k
+    kind = {0: ("even", 0, 3), 3: ("odd", 0, 3), 1: ("xi_odd", 2, 5), 4: ("even", 2, 5), 2: ("even", 1, 4), 5: ("odd", 1, 4)}
+    tab = []
+    for g in range(16):
+        terms = []
+        if g < 12:
+            k, part = g >> 1, g & 1
+            ty, a, b = kind[k]
+            if ty == "even":    # a^2 + xi b^2
+                if part == 0:
+                    terms = [(A(a, 0), A(a, 0)), (NA(a), A(a, 1)), (A(b, 0), A(b, 0)), (NA(b), A(b, 1)), (A(b, 0), ND(b))]
+                else:
+                    terms = [(A(a, 0), D(a, 1)), (A(b, 0), A(b, 0)), (NA(b), A(b, 1)), (A(b, 0), D(b, 1))]
+            elif ty == "odd":   # 2 a b
+                if part == 0:
+                    terms = [(A(a, 0), D(b, 0)), (NA(a), D(b, 1))]
+                else:
+                    terms = [(A(a, 0), D(b, 1)), (A(a, 1), D(b, 0))]
+            else:               # 2 xi a b
+                if part == 0:
+                    terms = [(A(a, 0), D(b, 0)), (NA(a), D(b, 1)), (A(a, 0), ND(b)), (NA(a), D(b, 0))]
+                else:
+                    terms = [(A(a, 0), D(b, 0)), (NA(a), D(b, 1)), (A(a, 0), D(b, 1)), (A(a, 1), D(b, 0))]
+        assert len(terms) <= N_CSQR_TERMS
+        while len(terms) < N_CSQR_TERMS:
+            terms.append((SLOT_ZERO, SLOT_ZERO))
+        tab.append(terms)
+    return tab
+
+
+def stage_csqr(g):
+    s = {SLOT_ZERO: 0}
+    for k in range(6):
+        s[SLOT_A + 2 * k], s[SLOT_A + 2 * k + 1] = g[k]
+        s[SLOT_NA + k] = (-g[k][1]) % P
+        s[SLOT_D + 2 * k], s[SLOT_D + 2 * k + 1] = 2 * g[k][0] % P, 2 * g[k][1] % P
+        s[SLOT_ND + k] = (-2 * g[k][1]) % P
+    return s
+
+
+def finish_csqr(q, g):
+    out = []
+    for lane in range(12):
+        k, part = lane >> 1, lane & 1
+        own = g[k][part]
+        out.append((3 * q[lane] + (-2 if k % 2 == 0 else 2) * own) % P)
+    return out
+
+
 # ----------------------------------------------------------------------------- big-integer simulation
 def stage_mul(a, b):
     """a, b: flat Fp12 (6 Fp2).  Returns slot dict."""
@@ -175,6 +237,15 @@ def self_check():
             # spare lanes: products for the other loop's next line
             exp = [v * xo % P for v in line_consts(lam_o, (0, 0))[:4]]
             assert out[12:16] == exp
+    # cyclotomic squaring on an element of the cyclotomic subgroup (easy part of a Miller value)
+    f = bls.miller_loop(bls.g1_mul(bls.G1_GEN, 777), bls.g2_mul(bls.G2_GEN, 3))
+    t = bls.f12_mul(bls.f12_conj(f), bls.f12_inv(f))
+    t = bls.f12_mul(bls.f12_frob(bls.f12_frob(t)), t)
+    ct = csqr_table()
+    for _ in range(4):
+        q = run(ct, stage_csqr(t))
+        assert to_flat(finish_csqr(q, t)) == bls.f12_sqr(t)
+        t = bls.f12_mul(bls.f12_sqr(t), t)
     return True
 
 
@@ -184,7 +255,7 @@ def emit():
          "#pragma once", "#include <stdint.h>"]
     for name in ("SLOT_A", "SLOT_NA", "SLOT_B", "SLOT_XB", "SLOT_T1", "SLOT_T2", "SLOT_PX1", "SLOT_PY1", "SLOT_PX2",
                  "SLOT_PY2", "SLOT_ZERO", "N_GROUP_SLOTS", "SLOT_LN1", "SLOT_LN2", "N_SHARED_SLOTS", "N_MUL_TERMS",
-                 "N_LINE_TERMS"):
+                 "N_LINE_TERMS", "N_CSQR_TERMS", "SLOT_D", "SLOT_ND"):
         o.append("#define COOP_%s %d" % (name, globals()[name]))
     o.append("#define COOP_SHARED_BASE %d" % SH)
 
@@ -197,6 +268,7 @@ def emit():
     arr("COOP_TAB_MUL", mul_table(), N_MUL_TERMS)
     arr("COOP_TAB_LINE1", line_table(1), N_LINE_TERMS)
     arr("COOP_TAB_LINE2", line_table(2), N_LINE_TERMS)
+    arr("COOP_TAB_CSQR", csqr_table(), N_CSQR_TERMS)
     path = os.path.join(ROOT, "plutus_halo2_verifier_gen_amd", "csrc", "coop_tables.h")
     with open(path, "w") as f:
         f.write("\n".join(o) + "\n")
