@@ -56,9 +56,12 @@ typedef struct {
     const uint8_t *committed;
 } h2v_batch;
 
-/* optional per-stage device timings (milliseconds, HIP events on the launch stream) */
+/* optional per-stage device timings (milliseconds, HIP events on the streams the kernels run on).  A large batch is
+ * cut into `launches` chunks that run as overlapping pipelines when H2V_PIPES > 1 (default 1): each *_ms is
+ * the SUM of that kernel's launch durations over the chunks, total_ms the span from the first launch to the last end. */
 typedef struct {
     float transcript_combiner_ms, g1_decompress_ms, g1_msm_ms, pairing_ms, total_ms;
+    uint32_t launches;
 } h2v_timings;
 
 /* ---- plan (VerifyingKey) lifecycle -------------------------------------------------------------------------

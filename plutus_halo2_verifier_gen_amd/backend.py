@@ -26,7 +26,7 @@ class Batch(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("transcript_combiner_ms", C.c_float), ("g1_decompress_ms", C.c_float), ("g1_msm_ms", C.c_float),
-                ("pairing_ms", C.c_float), ("total_ms", C.c_float)]
+                ("pairing_ms", C.c_float), ("total_ms", C.c_float), ("launches", C.c_uint32)]
 
 
 EXPORTS = [

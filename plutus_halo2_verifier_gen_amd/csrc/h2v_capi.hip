@@ -50,12 +50,16 @@ struct h2v_workspace {
     uint8_t *in_proofs = nullptr, *in_inst = nullptr, *in_ci = nullptr;
     uint64_t *in_off = nullptr;
     size_t in_proofs_cap = 0, in_inst_cap = 0, in_ci_cap = 0, in_off_cap = 0;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // ring of per-call event sets: [0]/[1] around the transcript+combiner kernel (main stream), [2]/[3] around the
-    // decompression kernel (side stream), [4]/[5] around the MSM, [5]/[6] around the pairing kernel (main stream)
+    // A batch is cut into up to MAXP chunks that run as independent pipelines on their own stream pairs, so that one
+    // chunk's decompression / transcript kernels (few waves) overlap another chunk's MSM / pairing kernels.
+    static constexpr int MAXP = 4;
+    hipStream_t pmain[MAXP] = {}, pside[MAXP] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAXP] = {}, ev_done[MAXP] = {};
+    // ring of per-call, per-chunk event sets: [0]/[1] around the transcript+combiner kernel, [2]/[3] around the
+    // decompression kernel (side stream), [4]/[5] around the MSM, [5]/[6] around the pairing kernel
     static constexpr int RING = 64, NEV = 7;
-    hipEvent_t ring[RING][NEV] = {};
+    hipEvent_t ring[RING][MAXP][NEV] = {};
+    uint8_t ring_pipes[RING] = {};
     uint64_t calls = 0;
 };
 
@@ -200,10 +204,12 @@ static void ws_release(h2v_workspace *w) {
     (void)hipSetDevice(w->device);
     void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off};
     for (void *q : ptrs) if (q) (void)hipFree(q);
-    if (w->side) (void)hipStreamDestroy(w->side);
+    for (hipStream_t q : w->pmain) if (q) (void)hipStreamDestroy(q);
+    for (hipStream_t q : w->pside) if (q) (void)hipStreamDestroy(q);
     if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
-    if (w->ev_join) (void)hipEventDestroy(w->ev_join);
-    for (auto &set : w->ring) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : w->ev_join) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : w->ev_done) if (e) (void)hipEventDestroy(e);
+    for (auto &call : w->ring) for (auto &set : call) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
 }
 static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bool with_trace, h2v_workspace **out) {
     if (max_batch == 0 || max_batch > (1ull << 24)) return fail(H2V_E_ARG, "max_batch out of range");
@@ -224,10 +230,13 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     WSALLOC(accept, (size_t)max_batch)
     if (with_trace && d.n_trace) { WSALLOC(trace, (size_t)max_batch * d.n_trace * 32) }
 #undef WSALLOC
-    if (hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess) { ws_release(w); delete w; return fail(H2V_E_DEVICE, "stream/event creation failed"); }
-    for (auto &set : w->ring) for (hipEvent_t &e : set)
-        if (hipEventCreate(&e) != hipSuccess) { ws_release(w); delete w; return fail(H2V_E_DEVICE, "event creation failed"); }
+    bool ok = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < h2v_workspace::MAXP && ok; k++)
+        ok = hipStreamCreateWithFlags(&w->pmain[k], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&w->pside[k], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&w->ev_join[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->ev_done[k], hipEventDisableTiming) == hipSuccess;
+    for (auto &call : w->ring) for (auto &set : call) for (hipEvent_t &e : set)
+        if (ok) ok = hipEventCreate(&e) == hipSuccess;
+    if (!ok) { ws_release(w); delete w; return fail(H2V_E_DEVICE, "stream/event creation failed"); }
     *out = w;
     return H2V_OK;
 }
@@ -266,12 +275,14 @@ static void launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *pts,
 // ---------------------------------------------------------------------------------------------- pipeline
 // Enqueues the four kernels.  Without timings the transcript/combiner kernel (few, long waves) and the
 // decompression kernel (many short ones) run concurrently on two streams and join before the MSM.
+extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_timings *tm);
 static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst,
                         const uint8_t *ci, uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st,
                         h2v_timings *tm, bool want_trace) {
     const uint32_t slots = d.n_points + d.n_ci;
     const uint32_t vm_blocks = (n + 63) / 64;
     const uint32_t dec_blocks = (n * slots + 63) / 64;
+    (void)vm_blocks; (void)dec_blocks;
     uint32_t *trace = want_trace ? w->trace : nullptr;
     uint32_t *status = w->status;
     static const bool dbg = getenv("H2V_DEBUG_SYNC") != nullptr;  // serialise + sync after every kernel, say which one ran
@@ -290,33 +301,52 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         if (status_out) HIPCHK(hipMemcpyAsync(status_out, status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         return H2V_OK;
     }
-    hipEvent_t *ev = w->ring[w->calls % h2v_workspace::RING];
+    // number of chunks (H2V_PIPES).  Default 1: measured on MI355X, 2/3/4 concurrent pipelines of a 4096-proof batch
+    // took 14.2 / 20.7 / 29.1 ms against 13.5 ms for one (kernels with different private-segment sizes alternating on
+    // several queues cost more than the idle SIMDs they fill), so the split is kept as an experiment knob only.
+    static const int env_pipes = []() { const char *e = getenv("H2V_PIPES"); return e ? atoi(e) : 0; }();
+    int pipes = env_pipes > 0 ? env_pipes : 1;
+    if (pipes > h2v_workspace::MAXP) pipes = h2v_workspace::MAXP;
+    if (want_trace || (uint32_t)pipes > n) pipes = 1;
+    const int slot = (int)(w->calls % h2v_workspace::RING);
+    w->ring_pipes[slot] = (uint8_t)pipes;
     w->calls++;
-    // fork: decompression (many short waves) runs beside the transcript+combiner kernel (few long waves)
     HIPCHK(hipEventRecord(w->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(w->side, w->ev_fork, 0));
-    HIPCHK(hipEventRecord(ev[2], w->side));
-    hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(64), 0, w->side, d, n, proofs, off, ci, w->pts, w->valid);
-    HIPCHK(hipEventRecord(ev[3], w->side));
-    HIPCHK(hipEventRecord(w->ev_join, w->side));
-    HIPCHK(hipEventRecord(ev[0], st));
-    hipLaunchKernelGGL(k_transcript_combiner, dim3(vm_blocks), dim3(64), 0, st, d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace);
-    HIPCHK(hipEventRecord(ev[1], st));
-    HIPCHK(hipStreamWaitEvent(st, w->ev_join, 0));
-    HIPCHK(hipEventRecord(ev[4], st));
-    launch_msm(d, n, w->scalars, w->pts, w->er, st);
-    HIPCHK(hipEventRecord(ev[5], st));
-    launch_pairing(d, n, w->pts, w->valid, w->er, status, accept, nullptr, st);
-    HIPCHK(hipEventRecord(ev[6], st));
+    for (int k = 0; k < pipes; k++) {
+        const uint32_t lo = (uint32_t)((uint64_t)n * k / pipes), hi = (uint32_t)((uint64_t)n * (k + 1) / pipes), m = hi - lo;
+        hipEvent_t *ev = w->ring[slot][k];
+        hipStream_t pm = w->pmain[k], ps = w->pside[k];
+        const uint64_t *off_k = off + lo;
+        const uint8_t *inst_k = inst ? inst + (size_t)lo * d.n_pi * 32 : nullptr;
+        const uint8_t *ci_k = ci ? ci + (size_t)lo * 48 : nullptr;
+        uint32_t *regs_k = w->regs + lo, *scal_k = w->scalars + (size_t)lo * d.n_terms * 8, *pts_k = w->pts + (size_t)lo * slots * 24;
+        uint32_t *er_k = w->er + (size_t)lo * 36, *status_k = status + lo;
+        uint8_t *valid_k = w->valid + (size_t)lo * slots, *accept_k = accept + lo;
+        HIPCHK(hipStreamWaitEvent(pm, w->ev_fork, 0));
+        HIPCHK(hipStreamWaitEvent(ps, w->ev_fork, 0));
+        // decompression (many short waves) runs beside the transcript+combiner kernel (few long waves)
+        HIPCHK(hipEventRecord(ev[2], ps));
+        hipLaunchKernelGGL(k_g1_decompress, dim3((m * slots + 63) / 64), dim3(64), 0, ps, d, m, proofs, off_k, ci_k, pts_k, valid_k);
+        HIPCHK(hipEventRecord(ev[3], ps));
+        HIPCHK(hipEventRecord(w->ev_join[k], ps));
+        HIPCHK(hipEventRecord(ev[0], pm));
+        hipLaunchKernelGGL(k_transcript_combiner, dim3((m + 63) / 64), dim3(64), 0, pm, d, m, w->stride, proofs, off_k, inst_k, ci_k, regs_k, scal_k, status_k, trace);
+        HIPCHK(hipEventRecord(ev[1], pm));
+        HIPCHK(hipStreamWaitEvent(pm, w->ev_join[k], 0));
+        HIPCHK(hipEventRecord(ev[4], pm));
+        launch_msm(d, m, scal_k, pts_k, er_k, pm);
+        HIPCHK(hipEventRecord(ev[5], pm));
+        launch_pairing(d, m, pts_k, valid_k, er_k, status_k, accept_k, nullptr, pm);
+        HIPCHK(hipEventRecord(ev[6], pm));
+        HIPCHK(hipEventRecord(w->ev_done[k], pm));
+        HIPCHK(hipStreamWaitEvent(st, w->ev_done[k], 0));
+    }
     HIPCHK(hipGetLastError());
     if (status_out) HIPCHK(hipMemcpyAsync(status_out, status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
     if (tm) {
         HIPCHK(hipStreamSynchronize(st));
-        HIPCHK(hipEventElapsedTime(&tm->transcript_combiner_ms, ev[0], ev[1]));
-        HIPCHK(hipEventElapsedTime(&tm->g1_decompress_ms, ev[2], ev[3]));
-        HIPCHK(hipEventElapsedTime(&tm->g1_msm_ms, ev[4], ev[5]));
-        HIPCHK(hipEventElapsedTime(&tm->pairing_ms, ev[5], ev[6]));
-        HIPCHK(hipEventElapsedTime(&tm->total_ms, ev[2], ev[6]));
+        int rc = h2v_workspace_timings(w, 0, tm);
+        if (rc) return rc;
     }
     return H2V_OK;
 }
@@ -351,13 +381,26 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
     if (!w || !tm) return fail(H2V_E_ARG, "null argument");
     if (calls_back >= h2v_workspace::RING || calls_back >= w->calls) return fail(H2V_E_ARG, "no such call in the event ring");
     HIPCHK(hipSetDevice(w->device));
-    hipEvent_t *ev = w->ring[(w->calls - 1 - calls_back) % h2v_workspace::RING];
-    HIPCHK(hipEventSynchronize(ev[6]));
-    HIPCHK(hipEventElapsedTime(&tm->transcript_combiner_ms, ev[0], ev[1]));
-    HIPCHK(hipEventElapsedTime(&tm->g1_decompress_ms, ev[2], ev[3]));
-    HIPCHK(hipEventElapsedTime(&tm->g1_msm_ms, ev[4], ev[5]));
-    HIPCHK(hipEventElapsedTime(&tm->pairing_ms, ev[5], ev[6]));
-    HIPCHK(hipEventElapsedTime(&tm->total_ms, ev[2], ev[6]));
+    const int slot = (int)((w->calls - 1 - calls_back) % h2v_workspace::RING);
+    const int pipes = w->ring_pipes[slot];
+    memset(tm, 0, sizeof *tm);
+    tm->launches = (uint32_t)pipes;
+    float first_start = 0, last_end = 0;
+    for (int k = 0; k < pipes; k++) {
+        hipEvent_t *ev = w->ring[slot][k];
+        HIPCHK(hipEventSynchronize(ev[6]));
+        float a, b, c, e, t0 = 0, t1 = 0;
+        HIPCHK(hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIPCHK(hipEventElapsedTime(&b, ev[2], ev[3]));
+        HIPCHK(hipEventElapsedTime(&c, ev[4], ev[5]));
+        HIPCHK(hipEventElapsedTime(&e, ev[5], ev[6]));
+        tm->transcript_combiner_ms += a; tm->g1_decompress_ms += b; tm->g1_msm_ms += c; tm->pairing_ms += e;
+        if (k > 0) { HIPCHK(hipEventElapsedTime(&t0, w->ring[slot][0][2], ev[2])); }
+        HIPCHK(hipEventElapsedTime(&t1, w->ring[slot][0][2], ev[6]));
+        if (k == 0 || t0 < first_start) first_start = t0;
+        if (t1 > last_end) last_end = t1;
+    }
+    tm->total_ms = last_end - first_start;
     return H2V_OK;
 }
 
