@@ -19,7 +19,7 @@ H2V_DI void g1j_from_affine(G1J &r, const G1A &a) {
     r.x = a.x; r.y = a.y; fp_set_one(r.z);
 }
 // dbl-2009-l (a = 0): 2M + 5S
-H2V_DN void g1j_dbl(G1J &r, const G1J &p) {
+H2V_DI void g1j_dbl_inl(G1J &r, const G1J &p) {
     if (g1j_is_inf(p) || fp_is_zero(p.y)) { g1j_set_inf(r); return; }
     Fp A, B, C, D, E, F, t, x3, y3, z3;
     fp_sqr(A, p.x);
@@ -35,6 +35,7 @@ H2V_DN void g1j_dbl(G1J &r, const G1J &p) {
     fp_sub(y3, y3, C);
     r.x = x3; r.y = y3; r.z = z3;
 }
+H2V_DN void g1j_dbl(G1J &r, const G1J &p) { g1j_dbl_inl(r, p); }
 // mixed addition r = p + q (q affine, may be infinity): 8M + 3S on the generic path
 H2V_DN void g1j_add_affine(G1J &r, const G1J &p, const G1A &q) {
     if (g1a_is_inf(q)) { r = p; return; }
@@ -55,8 +56,8 @@ H2V_DN void g1j_add_affine(G1J &r, const G1J &p, const G1A &q) {
     fp_mul(z3, p.z, h);
     r.x = x3; r.y = y3; r.z = z3;
 }
-// full addition: 12M + 4S on the generic path
-H2V_DN void g1j_add(G1J &r, const G1J &p, const G1J &q) {
+// full addition: 12M + 4S on the generic path (inline form for the MSM ladder: the accumulator stays in VGPRs)
+H2V_DI void g1j_add_inl(G1J &r, const G1J &p, const G1J &q) {
     if (g1j_is_inf(p)) { r = q; return; }
     if (g1j_is_inf(q)) { r = p; return; }
     Fp z1z1, z2z2, u1, u2, s1, s2, h, rr, hh, hhh, v, t, x3, y3, z3;
@@ -75,6 +76,7 @@ H2V_DN void g1j_add(G1J &r, const G1J &p, const G1J &q) {
     fp_mul(z3, p.z, q.z); fp_mul(z3, z3, h);
     r.x = x3; r.y = y3; r.z = z3;
 }
+H2V_DN void g1j_add(G1J &r, const G1J &p, const G1J &q) { g1j_add_inl(r, p, q); }
 H2V_DN void g1j_to_affine(G1A &r, const G1J &p) {
     if (g1j_is_inf(p)) { g1a_set_inf(r); return; }
     Fp zi, zi2;

@@ -265,11 +265,39 @@ H2V_DI Fp fp_sqr_inl(const Fp &a) {
     FpF::cond_sub(r, w, 0);
     return r;
 }
-// ---- out-of-line entry points (operands and result travel in VGPRs): keep code size and compile time in check.
-H2V_DN Fp fp_mul_v(Fp a, Fp b) { return fp_mul_inl(a, b); }
-H2V_DN Fp fp_sqr_v(Fp a) { return fp_sqr_inl(a); }
-H2V_DI void fp_mul(Fp &r, const Fp &a, const Fp &b) { r = fp_mul_v(a, b); }
-H2V_DI void fp_sqr(Fp &r, const Fp &a) { r = fp_sqr_v(a); }
+// ---- out-of-line entry points: keep code size and compile time in check.  Operands and result travel in VGPRs:
+// the device ABI passes 16-byte vectors in registers, whereas a second 48-byte struct argument went through
+// scratch memory (one of the sources of the MSM kernel's 10 GB of HBM traffic per launch).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct FpRegs { u32x4 a, b, c; };
+H2V_DI FpRegs fp_pack(const Fp &x) {
+    FpRegs r;
+    r.a = u32x4{x.v[0], x.v[1], x.v[2], x.v[3]};
+    r.b = u32x4{x.v[4], x.v[5], x.v[6], x.v[7]};
+    r.c = u32x4{x.v[8], x.v[9], x.v[10], x.v[11]};
+    return r;
+}
+H2V_DI Fp fp_unpack(const u32x4 a, const u32x4 b, const u32x4 c) {
+    Fp x;
+    x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
+    x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
+    x.v[8] = c.x; x.v[9] = c.y; x.v[10] = c.z; x.v[11] = c.w;
+    return x;
+}
+H2V_DN FpRegs fp_mul_raw(u32x4 a0, u32x4 a1, u32x4 a2, u32x4 b0, u32x4 b1, u32x4 b2) {
+    return fp_pack(fp_mul_inl(fp_unpack(a0, a1, a2), fp_unpack(b0, b1, b2)));
+}
+H2V_DN FpRegs fp_sqr_raw(u32x4 a0, u32x4 a1, u32x4 a2) { return fp_pack(fp_sqr_inl(fp_unpack(a0, a1, a2))); }
+H2V_DI void fp_mul(Fp &r, const Fp &a, const Fp &b) {
+    const FpRegs x = fp_pack(a), y = fp_pack(b);
+    const FpRegs z = fp_mul_raw(x.a, x.b, x.c, y.a, y.b, y.c);
+    r = fp_unpack(z.a, z.b, z.c);
+}
+H2V_DI void fp_sqr(Fp &r, const Fp &a) {
+    const FpRegs x = fp_pack(a);
+    const FpRegs z = fp_sqr_raw(x.a, x.b, x.c);
+    r = fp_unpack(z.a, z.b, z.c);
+}
 H2V_DI void fp_add(Fp &r, const Fp &a, const Fp &b) { FpF::add(r, a, b); }
 H2V_DI void fp_sub(Fp &r, const Fp &a, const Fp &b) { FpF::sub(r, a, b); }
 H2V_DI void fp_neg(Fp &r, const Fp &a) { FpF::neg(r, a); }

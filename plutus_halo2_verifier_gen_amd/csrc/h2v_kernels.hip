@@ -404,13 +404,14 @@ k_g1_msm(H2vDevPlan plan, uint32_t n, uint32_t tp /* pow2 >= n_terms, <= 64 */, 
 #pragma unroll 1
             for (int q = 32; q >= 0; q--) {
                 if (q != 32) {
-                    g1j_dbl(acc, acc); g1j_dbl(acc, acc); g1j_dbl(acc, acc); g1j_dbl(acc, acc);
+#pragma unroll 1
+                    for (int rep = 0; rep < 4; rep++) g1j_dbl_inl(acc, acc);  // inlined: acc never leaves the VGPRs
                 }
                 const int d = dg[q];
                 if (d != 0) {
                     G1J t = tab[(d < 0 ? -d : d) - 1];
                     if (d < 0) fp_neg(t.y, t.y);
-                    g1j_add(acc, acc, t);
+                    g1j_add_inl(acc, acc, t);
                 }
             }
         }
