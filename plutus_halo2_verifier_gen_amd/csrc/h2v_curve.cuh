@@ -18,22 +18,23 @@ H2V_DI void g1j_from_affine(G1J &r, const G1A &a) {
     if (g1a_is_inf(a)) { g1j_set_inf(r); return; }
     r.x = a.x; r.y = a.y; fp_set_one(r.z);
 }
-// dbl-2009-l (a = 0): 2M + 5S
+// dbl-2009-l (a = 0): 2M + 5S.  Ordered so that at most five field elements are live at any call (the MSM ladder keeps
+// the accumulator in VGPRs across the out-of-line multiplier calls; a wider live set spills to scratch = HBM traffic).
 H2V_DI void g1j_dbl_inl(G1J &r, const G1J &p) {
     if (g1j_is_inf(p) || fp_is_zero(p.y)) { g1j_set_inf(r); return; }
-    Fp A, B, C, D, E, F, t, x3, y3, z3;
-    fp_sqr(A, p.x);
-    fp_sqr(B, p.y);
+    Fp X = p.x, Y = p.y, Z = p.z, A, B, C, D, t;
+    fp_mul(Z, Y, Z); fp_dbl(Z, Z);                 // Z3 = 2 Y Z
+    fp_sqr(A, X);
+    fp_sqr(B, Y);
+    fp_add(t, X, B); fp_sqr(t, t);
     fp_sqr(C, B);
-    fp_add(t, p.x, B); fp_sqr(t, t); fp_sub(t, t, A); fp_sub(t, t, C); fp_dbl(D, t);
-    fp_dbl(E, A); fp_add(E, E, A);
-    fp_sqr(F, E);
-    fp_mul(z3, p.y, p.z); fp_dbl(z3, z3);
-    fp_dbl(t, D); fp_sub(x3, F, t);
-    fp_sub(t, D, x3); fp_mul(y3, E, t);
+    fp_sub(t, t, A); fp_sub(t, t, C); fp_dbl(D, t);  // D = 2((X+B)^2 - A - C)
+    fp_dbl(t, A); fp_add(A, t, A);                 // E = 3A (in A)
+    fp_sqr(X, A); fp_dbl(t, D); fp_sub(X, X, t);   // X3 = E^2 - 2D
+    fp_sub(t, D, X); fp_mul(Y, A, t);              // E (D - X3)
     fp_dbl(C, C); fp_dbl(C, C); fp_dbl(C, C);
-    fp_sub(y3, y3, C);
-    r.x = x3; r.y = y3; r.z = z3;
+    fp_sub(Y, Y, C);                               // - 8C
+    r.x = X; r.y = Y; r.z = Z;
 }
 H2V_DN void g1j_dbl(G1J &r, const G1J &p) { g1j_dbl_inl(r, p); }
 // mixed addition r = p + q (q affine, may be infinity): 8M + 3S on the generic path
@@ -56,26 +57,35 @@ H2V_DN void g1j_add_affine(G1J &r, const G1J &p, const G1A &q) {
     fp_mul(z3, p.z, h);
     r.x = x3; r.y = y3; r.z = z3;
 }
-// full addition: 12M + 4S on the generic path (inline form for the MSM ladder: the accumulator stays in VGPRs)
-H2V_DI void g1j_add_inl(G1J &r, const G1J &p, const G1J &q) {
-    if (g1j_is_inf(p)) { r = q; return; }
+// full addition: 12M + 4S on the generic path.  q is read through the reference where it is needed (it lives in the
+// ladder's table in private memory) and negated on the fly when neg_q; at most six field elements are live at a call.
+H2V_DI void g1j_add_signed_inl(G1J &r, const G1J &p, const G1J &q, const bool neg_q) {
     if (g1j_is_inf(q)) { r = p; return; }
-    Fp z1z1, z2z2, u1, u2, s1, s2, h, rr, hh, hhh, v, t, x3, y3, z3;
-    fp_sqr(z1z1, p.z); fp_sqr(z2z2, q.z);
-    fp_mul(u1, p.x, z2z2); fp_mul(u2, q.x, z1z1);
-    fp_mul(s1, p.y, q.z); fp_mul(s1, s1, z2z2);
-    fp_mul(s2, q.y, p.z); fp_mul(s2, s2, z1z1);
-    fp_sub(h, u2, u1); fp_sub(rr, s2, s1);
-    if (fp_is_zero(h)) {
-        if (fp_is_zero(rr)) { g1j_dbl(r, p); return; }
+    if (g1j_is_inf(p)) { r = q; if (neg_q) fp_neg(r.y, r.y); return; }
+    Fp X1 = p.x, Y1 = p.y, Z1 = p.z, a, b, c, t;
+    fp_sqr(a, q.z);                                  // z2z2
+    fp_mul(X1, X1, a);                               // u1
+    fp_mul(t, q.z, a); fp_mul(Y1, Y1, t);            // s1
+    fp_sqr(a, Z1);                                   // z1z1
+    fp_mul(b, q.x, a);                               // u2
+    fp_mul(t, Z1, a);
+    { Fp qy = q.y; if (neg_q) fp_neg(qy, qy); fp_mul(c, qy, t); }  // s2
+    fp_sub(b, b, X1);                                // h
+    fp_sub(c, c, Y1);                                // rr
+    if (fp_is_zero(b)) {
+        if (fp_is_zero(c)) { g1j_dbl_inl(r, p); return; }
         g1j_set_inf(r); return;
     }
-    fp_sqr(hh, h); fp_mul(hhh, hh, h); fp_mul(v, u1, hh);
-    fp_sqr(x3, rr); fp_sub(x3, x3, hhh); fp_dbl(t, v); fp_sub(x3, x3, t);
-    fp_sub(t, v, x3); fp_mul(y3, rr, t); fp_mul(t, s1, hhh); fp_sub(y3, y3, t);
-    fp_mul(z3, p.z, q.z); fp_mul(z3, z3, h);
-    r.x = x3; r.y = y3; r.z = z3;
+    fp_mul(Z1, Z1, q.z); fp_mul(Z1, Z1, b);          // Z3
+    fp_sqr(a, b);                                    // hh
+    fp_mul(b, b, a);                                 // hhh
+    fp_mul(a, X1, a);                                // v
+    fp_sqr(X1, c); fp_sub(X1, X1, b); fp_dbl(t, a); fp_sub(X1, X1, t);   // X3
+    fp_sub(t, a, X1); fp_mul(c, c, t);               // rr (v - X3)
+    fp_mul(t, Y1, b); fp_sub(Y1, c, t);              // Y3
+    r.x = X1; r.y = Y1; r.z = Z1;
 }
+H2V_DI void g1j_add_inl(G1J &r, const G1J &p, const G1J &q) { g1j_add_signed_inl(r, p, q, false); }
 H2V_DN void g1j_add(G1J &r, const G1J &p, const G1J &q) { g1j_add_inl(r, p, q); }
 H2V_DN void g1j_to_affine(G1A &r, const G1J &p) {
     if (g1j_is_inf(p)) { g1a_set_inf(r); return; }

@@ -401,19 +401,21 @@ k_g1_msm(H2vDevPlan plan, uint32_t n, uint32_t tp /* pow2 >= n_terms, <= 64 */, 
             g1j_dbl(tab[5], tab[2]);
             g1j_add_affine(tab[6], tab[5], base);
             g1j_dbl(tab[7], tab[3]);
+            // `lad` is only ever touched by inlined code, so it is promoted to VGPRs; `acc` is handed by reference to the
+            // out-of-line reduction below and therefore lives in private memory (keeping the ladder on `acc` cost
+            // ~6 GB of scratch traffic per launch).
+            G1J lad;
+            g1j_set_inf(lad);
 #pragma unroll 1
             for (int q = 32; q >= 0; q--) {
                 if (q != 32) {
 #pragma unroll 1
-                    for (int rep = 0; rep < 4; rep++) g1j_dbl_inl(acc, acc);  // inlined: acc never leaves the VGPRs
+                    for (int rep = 0; rep < 4; rep++) g1j_dbl_inl(lad, lad);
                 }
                 const int d = dg[q];
-                if (d != 0) {
-                    G1J t = tab[(d < 0 ? -d : d) - 1];
-                    if (d < 0) fp_neg(t.y, t.y);
-                    g1j_add_inl(acc, acc, t);
-                }
+                if (d != 0) g1j_add_signed_inl(lad, lad, tab[(d < 0 ? -d : d) - 1], d < 0);
             }
+            acc = lad;
         }
     }
     // segmented reduction over the 2*tp lanes of each proof
