@@ -19,6 +19,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# Integer-multiply issue ceiling measured on this chip with tools/ubench/imad.hip: v_mad_u64_u32 sustains one
+# wave-instruction per 5.4 cycles per SIMD at >= 2 waves/SIMD  ->  1024 SIMDs * 64 lanes * 2.4e9 / 5.4 lane-mads/s.
+IMAD_PEAK_TOPS = 1024 * 64 * 2.4e9 / 5.4 / 1e12
+# v_mad_u64_u32 per field operation (csrc/h2v_field.cuh): product-scanning multiply 392, square 301
+MAD_MUL, MAD_SQR = 392, 301
+MAD_DBL = 2 * MAD_MUL + 5 * MAD_SQR          # dbl-2009-l
+MAD_MADD = 8 * MAD_MUL + 3 * MAD_SQR         # mixed addition
+MAD_ADD = 12 * MAD_MUL + 4 * MAD_SQR         # full Jacobian addition
 
 WORKLOADS = {
     # name: (vk builder, proofs per GPU, BASELINE config label)
@@ -153,6 +161,21 @@ def main():
                     "avg_launch_ms": round(kernel_ms[k] / launches, 4), "launches_per_step": launches,
                     "algorithmic_bytes_per_launch": bytes_per_launch[k] // launches}
 
+        # analytical multiply-add counts per launch (lane-level v_mad_u64_u32), see DESIGN.md section 6
+        msm_lane = 4 * MAD_DBL + 3 * MAD_MADD + 128 * MAD_DBL + 31 * MAD_ADD + MAD_MUL      # table + 32 windows + phi
+        mads = {
+            "g1_msm": B * T * 2 * msm_lane + B * (2 * T - 1) * MAD_ADD,
+            "pairing": B * 32 * (98 * (6 * 196 + 196) + (315 + 136) * (3 * 196 + 196)),     # coop program: MUL / CSQR+LINE
+            "g1_decompress": B * slots * (380 * MAD_SQR + 190 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD),
+            "transcript_combiner": B * sum(128 for ins in pl.instrs if ins[0] == PL.OP_MUL),
+        }
+
+        def int_roof(k):
+            tops = mads[k] / (kernel_ms[k] * 1e-3) / 1e12 if kernel_ms[k] > 0 else 0.0
+            return {"kernel": kname[k], "bound": "int-mad issue (measured v_mad_u64_u32 ceiling)", "achieved": round(tops, 3),
+                    "peak": round(IMAD_PEAK_TOPS, 2), "unit": "T lane-mad/s", "frac": round(tops / IMAD_PEAK_TOPS, 4),
+                    "mads_per_launch": mads[k] // launches}
+
         dominant = max(kernel_ms, key=kernel_ms.get)
         result = {
             "metric": "halo2_proofs_verified_per_sec",
@@ -172,6 +195,8 @@ def main():
                        "parallelism": "independent proofs sharded per GPU; accept gather over RCCL" if world > 1 else "1 GPU"},
             "roofline": roof(dominant),
             "msm_roofline": roof("g1_msm"),
+            "int_roofline": int_roof(dominant),
+            "msm_int_roofline": int_roof("g1_msm"),
             "kernel_ms": {kname[k]: round(v, 4) for k, v in kernel_ms.items()},
             "pipelines_per_step": launches,
             "all_accepted": ok_all,
@@ -201,7 +226,7 @@ def cpu_baseline(vk, batch, pl, sample, gpu_accept):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    n = min(sample, batch.n)
+    n = min(max(sample, 8 * cores), batch.n)  # at least 8 proofs per thread
     n_pi = vk.n_public_inputs
     proofs = batch.proofs[:batch.proof_off[n]]
     inst = batch.instances[:32 * n_pi * n]

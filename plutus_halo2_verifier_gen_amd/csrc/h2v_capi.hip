@@ -44,7 +44,7 @@ struct h2v_workspace {
     int device = 0;
     uint64_t cap = 0;       // max batch
     uint32_t stride = 0;    // register-file stride (cap rounded up to 64)
-    uint32_t *regs = nullptr, *scalars = nullptr, *pts = nullptr, *er = nullptr, *status = nullptr, *trace = nullptr;
+    uint32_t *regs = nullptr, *scalars = nullptr, *pts = nullptr, *er = nullptr, *status = nullptr, *trace = nullptr, *msm_tab = nullptr;
     uint8_t *valid = nullptr, *accept = nullptr;
     // staging for the host-buffer entry point
     uint8_t *in_proofs = nullptr, *in_inst = nullptr, *in_ci = nullptr;
@@ -202,7 +202,7 @@ extern "C" int h2v_plan_trace_slots(const h2v_plan *p, uint32_t *slot_ids, uint3
 // ---------------------------------------------------------------------------------------------- workspace
 static void ws_release(h2v_workspace *w) {
     (void)hipSetDevice(w->device);
-    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off};
+    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off, w->msm_tab};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipStream_t q : w->pmain) if (q) (void)hipStreamDestroy(q);
     for (hipStream_t q : w->pside) if (q) (void)hipStreamDestroy(q);
@@ -226,6 +226,7 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     WSALLOC(pts, (size_t)max_batch * slots * 96)
     WSALLOC(valid, (size_t)max_batch * slots)
     WSALLOC(er, (size_t)max_batch * 144)
+    WSALLOC(msm_tab, (size_t)max_batch * d.n_terms * 2 * 8 * 144)  // per (proof, term, half): [1..8]*P Jacobian
     WSALLOC(status, (size_t)max_batch * 4)
     WSALLOC(accept, (size_t)max_batch)
     if (with_trace && d.n_trace) { WSALLOC(trace, (size_t)max_batch * d.n_trace * 32) }
@@ -251,12 +252,12 @@ extern "C" void h2v_workspace_free(h2v_workspace *w) {
 }
 
 // MSM launch geometry: 2 lanes per (proof, term); block = max(64, 2*tp) threads, LDS 144 B per thread.
-static void launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, uint32_t *er, hipStream_t st) {
+static void launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, uint32_t *er, uint32_t *tabws, hipStream_t st) {
     const uint32_t tp = next_pow2(d.n_terms);
     const uint32_t bs = 2 * tp < 64 ? 64 : 2 * tp;
     const uint32_t per_block = bs / (2 * tp);
     const uint32_t blocks = (n + per_block - 1) / per_block;
-    hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 144, st, d, n, tp, scalars, pts, er);
+    hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 144, st, d, n, tp, scalars, pts, er, tabws);
 }
 
 // Pairing kernel selection: the cooperative 16-lanes-per-proof kernel is the product path; the one-lane-per-proof
@@ -295,7 +296,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         fprintf(stderr, "[h2v] %s done\n", name); fflush(stderr);
         DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(64), 0, st, d, n, proofs, off, ci, w->pts, w->valid))
         DBG_STAGE("k_transcript_combiner", hipLaunchKernelGGL(k_transcript_combiner, dim3(vm_blocks), dim3(64), 0, st, d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace))
-        DBG_STAGE("k_g1_msm", launch_msm(d, n, w->scalars, w->pts, w->er, st))
+        DBG_STAGE("k_g1_msm", launch_msm(d, n, w->scalars, w->pts, w->er, w->msm_tab, st))
         DBG_STAGE("k_pairing_check", launch_pairing(d, n, w->pts, w->valid, w->er, status, accept, nullptr, st))
 #undef DBG_STAGE
         if (status_out) HIPCHK(hipMemcpyAsync(status_out, status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
@@ -334,7 +335,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipEventRecord(ev[1], pm));
         HIPCHK(hipStreamWaitEvent(pm, w->ev_join[k], 0));
         HIPCHK(hipEventRecord(ev[4], pm));
-        launch_msm(d, m, scal_k, pts_k, er_k, pm);
+        launch_msm(d, m, scal_k, pts_k, er_k, w->msm_tab + (size_t)lo * d.n_terms * 2 * 8 * 36, pm);
         HIPCHK(hipEventRecord(ev[5], pm));
         launch_pairing(d, m, pts_k, valid_k, er_k, status_k, accept_k, nullptr, pm);
         HIPCHK(hipEventRecord(ev[6], pm));
@@ -575,14 +576,15 @@ extern "C" int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_
     if (rc) return rc;
     if (!scalars || !bases_compressed || !out_xy_be || n == 0 || T == 0 || T > 64) return fail(H2V_E_ARG, "bad argument");
     MiniPlan mp;
-    DevBuf din, doff, dsc, dpts, dvalid, der, dout;
+    DevBuf din, doff, dsc, dpts, dvalid, der, dout, dtab;
     if (mp.build(T, T, nullptr, nullptr) || upload_offsets(doff, n, 48 * T) || din.alloc((size_t)n * T * 48) || dsc.alloc((size_t)n * T * 32) ||
         dpts.alloc((size_t)n * T * 96) || dvalid.alloc((size_t)n * T) || der.alloc((size_t)n * 144) || dout.alloc((size_t)n * 96))
         return fail(H2V_E_DEVICE, "probe setup failed");
     HIPCHK(hipMemcpy(din.p, bases_compressed, (size_t)n * T * 48, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dsc.p, scalars, (size_t)n * T * 32, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(64), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
-    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), nullptr);
+    if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 144)) return fail(H2V_E_DEVICE, "hipMalloc failed");
+    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), dtab.as<uint32_t>(), nullptr);
     hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 1, der.as<uint32_t>(), dout.as<uint8_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
@@ -600,7 +602,7 @@ extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t
     DevBuf ddbg;
     HIPCHK(hipSetDevice(p->device));
     MiniPlan mp;
-    DevBuf din, doff, dsc, dpts, dvalid, der, dst, dacc;
+    DevBuf din, doff, dsc, dpts, dvalid, der, dst, dacc, dtab;
     mp.d.lines28_sg2 = p->d.lines28_sg2;
     mp.d.lines28_g2 = p->d.lines28_g2;
     if (mp.build(2, 1, p->d.lines_sg2, p->d.lines_g2) || upload_offsets(doff, n, 96) || din.alloc((size_t)n * 96) || dsc.alloc((size_t)n * 32) ||
@@ -615,7 +617,8 @@ extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t
     HIPCHK(hipMemcpy(dsc.p, one.data(), one.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dst.p, 0, (size_t)n * 4));
     hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(64), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
-    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), nullptr);
+    if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 144)) return fail(H2V_E_DEVICE, "hipMalloc failed");
+    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), dtab.as<uint32_t>(), nullptr);
     if (ddbg.alloc(dbg ? (size_t)n * 24 * 48 : 8)) return fail(H2V_E_DEVICE, "hipMalloc failed");
     launch_pairing_impl(impl, mp.d, n, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), der.as<uint32_t>(), dst.as<uint32_t>(), dacc.as<uint8_t>(), dbg ? ddbg.as<uint32_t>() : nullptr, nullptr);
     HIPCHK(hipGetLastError());

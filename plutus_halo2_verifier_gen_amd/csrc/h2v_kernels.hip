@@ -343,7 +343,7 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
 // Bytes per term: 32 (scalar) + 96 (affine base) in, 144 per proof out (Jacobian).
 extern "C" __global__ void __launch_bounds__(128, 2)
 k_g1_msm(H2vDevPlan plan, uint32_t n, uint32_t tp /* pow2 >= n_terms, <= 64 */, const uint32_t *__restrict__ scalars,
-         const uint32_t *__restrict__ pts, uint32_t *__restrict__ out) {
+         const uint32_t *__restrict__ pts, uint32_t *__restrict__ out, uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];  // Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t]
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
     const uint32_t lanes_per_proof = 2 * tp;
@@ -391,16 +391,22 @@ k_g1_msm(H2vDevPlan plan, uint32_t n, uint32_t tp /* pow2 >= n_terms, <= 64 */, 
                 dg[q] = (int8_t)(carry ? (int)d - 16 : (int)d);
             }
             dg[32] = (int8_t)carry;
-            // table[m-1] = m*P, m = 1..8
-            G1J tab[8];
-            g1j_from_affine(tab[0], base);
-            g1j_dbl(tab[1], tab[0]);
-            g1j_add_affine(tab[2], tab[1], base);
-            g1j_dbl(tab[3], tab[1]);
-            g1j_add_affine(tab[4], tab[3], base);
-            g1j_dbl(tab[5], tab[2]);
-            g1j_add_affine(tab[6], tab[5], base);
-            g1j_dbl(tab[7], tab[3]);
+            // table[m-1] = m*P, m = 1..8, in a per-lane slab of the workspace: [lane][entry][36 dwords], so that the
+            // digit-indexed read of one entry is 144 contiguous bytes.  (A private-memory table is dword-interleaved
+            // across lanes: with per-lane digits every 4-byte read pulled its own sector, 2.4 GB fetched per launch.)
+            G1J *tab = reinterpret_cast<G1J *>(tabws + (((size_t)i * plan.n_terms + term) * 2 + half) * (8 * 36));
+            {
+                G1J t1, t2, t3, t4, tq;
+                g1j_from_affine(t1, base);
+                g1j_dbl(t2, t1);
+                g1j_add_affine(t3, t2, base);
+                g1j_dbl(t4, t2);
+                tab[0] = t1; tab[1] = t2; tab[2] = t3; tab[3] = t4;
+                g1j_add_affine(tq, t4, base); tab[4] = tq;
+                g1j_dbl(tq, t3); tab[5] = tq;
+                g1j_add_affine(tq, tq, base); tab[6] = tq;
+                g1j_dbl(tq, t4); tab[7] = tq;
+            }
             // `lad` is only ever touched by inlined code, so it is promoted to VGPRs; `acc` is handed by reference to the
             // out-of-line reduction below and therefore lives in private memory (keeping the ladder on `acc` cost
             // ~6 GB of scratch traffic per launch).
