@@ -151,7 +151,7 @@ def main():
             "pairing": B * (96 + 144 + 1 + 4) + 2 * 68 * 192,
         }
         kname = {"g1_msm": "k_g1_msm", "g1_decompress": "k_g1_decompress", "transcript_combiner": "k_transcript_combiner",
-                 "pairing": "k_pairing_check"}
+                 "pairing": "k_pairing_coop" if os.environ.get("H2V_PAIRING") != "legacy" else "k_pairing_check"}
 
         def roof(k):
             # one launch handles B / launches proofs; average launch duration = per-step sum / launches
