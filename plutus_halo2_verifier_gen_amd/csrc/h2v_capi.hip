@@ -294,7 +294,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipGetLastError());                                                              \
         HIPCHK(hipDeviceSynchronize());                                                         \
         fprintf(stderr, "[h2v] %s done\n", name); fflush(stderr);
-        DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(64), 0, st, d, n, proofs, off, ci, w->pts, w->valid))
+        DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(128), 0, st, d, n, proofs, off, ci, w->pts, w->valid))
         DBG_STAGE("k_transcript_combiner", hipLaunchKernelGGL(k_transcript_combiner, dim3(vm_blocks), dim3(64), 0, st, d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace))
         DBG_STAGE("k_g1_msm", launch_msm(d, n, w->scalars, w->pts, w->er, w->msm_tab, st))
         DBG_STAGE("k_pairing_check", launch_pairing(d, n, w->pts, w->valid, w->er, status, accept, nullptr, st))
@@ -327,7 +327,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipStreamWaitEvent(ps, w->ev_fork, 0));
         // decompression (many short waves) runs beside the transcript+combiner kernel (few long waves)
         HIPCHK(hipEventRecord(ev[2], ps));
-        hipLaunchKernelGGL(k_g1_decompress, dim3((m * slots + 63) / 64), dim3(64), 0, ps, d, m, proofs, off_k, ci_k, pts_k, valid_k);
+        hipLaunchKernelGGL(k_g1_decompress, dim3((m * slots + 63) / 64), dim3(128), 0, ps, d, m, proofs, off_k, ci_k, pts_k, valid_k);
         HIPCHK(hipEventRecord(ev[3], ps));
         HIPCHK(hipEventRecord(w->ev_join[k], ps));
         HIPCHK(hipEventRecord(ev[0], pm));
@@ -563,7 +563,7 @@ extern "C" int h2v_probe_g1_decompress(int device, uint32_t n, const uint8_t *co
     if (mp.build(1, 0, nullptr, nullptr) || upload_offsets(doff, n, 48) || din.alloc((size_t)n * 48) || dpts.alloc((size_t)n * 96) ||
         dvalid.alloc(n) || dout.alloc((size_t)n * 96)) return fail(H2V_E_DEVICE, "probe setup failed");
     HIPCHK(hipMemcpy(din.p, compressed, (size_t)n * 48, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_g1_decompress, dim3((n + 63) / 64), dim3(64), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
     hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 0, dpts.as<uint32_t>(), dout.as<uint8_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
@@ -582,7 +582,7 @@ extern "C" int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_
         return fail(H2V_E_DEVICE, "probe setup failed");
     HIPCHK(hipMemcpy(din.p, bases_compressed, (size_t)n * T * 48, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dsc.p, scalars, (size_t)n * T * 32, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(64), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
     if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 144)) return fail(H2V_E_DEVICE, "hipMalloc failed");
     launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), dtab.as<uint32_t>(), nullptr);
     hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 1, der.as<uint32_t>(), dout.as<uint8_t>());
@@ -616,7 +616,7 @@ extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t
     HIPCHK(hipMemcpy(din.p, in.data(), in.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dsc.p, one.data(), one.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dst.p, 0, (size_t)n * 4));
-    hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(64), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
     if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 144)) return fail(H2V_E_DEVICE, "hipMalloc failed");
     launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), dtab.as<uint32_t>(), nullptr);
     if (ddbg.alloc(dbg ? (size_t)n * 24 * 48 : 8)) return fail(H2V_E_DEVICE, "hipMalloc failed");

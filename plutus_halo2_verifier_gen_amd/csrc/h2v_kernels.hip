@@ -273,34 +273,54 @@ k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_
 // ============================================================================ K2: G1 decompression
 // zcash compressed encoding (bls_utils.ak:17-49, CompressUncompress.hs:53-100): bit7 compressed, bit6 infinity,
 // bit5 "y is the lexicographically larger root"; y = (x^3+4)^((p+1)/4).
-// One lane per (proof, point).  Slot n_points is the committed instance when the circuit has one.
+// Slot n_points is the committed instance when the circuit has one.
 // out: affine Montgomery x||y (24 dwords, (0,0) = infinity); valid[...] = 1 iff the encoding is a point of G1.
-extern "C" __global__ void __launch_bounds__(64, 2)
+//
+// TWO waves per 64 points (block = 128 threads, the role is wave-uniform), because the square root and the subgroup
+// test are the two long serial chains and the second does not need y:
+//   wave 0: y = c^((p+1)/4) with c = x^3 + 4, y^2 == c, sign selection;
+//   wave 1: r-torsion test sigma(P) == [-x^2]P carried to the isomorphic curve E': Y^2 = X^3 + 4c^3 through
+//           (x, y) -> (y^2 x, y^3 y) = (c x, c^2), which is known without the root.  The a = 0 group law does not
+//           involve b, and the isomorphism commutes with sigma (X -> beta X), so the test on E' is the test on E for
+//           either root y; when c is a non-residue wave 0 rejects and this result is ignored.  c == 0 means y == 0,
+//           a 2-torsion point: rejected.
+#define H2V_DEC_PTS 64
+extern "C" __global__ void __launch_bounds__(128, 2)
 k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
                 const uint8_t *__restrict__ committed, uint32_t *__restrict__ pts, uint8_t *__restrict__ valid) {
+    __shared__ uint8_t sub_ok[H2V_DEC_PTS];
     const uint32_t slots = plan.n_points + plan.n_ci;
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n * slots) return;
-    const uint32_t i = gid / slots, j = gid - i * slots;
-    const uint8_t *src;
+    const uint32_t role = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t gid = blockIdx.x * H2V_DEC_PTS + lane;
+    const bool live = gid < n * slots;
+    const uint32_t gg = live ? gid : 0;
+    const uint32_t i = gg / slots, j = gg - i * slots;
+    bool ok = live;
+    const uint8_t *src = nullptr;
     if (j < plan.n_points) {
         const uint64_t off0 = proof_off[i];
-        if (proof_off[i + 1] - off0 < plan.proof_len) { valid[gid] = 0; return; }  // short proof: nothing to read
-        src = proofs + off0 + plan.points[j];
+        if (proof_off[i + 1] - off0 < plan.proof_len) ok = false;  // short proof: nothing to read
+        else src = proofs + off0 + plan.points[j];
     } else {
         src = committed + (size_t)i * 48;
     }
     uint32_t w[12];  // big-endian bytes -> little-endian limbs
 #pragma unroll
-    for (int k = 0; k < 12; k++) {
-        const uint8_t *p = src + 44 - 4 * k;
-        w[k] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+    for (int k = 0; k < 12; k++) w[k] = 0;
+    if (ok) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const uint8_t *p = src + 44 - 4 * k;
+            w[k] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+        }
     }
     const uint32_t flags = w[11] >> 29;
     w[11] &= 0x1fffffffu;
     G1A out;
     g1a_set_inf(out);
-    bool ok = (flags & 4) != 0;
+    ok = ok && (flags & 4) != 0;
+    bool finite = false;
     if (ok && (flags & 2)) {
         // infinity: all other bits must be clear
         uint32_t any = flags & 1;
@@ -309,27 +329,42 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
         ok = any == 0;
     } else if (ok) {
         ok = !FpF::geq_mod(w);
-        if (ok) {
-            Fp x, y, t, b4;
+        finite = ok;
+    }
+    if (finite) {
+        Fp x, c, t, b4;
 #pragma unroll
-            for (int k = 0; k < 12; k++) { t.v[k] = w[k]; b4.v[k] = FP_B[k]; }
-            fp_to_mont(x, t);
-            fp_sqr(t, x); fp_mul(t, t, x); fp_add(t, t, b4);
-            fp_pow_const<12>(y, t, FP_SQRT_EXP);
-            Fp chk;
+        for (int k = 0; k < 12; k++) { t.v[k] = w[k]; b4.v[k] = FP_B[k]; }
+        fp_to_mont(x, t);
+        fp_sqr(c, x); fp_mul(c, c, x); fp_add(c, c, b4);
+        if (role == 0) {
+            Fp y, chk;
+            fp_pow_const<12>(y, c, FP_SQRT_EXP);
             fp_sqr(chk, y);
-            ok = fp_eq(chk, t);
+            ok = fp_eq(chk, c);
             if (ok) {
                 if (fp_is_lex_larger(y) != ((flags & 1) != 0)) fp_neg(y, y);
                 out.x = x; out.y = y;
-                ok = g1a_in_subgroup(out);
+            }
+        } else {
+            ok = !fp_is_zero(c);
+            if (ok) {
+                G1A q;
+                fp_mul(q.x, c, x);
+                fp_sqr(q.y, c);
+                ok = g1a_in_subgroup(q);
             }
         }
     }
-    if (!ok) g1a_set_inf(out);
+    if (role == 1) sub_ok[lane] = ok ? 1 : 0;
+    __syncthreads();
+    if (role == 0 && live) {
+        ok = ok && sub_ok[lane] != 0;
+        if (!ok) g1a_set_inf(out);
 #pragma unroll
-    for (int k = 0; k < 12; k++) { pts[(size_t)gid * 24 + k] = out.x.v[k]; pts[(size_t)gid * 24 + 12 + k] = out.y.v[k]; }
-    valid[gid] = ok ? 1 : 0;
+        for (int k = 0; k < 12; k++) { pts[(size_t)gid * 24 + k] = out.x.v[k]; pts[(size_t)gid * 24 + 12 + k] = out.y.v[k]; }
+        valid[gid] = ok ? 1 : 0;
+    }
 }
 
 // ============================================================================ K4: per-proof G1 MSM
