@@ -208,3 +208,92 @@ def test_api_errors(be, circuits):
         be.DevicePlan(bytes(bad), 0)
     # empty batch is fine
     assert dp.verify_batch(b"", [0], b"", None) == b""
+
+
+def _permute(batch, order, n_pi):
+    from plutus_halo2_verifier_gen_amd import synth
+    proofs = [batch.proof(i) for i in order]
+    off = [0]
+    for p in proofs:
+        off.append(off[-1] + len(p))
+    inst = b"".join(batch.instances[32 * n_pi * i:32 * n_pi * (i + 1)] for i in order)
+    ci = None if batch.committed is None else b"".join(batch.ci(i) for i in order)
+    return synth.Batch(n=len(order), proofs=b"".join(proofs), proof_off=off, instances=inst, committed=ci,
+                       expected=[batch.expected[i] for i in order])
+
+
+def test_full_size_batch_properties(be, circuits):
+    """BASELINE configs[1] size (simple_mul x 4096): size-independent properties + an oracle sample.
+    accept must equal the construction (forged proofs accept, every corruption kind rejects), must not depend on the
+    position of a proof in the batch (permutation), nor on the batch it travels in (prefix), and must equal the
+    oracle's verdict on a random sample."""
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    n, n_pi = 4096, vk.n_public_inputs
+    batch = synth.forge_batch(vk, td, n, seed=77, plan=pl, workers=8)
+    batch = synth.with_rejects(pl, batch, n_pi, fraction=0.1, seed=13, kinds=list(synth.CORRUPTIONS))
+    ws = be.Workspace(dp, n)
+    got = dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws)
+    assert list(got) == batch.expected
+    assert 3000 < sum(got) < n
+    order = list(range(n))
+    random.Random(5).shuffle(order)
+    perm = _permute(batch, order, n_pi)
+    got_p = dp.verify_batch(perm.proofs, perm.proof_off, perm.instances, perm.committed, ws=ws)
+    assert list(got_p) == [got[i] for i in order]
+    pre = _permute(batch, list(range(1000)), n_pi)
+    assert list(dp.verify_batch(pre.proofs, pre.proof_off, pre.instances, pre.committed)) == list(got[:1000])
+    sample = sorted(random.Random(6).sample(range(n), 192))
+    sb = _permute(batch, sample, n_pi)
+    want = ov.verify_batch(sb.proofs, sb.proof_off, sb.instances, sb.committed, threads=16)
+    assert list(want) == [got[i] for i in sample]
+
+
+def test_ragged_and_edge_batches(be, circuits):
+    """Ragged inputs: proofs of different lengths in one buffer (truncated, exact, with trailing bytes, empty), gaps
+    between proofs, a single-proof batch, and a batch larger than the workspace it is handed (must be refused, not
+    overrun).  prepare() reads exactly the plan's layout; trailing bytes are the business of assert_empty()
+    (examples/ivc.rs:92-94), so a proof followed by garbage still verifies."""
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    n_pi = vk.n_public_inputs
+    b = synth.forge_batch(vk, td, 6, seed=31, plan=pl, workers=1)
+    L = pl.proof_len
+    pieces = [b.proof(0), b.proof(1)[:L - 1], b.proof(2) + b"\xff" * 17, b"", b.proof(4)[:48], b.proof(5)]
+    expected = [1, 0, 1, 0, 0, 1]
+    # gaps: 5 junk bytes before every proof; offsets are given explicitly, so proof i is [off[i], off[i+1]) and the
+    # junk belongs to the previous proof's tail (ignored by prepare)
+    buf, off = b"", [0]
+    for p in pieces:
+        buf += p
+        off.append(len(buf))
+    got = dp.verify_batch(buf, off, b.instances, None)
+    want = ov.verify_batch(buf, off, b.instances, None, threads=2)
+    assert list(got) == list(want) == expected
+    # single proof
+    one = _permute(b, [3], n_pi)
+    assert list(dp.verify_batch(one.proofs, one.proof_off, one.instances, None)) == [1]
+    # workspace too small for the batch
+    ws = be.Workspace(dp, 2)
+    with pytest.raises(be.H2VError):
+        dp.verify_batch(b.proofs, b.proof_off, b.instances, None, ws=ws)
+    # the same workspace keeps working afterwards
+    two = _permute(b, [0, 1], n_pi)
+    assert list(dp.verify_batch(two.proofs, two.proof_off, two.instances, None, ws=ws)) == [1, 1]
+
+
+def test_verdict_is_deterministic_and_workspace_reusable(be, circuits):
+    """Idempotence: the same batch through the same workspace twice, then through a fresh one, gives one answer; a
+    rejecting batch does not poison the workspace for the next accepting one."""
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits["lookup_table"]
+    n_pi = vk.n_public_inputs
+    good = synth.forge_batch(vk, td, 96, seed=41, plan=pl, workers=1)
+    bad = synth.with_rejects(pl, good, n_pi, fraction=1.0, seed=3, kinds=list(synth.CORRUPTIONS))
+    ws = be.Workspace(dp, 96)
+    a1 = dp.verify_batch(good.proofs, good.proof_off, good.instances, good.committed, ws=ws)
+    r1 = dp.verify_batch(bad.proofs, bad.proof_off, bad.instances, bad.committed, ws=ws)
+    a2 = dp.verify_batch(good.proofs, good.proof_off, good.instances, good.committed, ws=ws)
+    a3 = dp.verify_batch(good.proofs, good.proof_off, good.instances, good.committed)
+    assert list(a1) == list(a2) == list(a3) == [1] * 96
+    assert list(r1) == bad.expected and sum(r1) == 0
