@@ -92,6 +92,31 @@ class VerifyingKey:
     def to_json(self) -> str:
         return json.dumps(asdict(self))
 
+    # ---- the instantiation-specific part, as the generated constant files carry it (wire.py: VKConstants)
+    def constants(self):
+        from .wire import VKConstants
+        return VKConstants(fixed_commitments=list(self.fixed_commitments),
+                           permutation_commitments=list(self.permutation_commitments), s_g2=self.s_g2,
+                           omega=self.omega, omega_inv=self.omega_inv, barycentric_weight=self.barycentric_weight,
+                           transcript_repr=self.transcript_repr, blinding_factors=self.blinding_factors)
+
+    def with_constants(self, c) -> "VerifyingKey":
+        """This circuit shape with the commitments / s_g2 / transcript representation of an exported
+        `verifier_key.ak` or `VKConstants.hs` (wire.load_vk_constants).  The domain constants must agree with k."""
+        from dataclasses import replace
+        from .wire import WireError
+        c.check(self.k)
+        if c.omega != self.omega:
+            raise WireError("omega differs from this build's 2^k-th root of unity")
+        if c.blinding_factors != self.blinding_factors:
+            raise WireError("blinding factors differ")
+        if len(c.fixed_commitments) != len(self.fixed_commitments) or \
+                len(c.permutation_commitments) != len(self.permutation_commitments):
+            raise WireError("commitment counts differ from the circuit shape")
+        return replace(self, fixed_commitments=list(c.fixed_commitments),
+                       permutation_commitments=list(c.permutation_commitments), s_g2=c.s_g2,
+                       transcript_repr=c.transcript_repr)
+
     @staticmethod
     def from_json(s: str) -> "VerifyingKey":
         d = json.loads(s)

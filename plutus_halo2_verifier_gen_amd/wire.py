@@ -1,0 +1,292 @@
+"""Wire formats of the artefacts the reference exports next to a proof, so that the
+backend consumes the reference's files directly.
+
+Formats (each restated from the reference lines cited; nothing here is on the per-proof hot path):
+
+* proof, hex          one line of lowercase hex, no newline         src/plutus_gen/proof_serialization.rs:11-25
+* proof, JSON         serde_json of a byte slice = `[12,255,...]`   proof_serialization.rs:27-41
+* public inputs       one 64-digit BIG-endian hex scalar per line   proof_serialization.rs:43-53
+* committed instance  affine x, newline, affine y (96 hex digits each, big-endian, no trailing newline);
+                      an empty file when the circuit has none      proof_serialization.rs:55-72
+* VK constants        the generated `verifier_key.ak` (emitters/aiken.rs:1049-1210 + aiken-verifier/templates/
+                      vk_constants.hbs) and `VKConstants.hs` (emitters/plinth.rs:915-1090 +
+                      plinth-verifier/templates/vk_constants.hbs): fixed / permutation commitments, s_g2, omega,
+                      omega^-1, barycentric weight, transcript representation, blinding factors.
+
+The C-ABI takes scalars as 32-byte little-endian and G1 as 48-byte zcash-compressed (include/h2v.h); the loaders
+return those.  The KZG parameter file (`SerdeFormat::RawBytesUnchecked`, src/kzg_params.rs:50-57) is NOT read here:
+its layout is defined inside the un-vendored `midnight-proofs` crate and the reference holds no sample of it, so a
+reader could not be pinned; `s_g2` comes from the VK constants files instead, which carry it in compressed form.
+"""
+from __future__ import annotations
+
+import json
+import re
+from dataclasses import dataclass, field
+from typing import IO, List, Optional, Sequence, Tuple
+
+from . import bls12_381 as bls
+
+R, P = bls.R, bls.P
+
+
+class WireError(ValueError):
+    pass
+
+
+# ----------------------------------------------------------------------------- proof
+def export_proof(path: str, proof: bytes) -> None:
+    """proof_serialization.rs:11-25 (`export_proof`)."""
+    with open(path, "w") as f:
+        f.write(bytes(proof).hex())
+
+
+def serialize_proof(path: str, proof: bytes) -> None:
+    """proof_serialization.rs:27-41 (`serialize_proof`): serde_json of `&[u8]` is an array of integers, no spaces."""
+    with open(path, "w") as f:
+        f.write(json.dumps(list(bytes(proof)), separators=(",", ":")))
+
+
+def parse_proof(text: str) -> bytes:
+    """Accepts either export: hex text or the JSON byte array."""
+    t = text.strip()
+    if t.startswith("["):
+        try:
+            vals = json.loads(t)
+        except json.JSONDecodeError as e:
+            raise WireError("proof JSON: %s" % e)
+        if not all(isinstance(v, int) and 0 <= v <= 255 for v in vals):
+            raise WireError("proof JSON: entries must be bytes")
+        return bytes(vals)
+    try:
+        return bytes.fromhex(t)
+    except ValueError as e:
+        raise WireError("proof hex: %s" % e)
+
+
+def load_proof(path: str) -> bytes:
+    with open(path) as f:
+        return parse_proof(f.read())
+
+
+# ----------------------------------------------------------------------------- public inputs
+def export_public_inputs(instance: Sequence[int], out: IO[str]) -> None:
+    """proof_serialization.rs:43-53: `to_bytes_be()` hex + newline per scalar."""
+    for v in instance:
+        if not 0 <= v < R:
+            raise WireError("public input out of range")
+        out.write("%064x\n" % v)
+
+
+def parse_public_inputs(text: str) -> List[int]:
+    vals = []
+    for ln, line in enumerate(text.splitlines(), 1):
+        s = line.strip()
+        if not s:
+            continue
+        if len(s) != 64 or not re.fullmatch(r"[0-9a-fA-F]{64}", s):
+            raise WireError("public inputs line %d: expected 64 hex digits" % ln)
+        v = int(s, 16)
+        if v >= R:
+            raise WireError("public inputs line %d: not a canonical scalar" % ln)
+        vals.append(v)
+    return vals
+
+
+def load_public_inputs(path: str) -> List[int]:
+    with open(path) as f:
+        return parse_public_inputs(f.read())
+
+
+def instances_to_abi(values: Sequence[int]) -> bytes:
+    """32-byte little-endian each: the layout of h2v_batch.instances (include/h2v.h)."""
+    return b"".join(int(v).to_bytes(32, "little") for v in values)
+
+
+# ----------------------------------------------------------------------------- committed instance
+def export_committed_inputs(point: Optional[Tuple[int, int]], out: IO[str]) -> None:
+    """proof_serialization.rs:55-72: nothing for None; x, newline, y (no trailing newline) otherwise."""
+    if point is None:
+        return
+    x, y = point
+    out.write("%096x\n" % x)
+    out.write("%096x" % y)
+
+
+def parse_committed_inputs(text: str) -> Optional[Tuple[int, int]]:
+    lines = [s.strip() for s in text.splitlines() if s.strip()]
+    if not lines:
+        return None
+    if len(lines) != 2 or any(not re.fullmatch(r"[0-9a-fA-F]{96}", s) for s in lines):
+        raise WireError("committed instance: expected two lines of 96 hex digits")
+    x, y = int(lines[0], 16), int(lines[1], 16)
+    if x >= P or y >= P:
+        raise WireError("committed instance: coordinate not reduced")
+    if (x, y) != (0, 0) and (y * y - x * x * x - 4) % P != 0:
+        raise WireError("committed instance: not on the curve")
+    return (x, y)
+
+
+def load_committed_inputs(path: str) -> Optional[Tuple[int, int]]:
+    with open(path) as f:
+        return parse_committed_inputs(f.read())
+
+
+def committed_to_abi(point: Optional[Tuple[int, int]]) -> Optional[bytes]:
+    """48-byte compressed G1 (h2v_batch.committed).  The exporter writes the identity as (0, 0)."""
+    if point is None:
+        return None
+    return bls.g1_compress(None if point == (0, 0) else point)
+
+
+# ----------------------------------------------------------------------------- VK constants (generated files)
+@dataclass
+class VKConstants:
+    """`InstantiationSpecificData` as far as the generated constant files carry it
+    (extraction/data/.../instantiation_data.rs:26-41)."""
+    fixed_commitments: List[str] = field(default_factory=list)        # 48-byte compressed, hex
+    permutation_commitments: List[str] = field(default_factory=list)
+    s_g2: str = ""                                                    # 96-byte compressed, hex
+    omega: int = 0
+    omega_inv: int = 0
+    barycentric_weight: int = 0
+    transcript_repr: int = 0
+    blinding_factors: int = 0
+
+    def check(self, k: Optional[int] = None) -> None:
+        """Internal consistency the reference guarantees by construction."""
+        if self.omega * self.omega_inv % R != 1:
+            raise WireError("omega * omega_inv != 1")
+        for h in self.fixed_commitments + self.permutation_commitments:
+            bls.g1_decompress(bytes.fromhex(h), True)
+        bls.g2_decompress(bytes.fromhex(self.s_g2))
+        if k is not None:
+            if pow(self.omega, 1 << k, R) != 1 or pow(self.omega, 1 << (k - 1), R) == 1:
+                raise WireError("omega is not a primitive 2^k-th root of unity")
+            if self.barycentric_weight * (1 << k) % R != 1:
+                raise WireError("barycentric weight != 1/n")
+
+
+def _compress_xy(x: int, y: int) -> str:
+    return bls.g1_compress(None if (x, y) == (0, 0) else (x, y)).hex()
+
+
+def render_vk_constants_aiken(c: VKConstants) -> str:
+    """The constant definitions of a generated `verifier_key.ak` (line formats of emitters/aiken.rs:1049-1160 and the
+    template's scalar lines).  Only the definitions: imports and the budget-check tests carry no data."""
+    o = []
+    for i, h in enumerate(c.permutation_commitments):
+        o.append('pub const p%d_commitment: ByteArray = #"%s"' % (i + 1, h))
+    o.append("")
+    for i, h in enumerate(c.fixed_commitments):
+        o.append('pub const f%d_commitment: ByteArray = #"%s"' % (i + 1, h))
+    o.append("")
+    o.append('pub const g2_const: G2Element = decompress_g2( #"%s" )' % c.s_g2)
+    o.append("pub const omega: State<Scalar> = from_int( 0x%064x )" % c.omega)
+    o.append("pub const omega_inv: State<Scalar> = from_int( 0x%064x )" % c.omega_inv)
+    o.append("pub const barycentric_weight: State<Scalar> = from_int( 0x%064x )" % c.barycentric_weight)
+    o.append("pub const transcript_rep: State<Scalar> = from_int( 0x%064x )" % c.transcript_repr)
+    o.append("pub const blinding_factors: Int = %d" % c.blinding_factors)
+    return "\n".join(o) + "\n"
+
+
+def parse_vk_constants_aiken(text: str) -> VKConstants:
+    c = VKConstants()
+
+    def numbered(prefix):
+        found = {int(m.group(1)): m.group(2).lower()
+                 for m in re.finditer(r'pub const %s(\d+)_commitment\s*:\s*ByteArray\s*=\s*#"([0-9a-fA-F]{96})"' % prefix, text)}
+        if sorted(found) != list(range(1, len(found) + 1)):
+            raise WireError("%s commitments are not numbered 1..n" % prefix)
+        return [found[i] for i in range(1, len(found) + 1)]
+
+    c.fixed_commitments = numbered("f")
+    c.permutation_commitments = numbered("p")
+    m = re.search(r'g2_const\s*:\s*G2Element\s*=\s*decompress_g2\(\s*#"([0-9a-fA-F]{192})"\s*\)', text)
+    if not m:
+        raise WireError("g2_const not found")
+    c.s_g2 = m.group(1).lower()
+
+    def scalar(name):
+        m = re.search(r"pub const %s\s*:\s*State<Scalar>\s*=\s*from_int\(\s*0x([0-9a-fA-F]+)\s*\)" % name, text)
+        if not m:
+            raise WireError("%s not found" % name)
+        return int(m.group(1), 16)
+
+    c.omega, c.omega_inv = scalar("omega"), scalar("omega_inv")
+    c.barycentric_weight, c.transcript_repr = scalar("barycentric_weight"), scalar("transcript_rep")
+    m = re.search(r"pub const blinding_factors\s*:\s*Int\s*=\s*(\d+)", text)
+    if not m:
+        raise WireError("blinding_factors not found")
+    c.blinding_factors = int(m.group(1))
+    return c
+
+
+def render_vk_constants_plinth(c: VKConstants) -> str:
+    """The data-carrying definitions of a generated `VKConstants.hs` (emitters/plinth.rs:917-975, 1046-1090)."""
+    def pairs(hexes):
+        rows = []
+        for h in hexes:
+            pt = bls.g1_decompress(bytes.fromhex(h), False)
+            x, y = (0, 0) if pt is None else pt
+            rows.append("    (0x%096x, 0x%096x)" % (x, y))
+        return ",\n".join(rows)
+
+    o = ["f_commitments_val_pairs :: [(Integer, Integer)]", "f_commitments_val_pairs =", "  [",
+         pairs(c.fixed_commitments), "  ]", "",
+         "p_commitment_val_pairs :: [(Integer, Integer)]", "p_commitment_val_pairs =", "  [",
+         pairs(c.permutation_commitments), "  ]", "",
+         "s_g2_val_bbs :: BuiltinByteString", "s_g2_val_bbs =", "  stringToBuiltinByteStringHex", '    "%s"' % c.s_g2, ""]
+    for name, v in (("omega_val", c.omega), ("omegaInv_val", c.omega_inv),
+                    ("barycentricWeight_val", c.barycentric_weight), ("transcriptRepr", c.transcript_repr)):
+        o += ["%s :: Scalar" % name, "%s =" % name, "  mkScalar", "    (0x%064x `modulo` bls12_381_field_prime)" % v, ""]
+    o += ["blinding_factors :: Integer", "blinding_factors = %d" % c.blinding_factors]
+    return "\n".join(o) + "\n"
+
+
+def parse_vk_constants_plinth(text: str) -> VKConstants:
+    c = VKConstants()
+
+    def pair_list(name):
+        m = re.search(r"^%s\s*=\s*\[(.*?)\]" % name, text, re.S | re.M)
+        if not m:
+            raise WireError("%s not found" % name)
+        out = []
+        for x, y in re.findall(r"\(\s*0x([0-9a-fA-F]+)\s*,\s*0x([0-9a-fA-F]+)\s*\)", m.group(1)):
+            xi, yi = int(x, 16), int(y, 16)
+            if xi >= P or yi >= P:
+                raise WireError("%s: coordinate not reduced" % name)
+            if (xi, yi) != (0, 0) and (yi * yi - xi * xi * xi - 4) % P != 0:
+                raise WireError("%s: point not on the curve" % name)
+            out.append(_compress_xy(xi, yi))
+        return out
+
+    c.fixed_commitments = pair_list("f_commitments_val_pairs")
+    c.permutation_commitments = pair_list("p_commitment_val_pairs")
+    m = re.search(r'stringToBuiltinByteStringHex\s*"([0-9a-fA-F]{192})"', text)
+    if not m:
+        raise WireError("s_g2 not found")
+    c.s_g2 = m.group(1).lower()
+
+    def scalar(name):
+        m = re.search(r"^%s\s*=\s*mkScalar\s*\(\s*0x([0-9a-fA-F]+)\s*`modulo`" % name, text, re.S | re.M)
+        if not m:
+            raise WireError("%s not found" % name)
+        return int(m.group(1), 16) % R
+
+    c.omega, c.omega_inv = scalar("omega_val"), scalar("omegaInv_val")
+    c.barycentric_weight, c.transcript_repr = scalar("barycentricWeight_val"), scalar("transcriptRepr")
+    m = re.search(r"^blinding_factors\s*=\s*(\d+)", text, re.M)
+    if not m:
+        raise WireError("blinding_factors not found")
+    c.blinding_factors = int(m.group(1))
+    return c
+
+
+def parse_vk_constants(text: str) -> VKConstants:
+    return parse_vk_constants_aiken(text) if "pub const" in text else parse_vk_constants_plinth(text)
+
+
+def load_vk_constants(path: str) -> VKConstants:
+    with open(path) as f:
+        return parse_vk_constants(f.read())

@@ -297,3 +297,30 @@ def test_verdict_is_deterministic_and_workspace_reusable(be, circuits):
     a3 = dp.verify_batch(good.proofs, good.proof_off, good.instances, good.committed)
     assert list(a1) == list(a2) == list(a3) == [1] * 96
     assert list(r1) == bad.expected and sum(r1) == 0
+
+
+def test_exported_artefact_files_verify_on_gpu(be, circuits, tmp_path, capsys):
+    """The reference's export files (proof hex + JSON, public-input lines, committed x/y, generated VK constants;
+    proof_serialization.rs:11-72, shared_utils/mod.rs:23-65) read back and verified through the C-ABI."""
+    from plutus_halo2_verifier_gen_amd import synth, verify_files, wire
+    vk, td, pl, dp, ov = circuits["sha256"]
+    assert vk.n_committed_instances == 1
+    b = synth.forge_batch(vk, td, 2, seed=51, plan=pl, workers=1)
+    (tmp_path / "vk.json").write_text(vk.to_json())
+    (tmp_path / "verifier_key.ak").write_text(wire.render_vk_constants_aiken(vk.constants()))
+    args = ["--vk", str(tmp_path / "vk.json"), "--vk-constants", str(tmp_path / "verifier_key.ak")]
+    for i in range(2):
+        wire.export_proof(str(tmp_path / ("p%d.hex" % i)), b.proof(i))
+        wire.serialize_proof(str(tmp_path / ("p%d.json" % i)), b.proof(i))
+        with open(tmp_path / ("pi%d.hex" % i), "w") as f:
+            wire.export_public_inputs(b.instance_ints(i, vk.n_public_inputs), f)
+        with open(tmp_path / ("ci%d.hex" % i), "w") as f:
+            wire.export_committed_inputs(bls.g1_decompress(b.ci(i), False) or (0, 0), f)
+        args += ["--proof", str(tmp_path / ("p%d.%s" % (i, "hex" if i == 0 else "json"))),
+                 "--public-inputs", str(tmp_path / ("pi%d.hex" % i)), "--committed", str(tmp_path / ("ci%d.hex" % i))]
+    assert verify_files.main(args) == 0
+    assert capsys.readouterr().out.count("accept") == 2
+    # swap the public inputs of the two proofs: both must be rejected
+    swapped = [a.replace("pi0", "piX").replace("pi1", "pi0").replace("piX", "pi1") for a in args]
+    assert verify_files.main(swapped) == 1
+    assert capsys.readouterr().out.count("reject") == 2

@@ -1,0 +1,109 @@
+"""Wire formats of the reference's exported artefacts: proof hex / JSON, public-input lines,
+committed-instance x/y, generated VK constant files.  CPU only; the GPU leg is in test_gpu_parity.py."""
+import io
+import json
+import random
+
+import pytest
+
+from plutus_halo2_verifier_gen_amd import bls12_381 as bls
+from plutus_halo2_verifier_gen_amd import vk as V
+from plutus_halo2_verifier_gen_amd import wire
+
+R = bls.R
+
+
+def test_proof_hex_and_json_roundtrip(tmp_path, kats):
+    proof = bytes.fromhex(kats["simple_mul_full"]["proof"])
+    h, j = tmp_path / "serialized_proof.hex", tmp_path / "serialized_proof.json"
+    wire.export_proof(str(h), proof)
+    wire.serialize_proof(str(j), proof)
+    # proof_serialization.rs:12 hex::encode = lowercase, no newline; :28 serde_json of &[u8] = integer array
+    assert h.read_text() == proof.hex()
+    assert json.loads(j.read_text()) == list(proof) and " " not in j.read_text()
+    assert wire.load_proof(str(h)) == wire.load_proof(str(j)) == proof
+    with pytest.raises(wire.WireError):
+        wire.parse_proof("zz")
+    with pytest.raises(wire.WireError):
+        wire.parse_proof("[1,2,256]")
+
+
+def test_public_inputs_are_big_endian_lines():
+    vals = [42, 0, R - 1, 1 << 200]
+    out = io.StringIO()
+    wire.export_public_inputs(vals, out)
+    lines = out.getvalue().split("\n")
+    assert lines[-1] == "" and len(lines) == 5
+    assert lines[0] == "00" * 31 + "2a"                       # to_bytes_be (proof_serialization.rs:45)
+    assert wire.parse_public_inputs(out.getvalue()) == vals
+    assert wire.instances_to_abi([42])[:2] == b"\x2a\x00"     # the C-ABI side is little-endian
+    with pytest.raises(wire.WireError):
+        wire.parse_public_inputs("%064x\n" % R)               # non-canonical
+    with pytest.raises(wire.WireError):
+        wire.parse_public_inputs("2a\n")
+
+
+def test_committed_instance_xy():
+    pt = bls.g1_mul(bls.G1_GEN, 12345)
+    out = io.StringIO()
+    wire.export_committed_inputs(pt, out)
+    text = out.getvalue()
+    assert text.count("\n") == 1 and not text.endswith("\n")  # x, newline, y, no trailing newline (:60-68)
+    assert wire.parse_committed_inputs(text) == pt
+    assert wire.committed_to_abi(pt) == bls.g1_compress(pt)
+    none = io.StringIO()
+    wire.export_committed_inputs(None, none)
+    assert none.getvalue() == "" and wire.parse_committed_inputs("") is None
+    assert wire.committed_to_abi((0, 0)) == bls.g1_compress(None)
+    with pytest.raises(wire.WireError):
+        wire.parse_committed_inputs("%096x\n%096x" % (pt[0], pt[1] ^ 1))
+
+
+@pytest.mark.parametrize("flavour", ["aiken", "plinth"])
+def test_vk_constants_files_roundtrip(flavour):
+    vk, _ = V.lookup_table_vk()
+    c = vk.constants()
+    c.check(vk.k)
+    render = wire.render_vk_constants_aiken if flavour == "aiken" else wire.render_vk_constants_plinth
+    text = render(c)
+    back = wire.parse_vk_constants(text)
+    assert back == c
+    # a different instantiation of the same circuit shape: constants replace, structure stays
+    rng = random.Random(4)
+    other = wire.VKConstants(**{**c.__dict__})
+    other.fixed_commitments = [bls.g1_compress(bls.g1_mul(bls.G1_GEN, rng.randrange(1, R))).hex() for _ in c.fixed_commitments]
+    other.transcript_repr = rng.randrange(R)
+    vk2 = vk.with_constants(wire.parse_vk_constants(render(other)))
+    assert vk2.fixed_commitments == other.fixed_commitments and vk2.gates == vk.gates
+    assert vk2.transcript_repr == other.transcript_repr
+    bad = wire.VKConstants(**{**c.__dict__})
+    bad.omega = (c.omega * c.omega) % R
+    with pytest.raises(wire.WireError):
+        vk.with_constants(bad)
+
+
+def test_vk_constants_golden_line_formats(kats):
+    """The reference's own constants (vk_constants.hbs / transcript.ak) in the generated-file syntax."""
+    neg_g1 = kats["neg_g1_generator"]
+    c = wire.VKConstants(fixed_commitments=[neg_g1.lower()], permutation_commitments=[],
+                         s_g2=bls.g2_compress(bls.G2_GEN).hex(), omega=V.domain_omega(4),
+                         omega_inv=bls.fr_inv(V.domain_omega(4)), barycentric_weight=bls.fr_inv(16),
+                         transcript_repr=7, blinding_factors=5)
+    text = wire.render_vk_constants_aiken(c)
+    assert 'pub const f1_commitment: ByteArray = #"%s"' % neg_g1.lower() in text     # emitters/aiken.rs:1060-1064
+    assert "pub const blinding_factors: Int = 5" in text
+    hs = wire.render_vk_constants_plinth(c)
+    x, y = bls.g1_neg(bls.G1_GEN)
+    assert "(0x%096x, 0x%096x)" % (x, y) in hs                                         # emitters/plinth.rs:923-927
+    assert wire.parse_vk_constants(hs) == c
+
+
+def test_assemble_batch_layout():
+    from plutus_halo2_verifier_gen_amd import verify_files
+    vk, _ = V.simple_mul_vk()
+    proofs = [b"\x01" * 10, b"\x02" * 7]
+    buf, off, inst, ci = verify_files.assemble(vk, proofs, [[1, 2, 3]], [])
+    assert off == [0, 10, 17] and buf == proofs[0] + proofs[1] and ci is None
+    assert inst == wire.instances_to_abi([1, 2, 3]) * 2
+    with pytest.raises(wire.WireError):
+        verify_files.assemble(vk, proofs, [[1, 2]], [])
