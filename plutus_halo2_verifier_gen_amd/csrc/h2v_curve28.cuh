@@ -1,0 +1,141 @@
+// G1 group law (a = 0 short Weierstrass; the constant b never enters the formulas, so the same code serves
+// y^2 = x^3 + 4 and the isomorphic curves the subgroup test works on) over the lazily reduced field of h2v_fp28.cuh.
+//
+// The point at infinity is an explicit flag (`inf`) beside the coordinates: with lazily reduced coordinates "Z == 0"
+// is not a limb pattern.  Completeness is kept exactly as in h2v_curve.cuh (P+P, P+(-P), infinity operands): proof
+// bytes are adversarial and the verdict must match the reference's group law
+// (aiken-verifier/aiken_halo2/lib/bls_utils.ak:77-86, the Plutus builtins bls12_381_G1_add / scalarMul).
+//
+// Coordinate bounds (v, lam) of every stored point, see h2v_fp28.cuh for the notation:
+//     X (31, 1)   Y (20, 1)   Z (4, 2)           -- closed under g1j28_dbl and g1j28_add (derivations inline);
+//     table entries (never negated in place) have Y (19, 1)
+#pragma once
+#include "h2v_curve.cuh"
+#include "h2v_fp28.cuh"
+
+struct G1J28 { F28 x, y, z; };
+
+// affine canonical point -> Jacobian (1,1),(1,1),(1,1)
+H2V_DI void g1j28_from_affine(G1J28 &r, const G1A &a) {
+    f28_from_fp(r.x, a.x);
+    f28_from_fp(r.y, a.y);
+    f28_set_one(r.z);
+}
+// -> canonical Jacobian coordinates of h2v_curve.cuh
+H2V_DI void g1j28_to_g1j(G1J &r, const G1J28 &p, const bool inf) {
+    if (inf) { g1j_set_inf(r); return; }
+    F28 z = p.z;
+    f28_carry(z);
+    f28_to_fp(r.x, p.x);
+    f28_to_fp(r.y, p.y);
+    f28_to_fp(r.z, z);
+}
+// dbl-2009-l, 2M + 5S.  p must not be infinity and must not have y == 0 (no 2-torsion on these curves: the group
+// order is odd).  In: X (<=43, 1), Y (<=45, 1), Z (v_Y v_Z <= 2048, lam <= 2).  Out: X (31,1) Y (19,1) Z (4,2).
+H2V_DI void g1j28_dbl(G1J28 &r, const G1J28 &p) {
+    F28 X = p.x, Y = p.y, Z = p.z, A, B, C, D, t;
+    f28_mul(Z, Y, Z); f28_mul_small<2>(Z, Z);        // Z3 = 2 Y Z                      (4, 2)
+    f28_sqr(A, X);                                   // A = X^2                          (2, 1)
+    f28_sqr(B, Y);                                   // B = Y^2                          (2, 1)
+    f28_add(t, X, B); f28_sqr(t, t);                 // (X + B)^2, operand (v_X+2, 2)    (2, 1)
+    f28_sqr(C, B);                                   // C = B^2                          (2, 1)
+    f28_add(D, A, C);                                //                                  (4, 2)
+    F28_SUB(t, t, D, 5, 2);                          // (X+B)^2 - A - C                  (7, 5)
+    f28_mul_small<2>(D, t); f28_carry(D);            // D                                (14, 1)
+    f28_mul_small<3>(A, A);                          // E = 3A                           (6, 3)
+    f28_sqr(X, A);                                   // E^2   lam 9, v 36                (2, 1)
+    f28_mul_small<2>(t, D);                          // 2D                               (28, 2)
+    F28_SUB(X, X, t, 29, 2); f28_carry(X);           // X3 = E^2 - 2D                    (31, 1)
+    F28_SUB(t, D, X, 32, 1);                         // D - X3                           (46, 4)
+    f28_mul(Y, A, t);                                // E (D - X3)  lam 12, v 276        (2, 1)
+    f28_mul_small<8>(C, C);                          // 8C                               (16, 8)
+    F28_SUB(Y, Y, C, 17, 8); f28_carry(Y);           // Y3                               (19, 1)
+    r.x = X; r.y = Y; r.z = Z;
+}
+// r = p + (neg_q ? -q : q), 12M + 4S; neither operand is infinity (the callers keep the flags).
+// Returns 0: generic sum in r; 1: p == +-q with equal y -> r = 2p; 2: p == -(+-q) -> the sum is infinity (r untouched).
+// In: both operands with the stored-point bounds.  Out: X (10,1) Y (5,1) Z (2,1).
+H2V_DI int g1j28_add(G1J28 &r, const G1J28 &p, const G1J28 &q, const bool neg_q) {
+    F28 X1 = p.x, Y1 = p.y, Z1 = p.z, a, b, c, t;
+    f28_sqr(a, q.z);                                 // Z2^2       lam 4, v 16           (2, 1)
+    f28_mul(X1, X1, a);                              // U1         v 62                  (2, 1)
+    f28_mul(t, q.z, a); f28_mul(Y1, Y1, t);          // S1         v 8 ; 38              (2, 1)
+    f28_sqr(a, Z1);                                  // Z1^2                             (2, 1)
+    f28_mul(b, q.x, a);                              // U2                               (2, 1)
+    f28_mul(t, Z1, a);                               // Z1^3                             (2, 1)
+    {
+        F28 qy = q.y, nq;
+        F28_NEG(nq, qy, 20, 1);                      // -Y2                              (20, 3)
+        if (neg_q) qy = nq;
+        f28_mul(c, qy, t);                           // S2         lam 3, v 40           (2, 1)
+    }
+    F28_SUB(b, b, X1, 3, 1); f28_carry(b);           // H = U2 - U1                      (5, 1)
+    F28_SUB(c, c, Y1, 3, 1); f28_carry(c);           // R = S2 - S1                      (5, 1)
+    if (f28_is_zero_v5(b)) {
+        if (f28_is_zero_v5(c)) { g1j28_dbl(r, p); return 1; }
+        return 2;
+    }
+    f28_mul(Z1, Z1, q.z); f28_mul(Z1, Z1, b);        // Z3         lam 4, v 16 ; v 10    (2, 1)
+    f28_sqr(a, b);                                   // HH                               (2, 1)
+    f28_mul(b, b, a);                                // HHH                              (2, 1)
+    f28_mul(a, X1, a);                               // V = U1 HH                        (2, 1)
+    f28_sqr(X1, c);                                  // R^2                              (2, 1)
+    F28_SUB(X1, X1, b, 3, 1);                        // R^2 - HHH                        (5, 4)
+    f28_mul_small<2>(t, a);                          // 2V                               (4, 2)
+    F28_SUB(X1, X1, t, 5, 2); f28_carry(X1);         // X3                               (10, 1)
+    F28_SUB(t, a, X1, 11, 1);                        // V - X3                           (13, 4)
+    f28_mul(c, c, t);                                // R (V - X3)   lam 4, v 65         (2, 1)
+    f28_mul(t, Y1, b);                               // S1 HHH                           (2, 1)
+    F28_SUB(Y1, c, t, 3, 1); f28_carry(Y1);          // Y3                               (5, 1)
+    r.x = X1; r.y = Y1; r.z = Z1;
+    return 0;
+}
+// acc (+flag) += (neg ? -q : q), q finite
+H2V_DI void g1j28_acc_add(G1J28 &acc, bool &acc_inf, const G1J28 &q, const bool neg) {
+    if (acc_inf) {
+        acc = q;
+        if (neg) { F28 ny; F28_NEG(ny, q.y, 20, 1); f28_carry(ny); acc.y = ny; }   // (20, 1)
+        acc_inf = false;
+        return;
+    }
+    const int k = g1j28_add(acc, acc, q, neg);
+    if (k == 2) acc_inf = true;
+}
+// out-of-line forms for the cold paths (window-table construction)
+H2V_DN void g1j28_dbl_ool(G1J28 &r, const G1J28 &p) { g1j28_dbl(r, p); }
+H2V_DN int g1j28_add_ool(G1J28 &r, const G1J28 &p, const G1J28 &q) { return g1j28_add(r, p, q, false); }
+
+// [|x|]P, |x| = 0xd201000000010000, complete (P of any order on an a = 0 curve of odd order)
+H2V_DN void g1j28_mul_x_abs(G1J28 &r, bool &r_inf, const G1J28 &p, const bool p_inf) {
+    G1J28 acc = p;
+    bool inf = p_inf;
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        if (!inf) g1j28_dbl(acc, acc);
+        if (((BLS_X_ABS >> i) & 1) && !p_inf) g1j28_acc_add(acc, inf, p, false);
+    }
+    r = acc;
+    r_inf = inf;
+}
+// Same statement as g1a_in_subgroup (h2v_curve.cuh): sigma(P) = (beta x, y) == [-x^2]P, for a finite affine point of
+// an a = 0 curve; the two 63-step chains run on the lazily reduced field, the final comparison on canonical limbs.
+H2V_DN bool g1a_in_subgroup28(const G1A &a) {
+    G1J28 p, t;
+    bool tinf = false;
+    g1j28_from_affine(p, a);
+    g1j28_mul_x_abs(t, tinf, p, false);
+    g1j28_mul_x_abs(t, tinf, t, tinf);   // [x^2]P
+    if (tinf) return false;
+    G1J tj;
+    g1j28_to_g1j(tj, t, false);
+    Fp beta, z2, z3, l, ny;
+#pragma unroll
+    for (int i = 0; i < 12; i++) beta.v[i] = FP_BETA[i];
+    fp_sqr(z2, tj.z);
+    fp_mul(z3, z2, tj.z);
+    fp_mul(l, a.x, beta); fp_mul(l, l, z2);
+    if (!fp_eq(l, tj.x)) return false;
+    fp_mul(l, a.y, z3);
+    fp_neg(ny, tj.y);
+    return fp_eq(l, ny);
+}

@@ -11,7 +11,7 @@
 // calls (aiken-verifier/aiken_halo2/lib/{transcript,lagrange,halo2_kzg,bls_utils}.ak); hash plug-in
 // /root/reference/src/plutus_gen/adjusted_types/mod.rs:30-72.
 #include <hip/hip_runtime.h>
-#include "h2v_curve.cuh"
+#include "h2v_curve28.cuh"
 #include "h2v_plan.h"
 #include "h2v_tower.cuh"
 #include "h2v_pairing_coop.cuh"
@@ -339,7 +339,12 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
         fp_sqr(c, x); fp_mul(c, c, x); fp_add(c, c, b4);
         if (role == 0) {
             Fp y, chk;
-            fp_pow_const<12>(y, c, FP_SQRT_EXP);
+            {
+                F28 c28, y28;
+                f28_from_fp(c28, c);
+                f28_pow_const<12>(y28, c28, FP_SQRT_EXP);
+                f28_to_fp(y, y28);
+            }
             fp_sqr(chk, y);
             ok = fp_eq(chk, c);
             if (ok) {
@@ -352,7 +357,7 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
                 G1A q;
                 fp_mul(q.x, c, x);
                 fp_sqr(q.y, c);
-                ok = g1a_in_subgroup(q);
+                ok = g1a_in_subgroup28(q);
             }
         }
     }
@@ -429,34 +434,34 @@ k_g1_msm(H2vDevPlan plan, uint32_t n, uint32_t tp /* pow2 >= n_terms, <= 64 */, 
             // table[m-1] = m*P, m = 1..8, in a per-lane slab of the workspace: [lane][entry][36 dwords], so that the
             // digit-indexed read of one entry is 144 contiguous bytes.  (A private-memory table is dword-interleaved
             // across lanes: with per-lane digits every 4-byte read pulled its own sector, 2.4 GB fetched per launch.)
-            G1J *tab = reinterpret_cast<G1J *>(tabws + (((size_t)i * plan.n_terms + term) * 2 + half) * (8 * 36));
+            G1J28 *tab = reinterpret_cast<G1J28 *>(tabws + (((size_t)i * plan.n_terms + term) * 2 + half) * (8 * 42));
             {
-                G1J t1, t2, t3, t4, tq;
-                g1j_from_affine(t1, base);
-                g1j_dbl(t2, t1);
-                g1j_add_affine(t3, t2, base);
-                g1j_dbl(t4, t2);
+                G1J28 t1, t2, t3, t4, tq;
+                g1j28_from_affine(t1, base);          // bases are points of G1 (validated / VK constants): every
+                g1j28_dbl_ool(t2, t1);                // multiple below r is finite and the sums below are generic
+                (void)g1j28_add_ool(t3, t2, t1);
+                g1j28_dbl_ool(t4, t2);
                 tab[0] = t1; tab[1] = t2; tab[2] = t3; tab[3] = t4;
-                g1j_add_affine(tq, t4, base); tab[4] = tq;
-                g1j_dbl(tq, t3); tab[5] = tq;
-                g1j_add_affine(tq, tq, base); tab[6] = tq;
-                g1j_dbl(tq, t4); tab[7] = tq;
+                (void)g1j28_add_ool(tq, t4, t1); tab[4] = tq;
+                g1j28_dbl_ool(tq, t3); tab[5] = tq;
+                (void)g1j28_add_ool(tq, tq, t1); tab[6] = tq;
+                g1j28_dbl_ool(tq, t4); tab[7] = tq;
             }
-            // `lad` is only ever touched by inlined code, so it is promoted to VGPRs; `acc` is handed by reference to the
-            // out-of-line reduction below and therefore lives in private memory (keeping the ladder on `acc` cost
-            // ~6 GB of scratch traffic per launch).
-            G1J lad;
-            g1j_set_inf(lad);
+            // The ladder runs on the lazily reduced 28-bit field (h2v_fp28.cuh / h2v_curve28.cuh) and is only ever
+            // touched by inlined code, so `lad` stays in VGPRs; the result is brought back to canonical limbs for the
+            // reduction tree below.
+            G1J28 lad;
+            bool lad_inf = true;
 #pragma unroll 1
             for (int q = 32; q >= 0; q--) {
-                if (q != 32) {
+                if (q != 32 && !lad_inf) {
 #pragma unroll 1
-                    for (int rep = 0; rep < 4; rep++) g1j_dbl_inl(lad, lad);
+                    for (int rep = 0; rep < 4; rep++) g1j28_dbl(lad, lad);
                 }
                 const int d = dg[q];
-                if (d != 0) g1j_add_signed_inl(lad, lad, tab[(d < 0 ? -d : d) - 1], d < 0);
+                if (d != 0) g1j28_acc_add(lad, lad_inf, tab[(d < 0 ? -d : d) - 1], d < 0);
             }
-            acc = lad;
+            g1j28_to_g1j(acc, lad, lad_inf);
         }
     }
     // segmented reduction over the 2*tp lanes of each proof
