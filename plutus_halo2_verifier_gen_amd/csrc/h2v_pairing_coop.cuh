@@ -20,6 +20,7 @@
 #include "coop_program.h"
 #include "coop_tables.h"
 #include "h2v_curve.cuh"
+#include "h2v_fp28.cuh"
 #include "h2v_plan.h"
 #include "h2v_tower.cuh"
 
@@ -51,14 +52,17 @@ H2V_DI uint32_t *coop_slot(const Coop &c, int s) {
     const int off = s < COOP_SHARED_BASE ? c.grp_off + s * COOP_SLOT_DW : COOP_SHR_OFF + (s - COOP_SHARED_BASE) * COOP_SLOT_DW;
     return coop_lds + off;
 }
-H2V_DI void coop_store28(uint32_t *p, const Fp &a) {
-    uint32_t l[14];
-    fp_to28(l, a);
+H2V_DI void coop_store28(uint32_t *p, const F28 &a) {   // a must be carried (limbs < 2^28)
     uint4 *q = reinterpret_cast<uint4 *>(p);
-    q[0] = make_uint4(l[0], l[1], l[2], l[3]);
-    q[1] = make_uint4(l[4], l[5], l[6], l[7]);
-    q[2] = make_uint4(l[8], l[9], l[10], l[11]);
-    q[3] = make_uint4(l[12], l[13], 0u, 0u);
+    q[0] = make_uint4(a.l[0], a.l[1], a.l[2], a.l[3]);
+    q[1] = make_uint4(a.l[4], a.l[5], a.l[6], a.l[7]);
+    q[2] = make_uint4(a.l[8], a.l[9], a.l[10], a.l[11]);
+    q[3] = make_uint4(a.l[12], a.l[13], 0u, 0u);
+}
+H2V_DI void coop_store28(uint32_t *p, const Fp &a) {
+    F28 t;
+    f28_from_fp(t, a);
+    coop_store28(p, t);
 }
 H2V_DI void coop_load28(uint32_t (&l)[14], const uint32_t *p) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
@@ -67,11 +71,21 @@ H2V_DI void coop_load28(uint32_t (&l)[14], const uint32_t *p) {
     l[8] = c.x; l[9] = c.y; l[10] = c.z; l[11] = c.w; l[12] = d.x; l[13] = d.y;
 }
 
+// Values between engine calls are lazily reduced F28 elements (h2v_fp28.cuh).  Bounds, in that header's (v, lam)
+// notation:  every Fp12 variable has lam = 1 and v <= 6 (engine outputs 2, conj 3..6, frob 5, inverse 1; the
+// generated program is checked for this by tools/gen_coop_program.py).  Operand slots must hold carried limbs: a
+// MUL column sums 12 terms x 14 products, which fills the 64-bit accumulator at lam = 1.  Staged operands:
+//   A = a (6)   NA = 7p - a_im (7)   B = b (6)   XB = (b0 - b1 + 7p, b0 + b1) (13)   D = 2a (12)   ND = 13p - 2 a_im (13)
+// so the engine's result is below (12 * 7 * 13 / 2520 + 1) p < 2p for MUL and (3 * 6 * 7 * 13 / 2520 + 1) p < 2p for
+// the tripled cyclotomic squaring (p / R < 1/2520).
+
 // out = sum_t X[tab[2t]] * Y[tab[2t+1]]  (mod p), one Montgomery reduction.  NT <= 12 (accumulator headroom).
-template <int NT>
-H2V_DN Fp coop_accumulate(const Coop c, const int tab_row_byte) {
+// TRIPLE: the column accumulators are multiplied by 3 before the reduction (6 terms * 3 still fits 64 bits).
+template <int NT, bool TRIPLE>
+H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
     const uint8_t *tab = reinterpret_cast<const uint8_t *>(coop_lds + COOP_TAB_OFF) + tab_row_byte;
     static_assert(NT <= 12, "column accumulators hold at most 12 unreduced products");
+    static_assert(!TRIPLE || NT <= 6, "tripling needs a factor 3 of headroom");
     uint64_t acc[28];
 #pragma unroll
     for (int i = 0; i < 28; i++) acc[i] = 0;
@@ -91,6 +105,7 @@ H2V_DN Fp coop_accumulate(const Coop c, const int tab_row_byte) {
     for (int i = 0; i < 28; i++) {
         const uint32_t lo = __shfl_xor((uint32_t)acc[i], 16), hi = __shfl_xor((uint32_t)(acc[i] >> 32), 16);
         acc[i] += (uint64_t)lo | ((uint64_t)hi << 32);
+        if (TRIPLE) acc[i] += acc[i] << 1;
     }
     // Montgomery reduction of the 28-column accumulator (operand scanning), R = 2^392
 #pragma unroll
@@ -100,109 +115,111 @@ H2V_DN Fp coop_accumulate(const Coop c, const int tab_row_byte) {
         for (int j = 0; j < 14; j++) acc[k + j] += (uint64_t)m * FP_MOD28[j];
         acc[k + 1] += acc[k] >> 28;
     }
-    uint32_t t28[14], w[12];
+    F28 r;
     uint64_t carry = 0;
 #pragma unroll
     for (int k = 0; k < 13; k++) {
         carry += acc[14 + k];
-        t28[k] = (uint32_t)carry & FP28_MASK;
+        r.l[k] = (uint32_t)carry & FP28_MASK;
         carry >>= 28;
     }
     carry += acc[27];
-    t28[13] = (uint32_t)carry;
-    fp_from28(w, t28);
-    Fp r;
-    FpF::cond_sub(r, w, 0);
-    return r;
+    r.l[13] = (uint32_t)carry;
+    return f28_pack(r);
+}
+template <int NT, bool TRIPLE>
+H2V_DI F28 coop_engine(const Coop &c, const int tab_row_byte) {
+    const F28Regs z = coop_accumulate<NT, TRIPLE>(c, tab_row_byte);
+    return f28_unpack(z.a, z.b, z.c, z.d);
 }
 
-H2V_DI Fp coop_shfl_xor1(const Fp &a) {
-    Fp r;
+H2V_DI F28 coop_shfl_xor1(const F28 &a) {
+    F28 r;
 #pragma unroll
-    for (int i = 0; i < 12; i++) r.v[i] = __shfl_xor(a.v[i], 1);
+    for (int i = 0; i < 14; i++) r.l[i] = __shfl_xor(a.l[i], 1);
     return r;
 }
-H2V_DI Fp coop_bcast(const Fp &a, int src_lane) {
-    Fp r;
-#pragma unroll
-    for (int i = 0; i < 12; i++) r.v[i] = __shfl(a.v[i], src_lane);
-    return r;
-}
-// stage a distributed value as the A operand (a_{k,part}, and -a_{k,1})
-H2V_DI void coop_stage_a(const Coop &c, const Fp &a) {
+// stage a distributed value (v <= 6) as the A operand (a_{k,part}, and -a_{k,1})
+H2V_DI void coop_stage_a(const Coop &c, const F28 &a) {
     if (c.g < 12 && c.h == 0) {
         coop_store28(coop_slot(c, COOP_SLOT_A + c.g), a);
         if (c.g & 1) {
-            Fp n;
-            fp_neg(n, a);
+            F28 n;
+            F28_NEG(n, a, 7, 1);
+            f28_carry(n);
             coop_store28(coop_slot(c, COOP_SLOT_NA + (c.g >> 1)), n);
         }
     }
 }
-// stage a distributed value as the B operand (b and xi*b)
-H2V_DI void coop_stage_b(const Coop &c, const Fp &b) {
-    const Fp pb = coop_shfl_xor1(b);
+// stage a distributed value (v <= 6) as the B operand (b and xi*b)
+H2V_DI void coop_stage_b(const Coop &c, const F28 &b) {
+    const F28 pb = coop_shfl_xor1(b);
     if (c.g < 12 && c.h == 1) {
         coop_store28(coop_slot(c, COOP_SLOT_B + c.g), b);
-        Fp xb;
-        if (c.g & 1) fp_add(xb, pb, b);   // (xi b)_1 = b0 + b1
-        else fp_sub(xb, b, pb);           // (xi b)_0 = b0 - b1
+        F28 xb, t;
+        F28_NEG(t, pb, 7, 1);                  // 7p - b1
+        if (c.g & 1) t = pb;                   // imaginary part: (xi b)_1 = b0 + b1 ; real part: (xi b)_0 = b0 - b1
+        f28_add(xb, b, t);
+        f28_carry(xb);
         coop_store28(coop_slot(c, COOP_SLOT_XB + c.g), xb);
     }
 }
 // c = a * b (all distributed)
-H2V_DI Fp coop_mul(const Coop &c, const Fp &a, const Fp &b) {
+H2V_DI F28 coop_mul(const Coop &c, const F28 &a, const F28 &b) {
     coop_stage_a(c, a);
     coop_stage_b(c, b);
     __syncthreads();
-    Fp r = coop_accumulate<COOP_N_MUL_TERMS>(c, COOP_TAB_MUL_B + c.g * 2 * COOP_N_MUL_TERMS);
+    const F28 r = coop_engine<COOP_N_MUL_TERMS, false>(c, COOP_TAB_MUL_B + c.g * 2 * COOP_N_MUL_TERMS);
     __syncthreads();
     return r;
 }
 // a^2 for a in the cyclotomic subgroup (Granger-Scott; formulas and table: tools/gen_coop_tables.py: csqr_table).
-// Operands: A = a, NA = -a_im (half 0 lanes), D = 2a and ND = -2 a_im (half 1 lanes); the engine returns the core Q_k
-// and the lane finishes with 3 Q_k -/+ 2 a_k (minus for even k).
-H2V_DI Fp coop_csqr(const Coop &c, const Fp &a) {
+// Operands: A = a, NA = -a_im (half 0 lanes), D = 2a and ND = -2 a_im (half 1 lanes), and the shared constants
+// +-2/3: the engine returns 3 (Q_k -/+ (2/3) a_k) = 3 Q_k -/+ 2 a_k already reduced.
+H2V_DI F28 coop_csqr(const Coop &c, const F28 &a) {
     coop_stage_a(c, a);
-    Fp d2;
-    fp_dbl(d2, a);
     if (c.g < 12 && c.h == 1) {
+        F28 d2, n;
+        f28_mul_small<2>(d2, a);               // (12, 2)
+        F28_NEG(n, d2, 13, 2);                 // (13, 4)
+        f28_carry(d2);
         coop_store28(coop_slot(c, COOP_SLOT_D + c.g), d2);
         if (c.g & 1) {
-            Fp n;
-            fp_neg(n, d2);
+            f28_carry(n);
             coop_store28(coop_slot(c, COOP_SLOT_ND + (c.g >> 1)), n);
         }
     }
     __syncthreads();
-    const Fp q = coop_accumulate<COOP_N_CSQR_TERMS>(c, COOP_TAB_CSQR_B + c.g * 2 * COOP_N_CSQR_TERMS);
+    const F28 r = coop_engine<COOP_N_CSQR_TERMS, true>(c, COOP_TAB_CSQR_B + c.g * 2 * COOP_N_CSQR_TERMS);
     __syncthreads();
-    Fp t, r;
-    fp_dbl(t, q);
-    fp_add(t, t, q);
-    if ((c.g >> 1) & 1) fp_add(r, t, d2);
-    else fp_sub(r, t, d2);
     return r;
 }
-H2V_DI Fp coop_conj(const Coop &c, const Fp &a) {  // w -> -w: odd powers change sign
-    Fp r = a;
-    if (c.g < 12 && ((c.g >> 1) & 1)) fp_neg(r, a);
+H2V_DI F28 coop_conj(const Coop &c, const F28 &a) {  // w -> -w: odd powers change sign.  a: v <= 5
+    F28 r = a;
+    if (c.g < 12 && ((c.g >> 1) & 1)) {
+        F28_NEG(r, a, 6, 1);
+        f28_carry(r);
+    }
     return r;
 }
-// a -> a^p: coefficient k becomes conj(a_k) * gamma^k
-H2V_DI Fp coop_frob(const Coop &c, const Fp &a) {
-    const Fp pa = coop_shfl_xor1(a);
-    Fp r = a;
+// a -> a^p: coefficient k becomes conj(a_k) * gamma^k.  Result v <= 5.
+H2V_DI F28 coop_frob(const Coop &c, const F28 &a) {
+    const F28 pa = coop_shfl_xor1(a);
+    F28 r = a;
     if (c.g < 12) {
         const int k = c.g >> 1;
-        Fp g0, g1, x, y;
+        Fp g0, g1;
 #pragma unroll
         for (int i = 0; i < 12; i++) { g0.v[i] = FROB_GAMMA[k][0][i]; g1.v[i] = FROB_GAMMA[k][1][i]; }
+        F28 h0, h1, x, y;
+        f28_from_fp(h0, g0);
+        f28_from_fp(h1, g1);
         if (c.g & 1) {   // imaginary part: a_k0*g1 - a_k1*g0
-            fp_mul(x, pa, g1); fp_mul(y, a, g0); fp_sub(r, x, y);
+            f28_mul(x, pa, h1); f28_mul(y, a, h0); F28_SUB(r, x, y, 3, 1);
         } else {         // real part: a_k0*g0 + a_k1*g1
-            fp_mul(x, a, g0); fp_mul(y, pa, g1); fp_add(r, x, y);
+            f28_mul(x, a, h0); f28_mul(y, pa, h1); f28_add(r, x, y);
         }
+        f28_carry(r);
     }
     return r;
 }
@@ -217,18 +234,22 @@ H2V_DI void coop_stage_line(const Coop &c, int shared_slot, const uint32_t *line
 // f <- f * line (loop 1: el against s_g2's lines; loop 2: -er against G2's lines).  The spare lanes' products go
 // to the OTHER loop's T slots (they belong to that loop's next line).
 template <int LOOP>
-H2V_DI Fp coop_line(const Coop &c, const Fp &f) {
+H2V_DI F28 coop_line(const Coop &c, const F28 &f) {
     coop_stage_a(c, f);
     __syncthreads();
-    Fp r = coop_accumulate<COOP_N_LINE_TERMS>(c, (LOOP == 1 ? COOP_TAB_LINE1_B : COOP_TAB_LINE2_B) + c.g * 2 * COOP_N_LINE_TERMS);
+    const F28 r = coop_engine<COOP_N_LINE_TERMS, false>(c, (LOOP == 1 ? COOP_TAB_LINE1_B : COOP_TAB_LINE2_B) + c.g * 2 * COOP_N_LINE_TERMS);
     __syncthreads();
     if (c.g >= 12 && c.h == 0) coop_store28(coop_slot(c, (LOOP == 1 ? COOP_SLOT_T2 : COOP_SLOT_T1) + (c.g - 12)), r);
     return r;
 }
-// 1/f for a distributed f: N = f * conj(f) lies in Fp6 (even powers of w); lane 0 inverts it with the tower code.
-H2V_DN Fp coop_inv(const Coop c, const Fp f, bool &ok) {
-    const Fp fc = coop_conj(c, f);
-    const Fp nrm = coop_mul(c, f, fc);
+// 1/f for a distributed f: N = f * conj(f) lies in Fp6 (even powers of w); lane 0 inverts it with the tower code
+// on canonical limbs.
+H2V_DN F28Regs coop_inv_raw(const Coop c, const F28Regs fr, bool &ok) {
+    const F28 f = f28_unpack(fr.a, fr.b, fr.c, fr.d);
+    const F28 fc = coop_conj(c, f);
+    const F28 nrm28 = coop_mul(c, f, fc);
+    Fp nrm;
+    f28_to_fp(nrm, nrm28);
     // gather the even coefficients on lane 0 through the (now free) A slots, raw 12 x 32 limbs
     if (c.g < 12 && c.h == 0) {
         uint32_t *p = coop_slot(c, COOP_SLOT_A + c.g);
@@ -264,7 +285,13 @@ H2V_DN Fp coop_inv(const Coop c, const Fp f, bool &ok) {
     }
     __syncthreads();
     ok = good;
-    return coop_mul(c, fc, ninv);
+    F28 ninv28;
+    f28_from_fp(ninv28, ninv);
+    return f28_pack(coop_mul(c, fc, ninv28));
+}
+H2V_DI F28 coop_inv(const Coop &c, const F28 &f, bool &ok) {
+    const F28Regs z = coop_inv_raw(c, f28_pack(f), ok);
+    return f28_unpack(z.a, z.b, z.c, z.d);
 }
 
 // dbg (optional): per proof 2 x 12 Fp (canonical, 12 dwords each): f after the Miller loop, f after the final
@@ -333,26 +360,30 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
     const bool skip1 = (flags & 1) != 0, skip2 = (flags & 2) != 0;
     bool inv_ok = true;
 
-    Fp vars[COOP_N_VARS];
+    if (lane < 14) {   // the two shared constants of the cyclotomic squaring
+        coop_lds[COOP_SHR_OFF + (COOP_SLOT_C23P - COOP_SHARED_BASE) * COOP_SLOT_DW + lane] = FP_C23P28[lane];
+        coop_lds[COOP_SHR_OFF + (COOP_SLOT_C23N - COOP_SHARED_BASE) * COOP_SLOT_DW + lane] = FP_C23N28[lane];
+    }
+    F28 vars[COOP_N_VARS];
     for (int pc = 0; pc < COOP_PROGRAM_LEN; pc++) {
         const uint32_t ins = COOP_PROGRAM[pc];
         const int op = ins & 0xff, d = (ins >> 8) & 0xff, a = (ins >> 16) & 0xff, b = ins >> 24;
         if (op == COOP_OP_END) break;
         switch (op) {
         case COOP_OP_MUL: {
-            const Fp x = vars[a], y = vars[b];
+            const F28 x = vars[a], y = vars[b];
             vars[d] = coop_mul(c, x, y);
         } break;
         case COOP_OP_CSQR: {
-            const Fp x = vars[a];
+            const F28 x = vars[a];
             vars[d] = coop_csqr(c, x);
         } break;
         case COOP_OP_LINE: {
             // d = loop, a = line index.  Invariants (see coop_tables.h / gen_coop_tables.py): before LINE1(n) the
             // shared slots hold LN1(n) and T1(n); LINE1's spare lanes produce T2(n) from LN2(n); LINE2's spare lanes
             // produce T1(n+1) from LN1(n+1).
-            const Fp f = vars[COOP_VAR_F];
-            Fp r;
+            const F28 f = vars[COOP_VAR_F];
+            F28 r;
             if (d == 1) {
                 if (a > 0) coop_stage_line(c, COOP_SLOT_LN2, plan.lines28_g2, a, lane);
                 __syncthreads();
@@ -380,15 +411,16 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
         } break;
         case COOP_OP_MOV: vars[d] = vars[a]; break;
         case COOP_OP_SETONE: {
-            Fp o;
-            fp_set_zero(o);
-            if (c.g == 0) fp_set_one(o);
+            F28 o;
+            f28_set_zero(o);
+            if (c.g == 0) f28_set_one(o);
             vars[d] = o;
         } break;
         case COOP_OP_DUMP: {
             if (dbg && live && c.g < 12 && c.h == 0) {
-                Fp o;
-                fp_from_mont(o, vars[a]);
+                Fp o, oc;
+                f28_to_fp(oc, vars[a]);
+                fp_from_mont(o, oc);
 #pragma unroll
                 for (int k = 0; k < 12; k++) dbg[((size_t)i * 24 + 12 * d + c.g) * 12 + k] = o.v[k];
             }
@@ -397,7 +429,8 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
         }
     }
     // == 1 ?
-    const Fp res = vars[COOP_VAR_F];
+    Fp res;
+    f28_to_fp(res, vars[COOP_VAR_F]);
     bool mine = true;
     if (c.g == 0) { Fp one; fp_set_one(one); mine = fp_eq(res, one); }
     else if (c.g < 12) mine = fp_is_zero(res);

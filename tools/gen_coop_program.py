@@ -36,12 +36,13 @@ def build_program():
             e(OP_LINE, 2, line)
             line += 1
     assert line == 68
-    e(OP_CONJ, F, F)          # x < 0
-    e(OP_DUMP, 0, F)
-    # easy part
+    # x < 0: the Miller value is m = conj(F).  Easy part m^(p^6-1) = conj(m) * m^-1 = F * conj(F^-1); written so that
+    # every CONJ / INV operand is an engine output (the lazily reduced field bounds of h2v_pairing_coop.cuh).
+    e(OP_CONJ, U, F)
+    e(OP_DUMP, 0, U)
     e(OP_INV, A, F)
-    e(OP_CONJ, T, F)
-    e(OP_MUL, T, T, A)        # f^(p^6-1)
+    e(OP_CONJ, A, A)
+    e(OP_MUL, T, F, A)        # m^(p^6-1)
     e(OP_FROB, A, T)
     e(OP_FROB, A, A)
     e(OP_MUL, T, A, T)        # ^(p^2+1)
@@ -66,6 +67,43 @@ def build_program():
     e(OP_MOV, F, T3)          # result is read from F
     e(OP_END)
     return prog
+
+
+def check_bounds(prog):
+    """Static check of the value bounds the kernel's lazily reduced field relies on (h2v_pairing_coop.cuh): with
+    `v` = the multiple of p a variable may reach, engine results are 2, CONJ needs v <= 5 and gives 6, FROB gives 5,
+    and every staged operand needs v <= 6."""
+    v = [None] * N_VARS
+    for op, d, a, b in prog:
+        if op == OP_END:
+            break
+        if op == OP_SETONE:
+            v[d] = 1
+        elif op == OP_MUL:
+            assert v[a] <= 6 and v[b] <= 6
+            v[d] = 2
+        elif op == OP_CSQR:
+            assert v[a] <= 6
+            v[d] = 2
+        elif op == OP_LINE:
+            assert v[F] <= 6
+            v[F] = 2
+        elif op == OP_CONJ:
+            assert v[a] <= 5, "CONJ of a value that is not an engine / FROB result"
+            v[d] = 6
+        elif op == OP_FROB:
+            assert v[a] <= 6
+            v[d] = 5
+        elif op == OP_INV:
+            assert v[a] <= 5
+            v[d] = 2
+        elif op == OP_MOV:
+            v[d] = v[a]
+        elif op == OP_WARMUP:
+            assert v[F] <= 6
+        elif op == OP_DUMP:
+            assert v[a] <= 1024
+    return True
 
 
 def simulate(prog, p1, q1, p2, q2):
@@ -103,6 +141,7 @@ def simulate(prog, p1, q1, p2, q2):
 
 def self_check():
     prog = build_program()
+    assert check_bounds(prog)
     rng = random.Random(3)
     s = rng.randrange(2, bls.R)
     q1 = bls.g2_mul(bls.G2_GEN, s)

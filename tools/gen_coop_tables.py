@@ -34,7 +34,10 @@ N_GROUP_SLOTS = 56
 SH = 64           # shared slots: per line 8 constants  [nl0, nl1, nxl0, nxl1, c0, c1, xc0, xc1]
 SLOT_LN1 = SH + 0
 SLOT_LN2 = SH + 8
-N_SHARED_SLOTS = 16
+SLOT_C23P = SH + 16   # +2/3 and -2/3 (wave-shared constants of the cyclotomic squaring)
+SLOT_C23N = SH + 17
+N_SHARED_SLOTS = 18
+C23 = 2 * pow(3, -1, P) % P
 LN_NL0, LN_NL1, LN_NXL0, LN_NXL1, LN_C0, LN_C1, LN_XC0, LN_XC1 = range(8)
 
 N_MUL_TERMS = 12
@@ -118,7 +121,9 @@ def csqr_table():
          h0 = 3(g0^2 + xi g3^2) - 2g0   h3 = 3(2 g0 g3) + 2g3
          h1 = 3 xi (2 g2 g5)    + 2g1   h4 = 3(g2^2 + xi g5^2) - 2g4
          h2 = 3(g1^2 + xi g4^2) - 2g2   h5 = 3(2 g1 g4) + 2g5
-    The engine computes the core Q_k; the lane finishes with h = 3 Q_k -/+ 2 g_k (minus for even k)."""
+    The engine computes Q'_k = Q_k -/+ (2/3) g_k (minus for even k; the 6th term of every lane, against the shared
+    constants +-2/3) with its column accumulators tripled before the Montgomery reduction, so h_k = 3 Q'_k leaves the
+    engine reduced and no additive post-processing is left to the lane."""
     A = lambda k, part: SLOT_A + 2 * k + part
     NA = lambda k: SLOT_NA + k
     D = lambda k, part: SLOT_D + 2 * k + part
@@ -145,7 +150,9 @@ def csqr_table():
                     terms = [(A(a, 0), D(b, 0)), (NA(a), D(b, 1)), (A(a, 0), ND(b)), (NA(a), D(b, 0))]
                 else:
                     terms = [(A(a, 0), D(b, 0)), (NA(a), D(b, 1)), (A(a, 0), D(b, 1)), (A(a, 1), D(b, 0))]
-        assert len(terms) <= N_CSQR_TERMS
+        if g < 12:
+            assert len(terms) <= N_CSQR_TERMS - 1
+            terms.append((A(g >> 1, g & 1), SLOT_C23N if (g >> 1) % 2 == 0 else SLOT_C23P))
         while len(terms) < N_CSQR_TERMS:
             terms.append((SLOT_ZERO, SLOT_ZERO))
         tab.append(terms)
@@ -153,7 +160,7 @@ def csqr_table():
 
 
 def stage_csqr(g):
-    s = {SLOT_ZERO: 0}
+    s = {SLOT_ZERO: 0, SLOT_C23P: C23, SLOT_C23N: (-C23) % P}
     for k in range(6):
         s[SLOT_A + 2 * k], s[SLOT_A + 2 * k + 1] = g[k]
         s[SLOT_NA + k] = (-g[k][1]) % P
@@ -166,8 +173,7 @@ def finish_csqr(q, g):
     out = []
     for lane in range(12):
         k, part = lane >> 1, lane & 1
-        own = g[k][part]
-        out.append((3 * q[lane] + (-2 if k % 2 == 0 else 2) * own) % P)
+        out.append(3 * q[lane] % P)
     return out
 
 
@@ -255,7 +261,7 @@ def emit():
          "#pragma once", "#include <stdint.h>"]
     for name in ("SLOT_A", "SLOT_NA", "SLOT_B", "SLOT_XB", "SLOT_T1", "SLOT_T2", "SLOT_PX1", "SLOT_PY1", "SLOT_PX2",
                  "SLOT_PY2", "SLOT_ZERO", "N_GROUP_SLOTS", "SLOT_LN1", "SLOT_LN2", "N_SHARED_SLOTS", "N_MUL_TERMS",
-                 "N_LINE_TERMS", "N_CSQR_TERMS", "SLOT_D", "SLOT_ND"):
+                 "N_LINE_TERMS", "N_CSQR_TERMS", "SLOT_D", "SLOT_ND", "SLOT_C23P", "SLOT_C23N"):
         o.append("#define COOP_%s %d" % (name, globals()[name]))
     o.append("#define COOP_SHARED_BASE %d" % SH)
 
