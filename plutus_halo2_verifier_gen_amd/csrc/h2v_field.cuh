@@ -392,67 +392,24 @@ H2V_DI void big_shl1(uint32_t (&a)[N]) {
     for (int i = N - 1; i > 0; i--) a[i] = (a[i] << 1) | (a[i - 1] >> 31);
     a[0] <<= 1;
 }
-// returns k and x = abar^-1 * 2^k mod m (plain integers); abar != 0, abar < m, m odd with `bits` bits.
-// Kaliski's four cases    u even: u/=2, s*=2 | v even: v/=2, r*=2 | u>v: u=(u-v)/2, r+=s, s*=2 | else: v=(v-u)/2, s+=r, r*=2
-// are ONE body after a conditional swap of (u,r) with (v,s):   [if both odd: U -= V, R += S] ; U /= 2 ; S *= 2.
-// Branch-free (masks), so the compiler keeps the four numbers in registers (a four-way branchy version spilled
-// ~185 words per iteration and dominated the pairing kernel's wait time).
-template <class PR>
-H2V_DI int kaliski_phase1(uint32_t (&x)[PR::N], const uint32_t (&abar)[PR::N]) {
-    constexpr int N = PR::N;
-    uint32_t u[N], v[N], rr[N], s[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) { u[i] = PR::mod(i); v[i] = abar[i]; rr[i] = 0; s[i] = 0; }
-    s[0] = 1;
-    int k = 0;
-#pragma unroll 1
-    while (!big_is_zero<N>(v)) {
-        const bool ue = !(u[0] & 1), ve = !(v[0] & 1);
-        const bool gt = big_gt<N>(u, v);
-        const uint32_t swap = (!ue && (ve || !gt)) ? 0xffffffffu : 0u;
-        const uint32_t sub = (!ue && !ve) ? 0xffffffffu : 0u;
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            const uint32_t t = (u[i] ^ v[i]) & swap; u[i] ^= t; v[i] ^= t;
-            const uint32_t w = (rr[i] ^ s[i]) & swap; rr[i] ^= w; s[i] ^= w;
-        }
-        uint32_t br = 0, bo, c = 0, co;
-#pragma unroll
-        for (int i = 0; i < N; i++) { u[i] = __builtin_subc(u[i], v[i] & sub, br, &bo); br = bo; }
-#pragma unroll
-        for (int i = 0; i < N; i++) { rr[i] = __builtin_addc(rr[i], s[i] & sub, c, &co); c = co; }
-        big_shr1<N>(u);
-        big_shl1<N>(s);
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            const uint32_t t = (u[i] ^ v[i]) & swap; u[i] ^= t; v[i] ^= t;
-            const uint32_t w = (rr[i] ^ s[i]) & swap; rr[i] ^= w; s[i] ^= w;
-        }
-        k++;
-    }
-    uint32_t m[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) m[i] = PR::mod(i);
-    if (!big_gt<N>(m, rr)) big_sub<N>(rr, rr, m);  // rr >= m
-    big_sub<N>(x, m, rr);
-    return k;
-}
-// returns false when a == 0
+#include "h2v_modinv.cuh"
+// Inversion: batched division steps (h2v_modinv.cuh).  The operand is a Montgomery residue aR; its integer
+// inverse is a^-1 R^-1, and one Montgomery product with R^3 returns a^-1 R.  Returns false when a == 0.
 H2V_DN bool fp_inv(Fp &r, const Fp &a) {
     if (fp_is_zero(a)) { fp_set_zero(r); return false; }
     Fp x, c;
-    const int k = kaliski_phase1<FpParams>(x.v, a.v);
+    ModInv30<13>::inverse<12>(x.v, a.v, FP_MOD30, FP_MINV30);
 #pragma unroll
-    for (int i = 0; i < 12; i++) c.v[i] = FP_INV_POW2[k - 381][i];
+    for (int i = 0; i < 12; i++) c.v[i] = FP_R3[i];
     fp_mul(r, x, c);
     return true;
 }
 H2V_DN bool fr_inv(Fr &r, const Fr &a) {
     if (FrF::is_zero(a)) { FrF::set_zero(r); return false; }
     Fr x, c;
-    const int k = kaliski_phase1<FrParams>(x.v, a.v);
+    ModInv30<9>::inverse<8>(x.v, a.v, FR_MOD30, FR_MINV30);
 #pragma unroll
-    for (int i = 0; i < 8; i++) c.v[i] = FR_INV_POW2[k - 255][i];
+    for (int i = 0; i < 8; i++) c.v[i] = FR_R3[i];
     fr_mul(r, x, c);
     return true;
 }

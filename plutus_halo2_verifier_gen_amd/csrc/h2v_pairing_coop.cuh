@@ -86,12 +86,23 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
     const uint8_t *tab = reinterpret_cast<const uint8_t *>(coop_lds + COOP_TAB_OFF) + tab_row_byte;
     static_assert(NT <= 12, "column accumulators hold at most 12 unreduced products");
     static_assert(!TRIPLE || NT <= 6, "tripling needs a factor 3 of headroom");
-    uint64_t acc[28];
-#pragma unroll
-    for (int i = 0; i < 28; i++) acc[i] = 0;
     static_assert((NT & 1) == 0, "terms are split over two lanes");
+    uint64_t acc[28];
+    {   // first term initialises the columns (no zero-fill of 56 registers)
+        uint32_t x[14], y[14];
+        coop_load28(x, coop_slot(c, tab[2 * c.h]));
+        coop_load28(y, coop_slot(c, tab[2 * c.h + 1]));
+#pragma unroll
+        for (int i = 0; i < 14; i++)
+#pragma unroll
+            for (int j = 0; j < 14; j++) {
+                if (i == 0 || j == 13) acc[i + j] = (uint64_t)x[i] * y[j];
+                else acc[i + j] += (uint64_t)x[i] * y[j];
+            }
+        acc[27] = 0;
+    }
 #pragma unroll 1
-    for (int t = c.h; t < NT; t += 2) {
+    for (int t = c.h + 2; t < NT; t += 2) {
         uint32_t x[14], y[14];
         coop_load28(x, coop_slot(c, tab[2 * t]));
         coop_load28(y, coop_slot(c, tab[2 * t + 1]));
@@ -100,12 +111,24 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
 #pragma unroll
             for (int j = 0; j < 14; j++) acc[i + j] += (uint64_t)x[i] * y[j];
     }
-    // add the partner lane's half of the sum (lane ^ 16), still unreduced
+    // add the partner lane's half of the sum (lane ^ 16), still unreduced.  v_permlane16_swap exchanges the odd
+    // 16-lane rows of its first operand with the even rows of its second: called on two copies of a register, one
+    // copy ends up holding (own | partner) and the other (partner | own) by row, so their sum is own + partner in
+    // every lane - a VALU-rate exchange (ds_bpermute cost 56 LDS round trips per call).
 #pragma unroll
     for (int i = 0; i < 28; i++) {
-        const uint32_t lo = __shfl_xor((uint32_t)acc[i], 16), hi = __shfl_xor((uint32_t)(acc[i] >> 32), 16);
-        acc[i] += (uint64_t)lo | ((uint64_t)hi << 32);
-        if (TRIPLE) acc[i] += acc[i] << 1;
+        const uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
+        const auto sl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto sh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        uint32_t cy;
+        const uint32_t slo = __builtin_addc(sl[0], sl[1], 0u, &cy);
+        const uint32_t shi = sh[0] + sh[1] + cy;
+        acc[i] = (uint64_t)slo | ((uint64_t)shi << 32);
+        if (TRIPLE) {   // x3 as one shift-add (the compiler's choice was two v_mad_u64_u32 per column)
+            uint64_t t3;
+            asm("v_lshl_add_u64 %0, %1, 1, %1" : "=v"(t3) : "v"(acc[i]));
+            acc[i] = t3;
+        }
     }
     // Montgomery reduction of the 28-column accumulator (operand scanning), R = 2^392
 #pragma unroll

@@ -212,3 +212,104 @@ def test_sharded_verify_two_ranks_gloo(tmp_path):
                          capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "GLOO_OK" in res.stdout
+
+
+def test_safegcd_model():
+    """Integer model of csrc/h2v_modinv.cuh (30 division steps per batch on the low words, transition matrix applied
+    to (f, g) and, modulo M with exact division by 2^30, to (d, e)) with the constants the device header carries:
+    every intermediate stays inside the 64-bit / 32-bit ranges the kernel code assumes, the loop ends within the
+    kernel's batch limit and the result is the modular inverse."""
+    import re
+    from plutus_halo2_verifier_gen_amd import bls12_381 as bls
+    hdr = open(os.path.join(ROOT, "plutus_halo2_verifier_gen_amd", "csrc", "bls_consts.h")).read()
+
+    def arr(name):
+        return [int(x.rstrip("u"), 16) for x in re.search(name + r"\[\d+\] = \{([^}]*)\}", hdr).group(1).split(", ")]
+
+    def const(name):
+        return int(re.search(name + r" = (0x[0-9a-f]+)u", hdr).group(1), 16)
+
+    M30 = (1 << 30) - 1
+
+    def s32(x):
+        x &= 0xFFFFFFFF
+        return x - (1 << 32) if x >> 31 else x
+
+    def divsteps(zeta, f, g):
+        u, v, q, r = 1, 0, 0, 1
+        for _ in range(30):
+            c1 = -1 if zeta < 0 else 0
+            c2 = -(g & 1)
+            x = ((f ^ (c1 & 0xFFFFFFFF)) - c1) & 0xFFFFFFFF
+            y, z = (u ^ c1) - c1, (v ^ c1) - c1
+            g = (g + (x & (c2 & 0xFFFFFFFF))) & 0xFFFFFFFF
+            q += y & c2
+            r += z & c2
+            c1 &= c2
+            zeta = (zeta ^ c1) - 1
+            f = (f + (g & (c1 & 0xFFFFFFFF))) & 0xFFFFFFFF
+            u += q & c1
+            v += r & c1
+            g >>= 1
+            u <<= 1
+            v <<= 1
+            assert all(-(1 << 30) <= t <= (1 << 30) for t in (u, v, q, r))
+        return zeta, (u, v, q, r)
+
+    def inverse(x, mod30, minv30):
+        L = len(mod30)
+        f, g = list(mod30), [(x >> (30 * i)) & M30 for i in range(L)]
+        d, e = [0] * L, [1] + [0] * (L - 1)
+        zeta = -1
+        for n in range(48):
+            zeta, (u, v, q, r) = divsteps(zeta, (f[0] | (f[1] << 30)) & 0xFFFFFFFF, (g[0] | (g[1] << 30)) & 0xFFFFFFFF)
+            sd, se = (-1 if d[-1] < 0 else 0), (-1 if e[-1] < 0 else 0)
+            md, me = (u & sd) + (v & se), (q & sd) + (r & se)
+            cd, ce = u * d[0] + v * e[0], q * d[0] + r * e[0]
+            md -= (minv30 * (cd & 0xFFFFFFFF) + md) & M30
+            me -= (minv30 * (ce & 0xFFFFFFFF) + me) & M30
+            assert -(1 << 31) <= md < (1 << 31) and -(1 << 31) <= me < (1 << 31)
+            cd += mod30[0] * md
+            ce += mod30[0] * me
+            assert cd & M30 == 0 and ce & M30 == 0
+            cd >>= 30
+            ce >>= 30
+            cf, cg = u * f[0] + v * g[0], q * f[0] + r * g[0]
+            assert cf & M30 == 0 and cg & M30 == 0
+            cf >>= 30
+            cg >>= 30
+            for i in range(1, L):
+                cd += u * d[i] + v * e[i] + mod30[i] * md
+                ce += q * d[i] + r * e[i] + mod30[i] * me
+                cf += u * f[i] + v * g[i]
+                cg += q * f[i] + r * g[i]
+                assert all(-(1 << 63) <= t < (1 << 63) for t in (cd, ce, cf, cg))
+                d[i - 1], e[i - 1], f[i - 1], g[i - 1] = cd & M30, ce & M30, cf & M30, cg & M30
+                cd >>= 30
+                ce >>= 30
+                cf >>= 30
+                cg >>= 30
+            assert all(-(1 << 31) <= t < (1 << 31) for t in (cd, ce, cf, cg))
+            d[-1], e[-1], f[-1], g[-1] = cd, ce, cf, cg
+            if not any(g):
+                break
+        else:
+            raise AssertionError("no convergence within the kernel's batch limit")
+        fv = sum(t << (30 * i) for i, t in enumerate(f))
+        dv = sum(t << (30 * i) for i, t in enumerate(d))
+        m = sum(t << (30 * i) for i, t in enumerate(mod30))
+        assert fv in (1, -1) and -2 * m < dv < m
+        return dv * fv % m, n + 1
+
+    rng = random.Random(8)
+    for mod, name, L in ((bls.P, "FP", 13), (bls.R, "FR", 9)):
+        mod30, minv30 = arr(name + "_MOD30"), const(name + "_MINV30")
+        assert len(mod30) == L and sum(t << (30 * i) for i, t in enumerate(mod30)) == mod
+        assert minv30 * mod % (1 << 30) == 1
+        worst = 0
+        for x in [1, 2, 3, mod - 1, mod - 2, (mod - 1) // 2, 1 << (mod.bit_length() - 1)] + [rng.randrange(1, mod) for _ in range(150)]:
+            inv, batches = inverse(x, mod30, minv30)
+            assert inv * x % mod == 1
+            worst = max(worst, batches)
+        assert worst <= 32
+    assert arr("FP_R3") == [(pow(2, 3 * bls.MONT_BITS_FP, bls.P) >> (32 * i)) & 0xFFFFFFFF for i in range(12)]
