@@ -162,7 +162,7 @@ def main():
                     "algorithmic_bytes_per_launch": bytes_per_launch[k] // launches}
 
         # analytical multiply-add counts per launch (lane-level v_mad_u64_u32), see DESIGN.md section 6
-        msm_lane = 4 * MAD_DBL + 3 * MAD_MADD + 128 * MAD_DBL + 31 * MAD_ADD + MAD_MUL      # table + 32 windows + phi
+        msm_lane = 4 * MAD_DBL + 3 * MAD_ADD + 128 * MAD_DBL + 31 * MAD_ADD + 4 * MAD_MUL  # table, 32 windows, phi, 3 conversions
         mads = {
             "g1_msm": B * T * 2 * msm_lane + B * (2 * T - 1) * MAD_ADD,
             "pairing": B * 32 * (98 * (6 * 196 + 196) + (315 + 136) * (3 * 196 + 196)),     # coop program: MUL / CSQR+LINE
