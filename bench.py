@@ -153,11 +153,28 @@ def main():
         kname = {"g1_msm": "k_g1_msm", "g1_decompress": "k_g1_decompress", "transcript_combiner": "k_transcript_combiner",
                  "pairing": "k_pairing_coop" if os.environ.get("H2V_PAIRING") != "legacy" else "k_pairing_check"}
 
+        def pmc_traffic(kernel):
+            """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB on gfx950) from the newest committed PMC summary
+            (tools/pmc_summary.py over separate rocprofv3 --pmc passes of this same command); None when absent."""
+            import glob
+            files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_summary.txt")))
+            if not files:
+                return None, None
+            vals = {}
+            for line in open(files[-1]):
+                f = line.split()
+                if len(f) >= 4 and f[0] == kernel and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    vals[f[1]] = float(f[3])
+            if len(vals) != 2:
+                return None, None
+            return int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.basename(files[-1])
+
         def roof(k):
             # one launch handles B / launches proofs; average launch duration = per-step sum / launches
             gbps = bytes_per_launch[k] / (kernel_ms[k] * 1e-3) / 1e9 if kernel_ms[k] > 0 else 0.0
+            traffic, src = pmc_traffic(kname[k])
             return {"kernel": kname[k], "bound": "hbm", "achieved": round(gbps, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(gbps / HBM_PEAK_GBPS, 6), "traffic": None,
+                    "frac": round(gbps / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": src,
                     "avg_launch_ms": round(kernel_ms[k] / launches, 4), "launches_per_step": launches,
                     "algorithmic_bytes_per_launch": bytes_per_launch[k] // launches}
 
