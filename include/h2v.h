@@ -39,6 +39,7 @@ extern "C" {
 #define H2V_ST_SHORT_PROOF 4u      /* fewer bytes than the plan's proof layout */
 #define H2V_ST_BAD_POINT 8u        /* a G1 encoding is malformed / off-curve / not in the subgroup */
 #define H2V_ST_PAIRING 16u         /* e(pi, s_g2) != e(er, G2) */
+#define H2V_ST_RECURSION 32u       /* IVC: the verifying-key hash in the public inputs is not this key's (aiken.rs:696) */
 
 typedef struct h2v_plan h2v_plan;           /* replaces VerifyingKey<F,CS> + ParamsVerifierKZG for this path */
 typedef struct h2v_workspace h2v_workspace; /* reusable device scratch for batches of up to max_batch proofs */

@@ -17,7 +17,9 @@ LIB_PATH = os.path.join(HERE, "_build", "libh2v_oracle.so")
 
 R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 ORC_MAX_EXPR = 256
-STATUS = {0: "accept", 1: "pairing", 2: "point", 3: "scalar", 4: "short", 5: "inverse"}
+# compressed -G1 (aiken-verifier/templates/vk_constants.hbs:18)
+NEG_G1_COMPRESSED = bytes.fromhex("b7f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb")
+STATUS = {0: "accept", 1: "pairing", 2: "point", 3: "scalar", 4: "short", 5: "inverse", 6: "recursion"}
 
 
 def build(force: bool = False) -> str:
@@ -134,6 +136,12 @@ def vk_desc(vk: dict, omega: int, omega_inv: int, barycentric_weight: int) -> by
             out += bytes.fromhex(h)
     out += bytes.fromhex(vk["s_g2"])
     out += struct.pack("<II", vk["n_public_inputs"], vk["n_committed_instances"])
+    if vk.get("recursion_vks") is not None:
+        # fixed bases of the accumulator in the emitter's order (emitters/aiken.rs:659-694): -G1, f.., p.., inner keys
+        bases = [NEG_G1_COMPRESSED] + [bytes.fromhex(h) for h in vk["fixed_commitments"] + vk["permutation_commitments"]]
+        for inner in vk["recursion_vks"]:
+            bases += [bytes.fromhex(h) for h in inner["fixed_commitments"] + inner["permutation_commitments"]]
+        out += struct.pack("<II", 1, len(bases)) + b"".join(bases)
     return bytes(out)
 
 

@@ -120,6 +120,10 @@ struct orc_vk {
     g1a *fixed_comm, *perm_comm;
     g2prep s_g2, g2gen;
     uint32_t n_pi, n_ci;
+    /* recursion (IVC): fixed bases of the accumulator, emitters/aiken.rs:659-694; has_rec = 0 for plain circuits */
+    int has_rec;
+    uint32_t n_rec_bases;
+    g1a *rec_bases;
     /* derived */
     uint32_t chunk_len, n_chunks, n_splits;
     int n_queries; query *queries;
@@ -279,6 +283,15 @@ orc_vk *orc_vk_parse(const uint8_t *desc, size_t len) {
     }
     vk->n_pi = rd_u32(&r); vk->n_ci = rd_u32(&r);
     if (r.err || vk->n_ci > 1 || vk->degree < 3) goto fail;
+    if (r.pos < r.len) { /* optional recursion section */
+        vk->has_rec = (int)rd_u32(&r);
+        vk->n_rec_bases = rd_u32(&r);
+        if (r.err || vk->has_rec > 1 || vk->n_rec_bases > 4096) goto fail;
+        vk->rec_bases = (g1a *)calloc(vk->n_rec_bases + 1, sizeof(g1a));
+        for (uint32_t i = 0; i < vk->n_rec_bases; i++) { b = rd_bytes(&r, 48); if (!b || !g1_decompress(&vk->rec_bases[i], b)) goto fail; }
+        /* not enough public inputs to support recursion: aiken.rs:702 (nb_vks + F + 10; nb_vks >= 1) */
+        if (vk->has_rec && vk->n_pi < 1 + vk->n_rec_bases + 10) goto fail;
+    }
     if (vk->n_perm_comm != vk->n_perm_cols) goto fail;
     /* every expression index must exist */
     for (int i = 0; i < vk->pool.cnt; i++) {
@@ -318,7 +331,7 @@ void orc_vk_free(orc_vk *vk) {
     free(vk->lk_in); free(vk->lk_tab); free(vk->lk_nin); free(vk->lk_ntab);
     for (uint32_t i = 0; i < vk->n_trash; i++) if (vk->tr_exprs) free(vk->tr_exprs[i]);
     free(vk->tr_sel); free(vk->tr_exprs); free(vk->tr_n);
-    free(vk->perm_cols); free(vk->fixed_comm); free(vk->perm_comm);
+    free(vk->perm_cols); free(vk->fixed_comm); free(vk->perm_comm); free(vk->rec_bases);
     free(vk->queries); free(vk->cd); free(vk->sets); free(vk->sort_order);
     free(vk);
 }
@@ -732,6 +745,51 @@ int orc_verify(const orc_vk *vk, const uint8_t *proof, size_t proof_len, const u
         g1_scale_add(&acc, pi_pt, &x3);
         g1j_add(&acc, &final_com, &acc);
         g1j_to_affine(&er, &acc);
+    }
+    /* Recursion (IVC): fold the collapsed accumulator carried by the public inputs into (el, er) before the pairing
+     * (RECURSION_ACCUMULATOR block, verification_h2.hbs:123; emitters/aiken.rs:696-757; docs/algorithms.html "IVC") */
+    if (vk->has_rec) {
+        const uint32_t N = vk->n_pi, F = vk->n_rec_bases;
+#define PI1(k) (&pi[(k) - 1]) /* the emitter's i_k are 1-based */
+        if (!fr_eq(PI1(1), &vk->transcript_repr)) REJECT(ORC_REJ_RECURSION);       /* expect transcript_rep == i_1 */
+        fp two224;
+        { uint64_t t[6] = {0, 0, 0, 1ull << 32, 0, 0}; fp_from_plain(&two224, t); } /* batching_coeff = (2^56)^4 */
+        g1a acc_pt[2];
+        for (int side = 0; side < 2; side++) {
+            /* left: x from i_{N-F-8}, i_{N-F-9}; y from i_{N-F-6}, i_{N-F-7}.  right: x i_{N-F-3}, i_{N-F-4}; y i_{N-F-1}, i_{N-F-2} */
+            const uint32_t xh = side == 0 ? N - F - 8 : N - F - 3, yh = side == 0 ? N - F - 6 : N - F - 1;
+            fp cx, cy, one_p;
+            fp_one(&one_p);
+            for (int c = 0; c < 2; c++) {
+                uint64_t hi[6] = {0}, lo[6] = {0};
+                fr_to_plain(hi, PI1(c == 0 ? xh : yh));
+                fr_to_plain(lo, PI1((c == 0 ? xh : yh) - 1));
+                fp h, l, v;
+                fp_from_plain(&h, hi); fp_from_plain(&l, lo);
+                fp_mul(&v, &h, &two224); fp_add(&v, &v, &l); fp_add(&v, &v, &one_p); /* (1 + hi*B + lo) mod p */
+                if (c == 0) cx = v; else cy = v;
+            }
+            /* g1_from_coords (bls_utils.ak:32-49): compressed x with the parity flag of y, then decompress */
+            uint8_t raw[48];
+            fp_to_be48(raw, &cx);
+            raw[0] |= fp_is_lex_larger(&cy) ? 0xa0 : 0x80;
+            if (!g1_decompress(&acc_pt[side], raw)) REJECT(ORC_REJ_POINT);
+        }
+        g1j accl, accr, t;
+        g1a accl_a, accr_a;
+        g1j_from_affine(&t, &acc_pt[0]); g1j_mul_fr(&accl, &t, PI1(N - F - 5));   /* scaleG1(acc_left_unscaled, i_{N-F-5}) */
+        g1j_from_affine(&t, &acc_pt[1]); g1j_mul_fr(&accr, &t, PI1(N - F));       /* scaleG1(acc_right_unscaled, i_{N-F}) */
+        for (uint32_t k = 0; k < F; k++) g1_scale_add(&accr, &vk->rec_bases[k], PI1(N - F + 1 + k));  /* + acc_fixed */
+        g1j_to_affine(&accl_a, &accl); g1j_to_affine(&accr_a, &accr);
+        uint8_t msg[192], dig[32];
+        g1_compress(msg, &el); g1_compress(msg + 48, &er); g1_compress(msg + 96, &accl_a); g1_compress(msg + 144, &accr_a);
+        blake2b256(dig, msg, 192);
+        fr ch;
+        (void)fr_from_le32(&ch, dig);                                            /* from_int(le_int(digest) % field_prime) */
+        g1j e1, e2;
+        g1j_from_affine(&e1, &el); g1_scale_add(&e1, &accl_a, &ch); g1j_to_affine(&el, &e1);
+        g1j_from_affine(&e2, &er); g1_scale_add(&e2, &accr_a, &ch); g1j_to_affine(&er, &e2);
+#undef PI1
     }
     /* P7 pairing: accept <=> e(el, s_g2) == e(er, G2) (verification_h2.hbs:125-128) */
     status = pairing_check_eq(&el, &vk->s_g2, &er, &vk->g2gen) ? ORC_ACCEPT : ORC_REJ_PAIRING;

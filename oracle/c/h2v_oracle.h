@@ -18,7 +18,7 @@ typedef struct orc_vk orc_vk;
 
 #define ORC_MAX_EXPR 256
 /* reject reasons (status) */
-enum { ORC_ACCEPT = 0, ORC_REJ_PAIRING = 1, ORC_REJ_POINT = 2, ORC_REJ_SCALAR = 3, ORC_REJ_SHORT = 4, ORC_REJ_INVERSE = 5 };
+enum { ORC_ACCEPT = 0, ORC_REJ_PAIRING = 1, ORC_REJ_POINT = 2, ORC_REJ_SCALAR = 3, ORC_REJ_SHORT = 4, ORC_REJ_INVERSE = 5, ORC_REJ_RECURSION = 6 };
 
 /* The reference's own intermediate-value surface (plutus_debug TRACES, src/plutus_gen/emitters/plinth.rs:792-831)
  * plus the multi-open scalars.  Scalars 32 B little-endian canonical; points affine x||y big-endian, all-zero

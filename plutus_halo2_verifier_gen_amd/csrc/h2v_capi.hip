@@ -36,6 +36,7 @@ struct h2v_plan {
     int device = 0;
     H2vDevPlan d{};            // device view
     void *blob = nullptr;      // one device allocation holding every section
+    void *fold_terms = nullptr;  // recursion: the 4-entry term table of the two fold MSMs
     uint32_t n_squeezes = 0, stream_len = 0;
     std::vector<uint32_t> trace_slots;
 };
@@ -45,6 +46,8 @@ struct h2v_workspace {
     uint64_t cap = 0;       // max batch
     uint32_t stride = 0;    // register-file stride (cap rounded up to 64)
     uint32_t *regs = nullptr, *scalars = nullptr, *pts = nullptr, *er = nullptr, *status = nullptr, *trace = nullptr, *msm_tab = nullptr;
+    // recursion (IVC): acc_left / acc_right_final sums, the fold's points + scalars, and the folded el / er
+    uint32_t *accl = nullptr, *accr = nullptr, *fold_pts = nullptr, *fold_scal = nullptr, *el2 = nullptr, *er2 = nullptr;
     uint8_t *valid = nullptr, *accept = nullptr;
     // staging for the host-buffer entry point
     uint8_t *in_proofs = nullptr, *in_inst = nullptr, *in_ci = nullptr;
@@ -96,7 +99,14 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
     if (n_instr == 0 || n_instr > (1u << 20) || n_regs == 0 || n_regs > 65535 || n_points == 0 || n_points > 4096 ||
         n_terms == 0 || n_ci > 1 || n_pi > (1u << 16) || proof_len > (1u << 24))
         return fail(H2V_E_PLAN, "implausible counts");
-    if (n_terms > 64) return fail(H2V_E_LIMIT, "more than 64 MSM terms per proof is not supported by this backend");
+    const uint32_t ivc = w[H2V_HW_IVC], n_main = w[H2V_HW_N_MAIN_TERMS];
+    if (ivc > 1 || n_main == 0 || n_main > n_terms || (!ivc && n_main != n_terms) || (ivc && n_terms < n_main + 2))
+        return fail(H2V_E_PLAN, "inconsistent recursion header");
+    if (n_main > 64 || (ivc && n_terms - n_main - 1 > 64))
+        return fail(H2V_E_LIMIT, "more than 64 MSM terms per sum is not supported by this backend");
+    if (ivc)
+        for (int k = 0; k < 8; k++)
+            if (w[H2V_HW_ACC_IDX0 + k] >= n_pi) return fail(H2V_E_PLAN, "accumulator public-input index out of range");
     if (w[H2V_HW_PI_POINT] >= n_points) return fail(H2V_E_PLAN, "pi point index out of range");
     // validate the program: every register / constant / offset the kernels will touch is in range
     const uint8_t *ip = blob + w[H2V_HW_OFF_INSTR];
@@ -119,6 +129,7 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
         case H2V_OP_ADD: case H2V_OP_SUB: case H2V_OP_MUL: ok = dst < n_regs && a < n_regs && b < n_regs; break;
         case H2V_OP_NEG: case H2V_OP_INV: ok = dst < n_regs && a < n_regs; break;
         case H2V_OP_OUT_SCALAR: ok = dst < n_terms && a < n_regs; break;
+        case H2V_OP_ASSERT_ZERO: ok = a < n_regs; break;
         default: ok = false;
         }
         if (!ok) return fail(H2V_E_PLAN, "instruction " + std::to_string(k) + " out of range");
@@ -132,7 +143,7 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
     for (uint32_t k = 0; k < n_terms; k++) {
         const uint32_t kind = rd32(tp + 8 * k), idx = rd32(tp + 8 * k + 4);
         const bool ok = (kind == H2V_TERM_PROOF_POINT && idx < n_points) || (kind == H2V_TERM_VK_BASE && idx < n_bases) ||
-                        (kind == H2V_TERM_COMMITTED_INSTANCE && n_ci == 1);
+                        (kind == H2V_TERM_COMMITTED_INSTANCE && n_ci == 1) || (kind == H2V_TERM_ACC_POINT && ivc && idx < 2);
         if (!ok) return fail(H2V_E_PLAN, "MSM term out of range");
     }
     const uint8_t *trp = blob + w[H2V_HW_OFF_TRACE];
@@ -155,9 +166,21 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
             const uint32_t kind = H2V_TERM_PROOF_POINT, idx = n_points;
             memcpy(t, &kind, 4);
             memcpy(t + 4, &idx, 4);
+        } else if (rd32(t) == H2V_TERM_ACC_POINT) {   // the decompression kernel rebuilds the accumulator points there
+            const uint32_t kind = H2V_TERM_PROOF_POINT, idx = n_points + n_ci + rd32(t + 4);
+            memcpy(t, &kind, 4);
+            memcpy(t + 4, &idx, 4);
         }
     }
-    if (hipMemcpy(p->blob, patched.data(), len, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p->blob); delete p; return fail(H2V_E_DEVICE, "plan upload failed"); }
+    if (ivc) {
+        const uint32_t ft[8] = {H2V_TERM_PROOF_POINT, 0, H2V_TERM_PROOF_POINT, 1, H2V_TERM_PROOF_POINT, 2, H2V_TERM_PROOF_POINT, 3};
+        if (hipMalloc(&p->fold_terms, sizeof ft) != hipSuccess || hipMemcpy(p->fold_terms, ft, sizeof ft, hipMemcpyHostToDevice) != hipSuccess) {
+            if (p->fold_terms) (void)hipFree(p->fold_terms);
+            (void)hipFree(p->blob); delete p;
+            return fail(H2V_E_DEVICE, "fold term upload failed");
+        }
+    }
+    if (hipMemcpy(p->blob, patched.data(), len, hipMemcpyHostToDevice) != hipSuccess) { if (p->fold_terms) (void)hipFree(p->fold_terms); (void)hipFree(p->blob); delete p; return fail(H2V_E_DEVICE, "plan upload failed"); }
     const uint8_t *base = (const uint8_t *)p->blob;
     H2vDevPlan &d = p->d;
     d.proof_len = proof_len; d.n_pi = n_pi; d.n_ci = n_ci; d.n_regs = n_regs; d.n_instr = n_instr; d.n_consts = n_consts;
@@ -172,6 +195,9 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
     d.trace = (const uint32_t *)(base + w[H2V_HW_OFF_TRACE]);
     d.lines28_sg2 = (const uint32_t *)(base + w[H2V_HW_OFF_LINES28_SG2]);
     d.lines28_g2 = (const uint32_t *)(base + w[H2V_HW_OFF_LINES28_G2]);
+    d.ivc = ivc; d.n_main_terms = n_main;
+    for (int k = 0; k < 8; k++) d.acc_idx[k] = w[H2V_HW_ACC_IDX0 + k];
+    d.fold_terms = (const uint32_t *)p->fold_terms;
     p->n_squeezes = n_sq;
     p->stream_len = w[H2V_HW_STREAM_LEN];
     for (uint32_t k = 0; k < n_trace; k++) p->trace_slots.push_back(rd32(trp + 8 * k));
@@ -182,6 +208,7 @@ extern "C" void h2v_plan_free(h2v_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->blob) (void)hipFree(p->blob);
+    if (p->fold_terms) (void)hipFree(p->fold_terms);
     delete p;
 }
 extern "C" int h2v_plan_info(const h2v_plan *p, uint32_t *proof_len, uint32_t *n_pi, uint32_t *n_ci, uint32_t *n_terms) {
@@ -202,7 +229,8 @@ extern "C" int h2v_plan_trace_slots(const h2v_plan *p, uint32_t *slot_ids, uint3
 // ---------------------------------------------------------------------------------------------- workspace
 static void ws_release(h2v_workspace *w) {
     (void)hipSetDevice(w->device);
-    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off, w->msm_tab};
+    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off, w->msm_tab,
+                    w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipStream_t q : w->pmain) if (q) (void)hipStreamDestroy(q);
     for (hipStream_t q : w->pside) if (q) (void)hipStreamDestroy(q);
@@ -218,7 +246,7 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     w->device = device;
     w->cap = max_batch;
     w->stride = (uint32_t)((max_batch + 63) / 64 * 64);
-    const uint64_t slots = d.n_points + d.n_ci;
+    const uint64_t slots = H2V_SLOTS(d);
 #define WSALLOC(field, bytes)                                                                  \
     if (hipMalloc((void **)&w->field, (bytes)) != hipSuccess) { ws_release(w); delete w; return fail(H2V_E_DEVICE, "hipMalloc(" #field ") failed"); }
     WSALLOC(regs, (size_t)d.n_regs * 8 * w->stride * 4)
@@ -230,6 +258,14 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     WSALLOC(status, (size_t)max_batch * 4)
     WSALLOC(accept, (size_t)max_batch)
     if (with_trace && d.n_trace) { WSALLOC(trace, (size_t)max_batch * d.n_trace * 32) }
+    if (d.ivc) {
+        WSALLOC(accl, (size_t)max_batch * 144)
+        WSALLOC(accr, (size_t)max_batch * 144)
+        WSALLOC(el2, (size_t)max_batch * 144)
+        WSALLOC(er2, (size_t)max_batch * 144)
+        WSALLOC(fold_pts, (size_t)max_batch * 4 * 96)
+        WSALLOC(fold_scal, (size_t)max_batch * 4 * 32)
+    }
 #undef WSALLOC
     bool ok = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < h2v_workspace::MAXP && ok; k++)
@@ -252,25 +288,46 @@ extern "C" void h2v_workspace_free(h2v_workspace *w) {
 }
 
 // MSM launch geometry: 2 lanes per (proof, term); block = max(64, 2*tp) threads, LDS 144 B per thread.
-static void launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, uint32_t *er, uint32_t *tabws, hipStream_t st) {
-    const uint32_t tp = next_pow2(d.n_terms);
+static void launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const uint32_t *scalars, const uint32_t *pts,
+                             uint32_t *out, uint32_t *tabws, hipStream_t st) {
+    const uint32_t tp = next_pow2(ma.n_terms);
     const uint32_t bs = 2 * tp < 64 ? 64 : 2 * tp;
     const uint32_t per_block = bs / (2 * tp);
     const uint32_t blocks = (n + per_block - 1) / per_block;
-    hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 144, st, d, n, tp, scalars, pts, er, tabws);
+    hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 144, st, d, ma, n, tp, scalars, pts, out, tabws);
+}
+// the proof's own MSM: terms [0, n_main_terms) of the plan's table, scalars from the combiner, points from decompression
+static void launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, uint32_t *er, uint32_t *tabws, hipStream_t st) {
+    const H2vMsmArgs ma = {d.terms, 0, d.n_main_terms, d.n_terms, 0, H2V_SLOTS(d)};
+    launch_msm_range(d, ma, n, scalars, pts, er, tabws, st);
+}
+// Recursion (IVC) fold between the MSM and the pairing (emitters/aiken.rs:696-757): acc_left, acc_right + fixed bases,
+// the batching challenge, then el' = el + c acc_left and er' = er + c acc_right_final.  Pointers are the chunk's.
+struct IvcBufs { uint32_t *accl, *accr, *fold_pts, *fold_scal, *el2, *er2; };
+static void launch_ivc_fold(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, const uint32_t *er,
+                            const IvcBufs &b, uint32_t *tabws, hipStream_t st) {
+    const uint32_t slots = H2V_SLOTS(d);
+    const H2vMsmArgs left = {d.terms, d.n_main_terms, 1, d.n_terms, d.n_main_terms, slots};
+    const H2vMsmArgs right = {d.terms, d.n_main_terms + 1, d.n_terms - d.n_main_terms - 1, d.n_terms, d.n_main_terms + 1, slots};
+    launch_msm_range(d, left, n, scalars, pts, b.accl, tabws, st);
+    launch_msm_range(d, right, n, scalars, pts, b.accr, tabws, st);
+    hipLaunchKernelGGL(k_ivc_challenge, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, er, b.accl, b.accr, b.fold_pts, b.fold_scal);
+    const H2vMsmArgs fl = {d.fold_terms, 0, 2, 4, 0, 4}, fr = {d.fold_terms, 2, 2, 4, 2, 4};
+    launch_msm_range(d, fl, n, b.fold_scal, b.fold_pts, b.el2, tabws, st);
+    launch_msm_range(d, fr, n, b.fold_scal, b.fold_pts, b.er2, tabws, st);
 }
 
 // Pairing kernel selection: the cooperative 16-lanes-per-proof kernel is the product path; the one-lane-per-proof
 // kernel stays as a cross-check (H2V_PAIRING=legacy, or impl = 0 in the probe).
 static void launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint32_t *er,
-                                uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st) {
-    if (impl == 0) hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, er, status, accept, dbg);
-    else hipLaunchKernelGGL(k_pairing_coop, dim3((n + 1) / 2), dim3(64), 0, st, d, n, pts, valid, er, status, accept, dbg);
+                                const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st) {
+    if (impl == 0) hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, er, el_jac, status, accept, dbg);
+    else hipLaunchKernelGGL(k_pairing_coop, dim3((n + 1) / 2), dim3(64), 0, st, d, n, pts, valid, er, el_jac, status, accept, dbg);
 }
 static void launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint32_t *er,
-                           uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st) {
+                           const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st) {
     static const int impl = []() { const char *e = getenv("H2V_PAIRING"); return (e && strcmp(e, "legacy") == 0) ? 0 : 1; }();
-    launch_pairing_impl(impl, d, n, pts, valid, er, status, accept, dbg, st);
+    launch_pairing_impl(impl, d, n, pts, valid, er, el_jac, status, accept, dbg, st);
 }
 
 // ---------------------------------------------------------------------------------------------- pipeline
@@ -280,7 +337,7 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
 static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst,
                         const uint8_t *ci, uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st,
                         h2v_timings *tm, bool want_trace) {
-    const uint32_t slots = d.n_points + d.n_ci;
+    const uint32_t slots = H2V_SLOTS(d);
     const uint32_t vm_blocks = (n + 63) / 64;
     const uint32_t dec_blocks = (n * slots + 63) / 64;
     (void)vm_blocks; (void)dec_blocks;
@@ -294,10 +351,14 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipGetLastError());                                                              \
         HIPCHK(hipDeviceSynchronize());                                                         \
         fprintf(stderr, "[h2v] %s done\n", name); fflush(stderr);
-        DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(128), 0, st, d, n, proofs, off, ci, w->pts, w->valid))
+        DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(128), 0, st, d, n, proofs, off, ci, inst, w->pts, w->valid))
         DBG_STAGE("k_transcript_combiner", hipLaunchKernelGGL(k_transcript_combiner, dim3(vm_blocks), dim3(64), 0, st, d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace))
         DBG_STAGE("k_g1_msm", launch_msm(d, n, w->scalars, w->pts, w->er, w->msm_tab, st))
-        DBG_STAGE("k_pairing_check", launch_pairing(d, n, w->pts, w->valid, w->er, status, accept, nullptr, st))
+        if (d.ivc) {
+            const IvcBufs ib = {w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2};
+            DBG_STAGE("ivc fold", launch_ivc_fold(d, n, w->scalars, w->pts, w->er, ib, w->msm_tab, st))
+        }
+        DBG_STAGE("k_pairing_check", launch_pairing(d, n, w->pts, w->valid, d.ivc ? w->er2 : w->er, d.ivc ? w->el2 : nullptr, status, accept, nullptr, st))
 #undef DBG_STAGE
         if (status_out) HIPCHK(hipMemcpyAsync(status_out, status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         return H2V_OK;
@@ -327,7 +388,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipStreamWaitEvent(ps, w->ev_fork, 0));
         // decompression (many short waves) runs beside the transcript+combiner kernel (few long waves)
         HIPCHK(hipEventRecord(ev[2], ps));
-        hipLaunchKernelGGL(k_g1_decompress, dim3((m * slots + 63) / 64), dim3(128), 0, ps, d, m, proofs, off_k, ci_k, pts_k, valid_k);
+        hipLaunchKernelGGL(k_g1_decompress, dim3((m * slots + 63) / 64), dim3(128), 0, ps, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k);
         HIPCHK(hipEventRecord(ev[3], ps));
         HIPCHK(hipEventRecord(w->ev_join[k], ps));
         HIPCHK(hipEventRecord(ev[0], pm));
@@ -335,9 +396,17 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipEventRecord(ev[1], pm));
         HIPCHK(hipStreamWaitEvent(pm, w->ev_join[k], 0));
         HIPCHK(hipEventRecord(ev[4], pm));
-        launch_msm(d, m, scal_k, pts_k, er_k, w->msm_tab + (size_t)lo * d.n_terms * 2 * 8 * 42, pm);
+        uint32_t *tab_k = w->msm_tab + (size_t)lo * d.n_terms * 2 * 8 * 42;
+        launch_msm(d, m, scal_k, pts_k, er_k, tab_k, pm);
+        const uint32_t *er_in = er_k, *el_in = nullptr;
+        if (d.ivc) {   // (timed with the MSM: it is three more sums of the same kernel plus the challenge hash)
+            const IvcBufs ib = {w->accl + (size_t)lo * 36, w->accr + (size_t)lo * 36, w->fold_pts + (size_t)lo * 96, w->fold_scal + (size_t)lo * 32,
+                                w->el2 + (size_t)lo * 36, w->er2 + (size_t)lo * 36};
+            launch_ivc_fold(d, m, scal_k, pts_k, er_k, ib, tab_k, pm);
+            er_in = ib.er2; el_in = ib.el2;
+        }
         HIPCHK(hipEventRecord(ev[5], pm));
-        launch_pairing(d, m, pts_k, valid_k, er_k, status_k, accept_k, nullptr, pm);
+        launch_pairing(d, m, pts_k, valid_k, er_in, el_in, status_k, accept_k, nullptr, pm);
         HIPCHK(hipEventRecord(ev[6], pm));
         HIPCHK(hipEventRecord(w->ev_done[k], pm));
         HIPCHK(hipStreamWaitEvent(st, w->ev_done[k], 0));
@@ -470,10 +539,10 @@ extern "C" int h2v_trace(const h2v_plan *p, const uint8_t *proof, size_t proof_l
     do {
         if (rc) break;
         if (hipMalloc((void **)&d_pts96, 192) != hipSuccess) { rc = fail(H2V_E_DEVICE, "hipMalloc failed"); break; }
-        const uint32_t slots = p->d.n_points + p->d.n_ci;
-        (void)slots;
-        hipLaunchKernelGGL(k_export_points, dim3(1), dim3(64), 0, nullptr, 1u, 0, ws->pts + (size_t)p->d.pi_point * 24, d_pts96);
-        hipLaunchKernelGGL(k_export_points, dim3(1), dim3(64), 0, nullptr, 1u, 1, ws->er, d_pts96 + 96);
+        // el / er as they enter the pairing: after the accumulator fold when the plan is recursive
+        if (p->d.ivc) hipLaunchKernelGGL(k_export_points, dim3(1), dim3(64), 0, nullptr, 1u, 1, ws->el2, d_pts96);
+        else hipLaunchKernelGGL(k_export_points, dim3(1), dim3(64), 0, nullptr, 1u, 0, ws->pts + (size_t)p->d.pi_point * 24, d_pts96);
+        hipLaunchKernelGGL(k_export_points, dim3(1), dim3(64), 0, nullptr, 1u, 1, p->d.ivc ? ws->er2 : ws->er, d_pts96 + 96);
         if (hipDeviceSynchronize() != hipSuccess) { rc = fail(H2V_E_DEVICE, "trace kernels failed"); break; }
         uint8_t both[192];
         if (hipMemcpy(both, d_pts96, 192, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(H2V_E_DEVICE, "download failed"); break; }
@@ -542,7 +611,7 @@ struct MiniPlan {
         if (points.alloc(slots * 4) || terms.alloc(terms_h.size() * 4)) return -1;
         if (hipMemcpy(points.p, pts.data(), slots * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
         if (hipMemcpy(terms.p, terms_h.data(), terms_h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
-        d.proof_len = 48 * slots; d.n_points = slots; d.n_terms = n_terms; d.pi_point = 0;
+        d.proof_len = 48 * slots; d.n_points = slots; d.n_terms = n_terms; d.n_main_terms = n_terms; d.pi_point = 0;
         d.points = points.as<uint32_t>(); d.terms = terms.as<uint32_t>();
         d.lines_sg2 = lines_sg2; d.lines_g2 = lines_g2;
         return 0;
@@ -563,7 +632,7 @@ extern "C" int h2v_probe_g1_decompress(int device, uint32_t n, const uint8_t *co
     if (mp.build(1, 0, nullptr, nullptr) || upload_offsets(doff, n, 48) || din.alloc((size_t)n * 48) || dpts.alloc((size_t)n * 96) ||
         dvalid.alloc(n) || dout.alloc((size_t)n * 96)) return fail(H2V_E_DEVICE, "probe setup failed");
     HIPCHK(hipMemcpy(din.p, compressed, (size_t)n * 48, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_g1_decompress, dim3((n + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
     hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 0, dpts.as<uint32_t>(), dout.as<uint8_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
@@ -582,7 +651,7 @@ extern "C" int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_
         return fail(H2V_E_DEVICE, "probe setup failed");
     HIPCHK(hipMemcpy(din.p, bases_compressed, (size_t)n * T * 48, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dsc.p, scalars, (size_t)n * T * 32, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
     if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 168)) return fail(H2V_E_DEVICE, "hipMalloc failed");
     launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), dtab.as<uint32_t>(), nullptr);
     hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 1, der.as<uint32_t>(), dout.as<uint8_t>());
@@ -616,11 +685,11 @@ extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t
     HIPCHK(hipMemcpy(din.p, in.data(), in.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dsc.p, one.data(), one.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dst.p, 0, (size_t)n * 4));
-    hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
     if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 168)) return fail(H2V_E_DEVICE, "hipMalloc failed");
     launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), dtab.as<uint32_t>(), nullptr);
     if (ddbg.alloc(dbg ? (size_t)n * 24 * 48 : 8)) return fail(H2V_E_DEVICE, "hipMalloc failed");
-    launch_pairing_impl(impl, mp.d, n, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), der.as<uint32_t>(), dst.as<uint32_t>(), dacc.as<uint8_t>(), dbg ? ddbg.as<uint32_t>() : nullptr, nullptr);
+    launch_pairing_impl(impl, mp.d, n, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), der.as<uint32_t>(), nullptr, dst.as<uint32_t>(), dacc.as<uint8_t>(), dbg ? ddbg.as<uint32_t>() : nullptr, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, dacc.p, n, hipMemcpyDeviceToHost));

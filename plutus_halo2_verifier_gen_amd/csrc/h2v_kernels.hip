@@ -246,6 +246,10 @@ k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_
             if (!fr_inv(r, a)) st |= H2V_ST_INVERSE_OF_ZERO;
             if (live) reg_store(regs, ins.dst, stride, i, r);
         } break;
+        case H2V_OP_ASSERT_ZERO: {
+            reg_load(a, regs, ins.a, stride, ii);
+            if (!FrF::is_zero(a)) st |= H2V_ST_RECURSION;   // expect transcript_rep == i_1 (emitters/aiken.rs:696)
+        } break;
         case H2V_OP_OUT_SCALAR: {
             reg_load(a, regs, ins.a, stride, ii);
             FrF::from_mont(r, a);
@@ -284,12 +288,40 @@ k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_
 //           involve b, and the isomorphism commutes with sigma (X -> beta X), so the test on E' is the test on E for
 //           either root y; when c is a non-residue wave 0 rejects and this result is ignored.  c == 0 means y == 0,
 //           a 2-torsion point: rejected.
+// Recursion (IVC) adds two slots per proof whose x and sign(y) are rebuilt from public inputs
+// (g1_from_coords, aiken_halo2/lib/bls_utils.ak:32-49; limb packing emitters/aiken.rs:705-741):
+//     coordinate = (1 + i_hi * 2^224 + i_lo) mod p ,  point = decompress(x with the parity flag of y).
 #define H2V_DEC_PTS 64
+H2V_DN void acc_coordinate(Fp &r, const uint8_t *ins, uint32_t idx_hi, uint32_t idx_lo) {
+    Fp part[2];
+#pragma unroll 1
+    for (int q = 0; q < 2; q++) {
+        const uint8_t *p = ins + (size_t)(q == 0 ? idx_hi : idx_lo) * 32;
+        Fr b, m;
+#pragma unroll
+        for (int l = 0; l < 8; l++)
+            b.v[l] = (uint32_t)p[4 * l] | ((uint32_t)p[4 * l + 1] << 8) | ((uint32_t)p[4 * l + 2] << 16) | ((uint32_t)p[4 * l + 3] << 24);
+        FrF::to_mont(m, b);       // public inputs are field elements: reduced mod r exactly as LOAD_INSTANCE does
+        FrF::from_mont(b, m);
+        Fp plain;
+#pragma unroll
+        for (int l = 0; l < 12; l++) plain.v[l] = l < 8 ? b.v[l] : 0u;
+        fp_to_mont(part[q], plain);
+    }
+    Fp c, one;
+#pragma unroll
+    for (int l = 0; l < 12; l++) c.v[l] = FP_TWO224[l];
+    fp_set_one(one);
+    fp_mul(r, part[0], c);
+    fp_add(r, r, part[1]);
+    fp_add(r, r, one);
+}
 extern "C" __global__ void __launch_bounds__(128, 2)
 k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
-                const uint8_t *__restrict__ committed, uint32_t *__restrict__ pts, uint8_t *__restrict__ valid) {
+                const uint8_t *__restrict__ committed, const uint8_t *__restrict__ instances,
+                uint32_t *__restrict__ pts, uint8_t *__restrict__ valid) {
     __shared__ uint8_t sub_ok[H2V_DEC_PTS];
-    const uint32_t slots = plan.n_points + plan.n_ci;
+    const uint32_t slots = H2V_SLOTS(plan);
     const uint32_t role = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t gid = blockIdx.x * H2V_DEC_PTS + lane;
@@ -298,17 +330,28 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
     const uint32_t i = gg / slots, j = gg - i * slots;
     bool ok = live;
     const uint8_t *src = nullptr;
+    const bool is_acc = j >= plan.n_points + plan.n_ci;
     if (j < plan.n_points) {
         const uint64_t off0 = proof_off[i];
         if (proof_off[i + 1] - off0 < plan.proof_len) ok = false;  // short proof: nothing to read
         else src = proofs + off0 + plan.points[j];
-    } else {
+    } else if (!is_acc) {
         src = committed + (size_t)i * 48;
     }
     uint32_t w[12];  // big-endian bytes -> little-endian limbs
 #pragma unroll
     for (int k = 0; k < 12; k++) w[k] = 0;
-    if (ok) {
+    Fp acc_x;
+    fp_set_zero(acc_x);
+    if (is_acc) {
+        // accumulator point: x (already a field element) and the parity of y; never the infinity encoding
+        const uint32_t s4 = 4 * (j - plan.n_points - plan.n_ci);
+        const uint8_t *ins = instances + (size_t)i * plan.n_pi * 32;
+        Fp cy;
+        acc_coordinate(acc_x, ins, plan.acc_idx[s4 + 0], plan.acc_idx[s4 + 1]);
+        acc_coordinate(cy, ins, plan.acc_idx[s4 + 2], plan.acc_idx[s4 + 3]);
+        w[11] = (4u | (fp_is_lex_larger(cy) ? 1u : 0u)) << 29;   // flags only; the limbs below stay unused
+    } else if (ok) {
 #pragma unroll
         for (int k = 0; k < 12; k++) {
             const uint8_t *p = src + 44 - 4 * k;
@@ -328,7 +371,7 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
         for (int k = 0; k < 12; k++) any |= w[k];
         ok = any == 0;
     } else if (ok) {
-        ok = !FpF::geq_mod(w);
+        ok = is_acc || !FpF::geq_mod(w);
         finite = ok;
     }
     if (finite) {
@@ -336,6 +379,7 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
 #pragma unroll
         for (int k = 0; k < 12; k++) { t.v[k] = w[k]; b4.v[k] = FP_B[k]; }
         fp_to_mont(x, t);
+        if (is_acc) x = acc_x;
         fp_sqr(c, x); fp_mul(c, c, x); fp_add(c, c, b4);
         if (role == 0) {
             Fp y, chk;
@@ -381,9 +425,20 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
 //     4 doublings + one table addition (digits in [-8, 8]);
 //   * a segmented tree reduction of the 2*TP partial sums of each proof through LDS (TP = 2^ceil(log2 T)).
 // Bytes per term: 32 (scalar) + 96 (affine base) in, 144 per proof out (Jacobian).
+// One launch sums a RANGE of a term table (the proof's own MSM; with recursion also acc_left, acc_right + fixed bases,
+// and the two folds el + c*acc_left, er + c*acc_right over the fold's own point / scalar buffers):
+struct H2vMsmArgs {
+    const uint32_t *terms;     // (kind, index) pairs; kind = VK base or per-proof slot of `pts`
+    uint32_t term_base;        // first term of the range
+    uint32_t n_terms;          // terms in the range (<= tp)
+    uint32_t scal_stride;      // scalars per proof in `scalars`
+    uint32_t scal_col_base;    // column of the range's first term
+    uint32_t slots;            // point slots per proof in `pts`
+};
 extern "C" __global__ void __launch_bounds__(128, 2)
-k_g1_msm(H2vDevPlan plan, uint32_t n, uint32_t tp /* pow2 >= n_terms, <= 64 */, const uint32_t *__restrict__ scalars,
-         const uint32_t *__restrict__ pts, uint32_t *__restrict__ out, uint32_t *__restrict__ tabws) {
+k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t tp /* pow2 >= ma.n_terms, <= 64 */,
+         const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ out,
+         uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];  // Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t]
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
     const uint32_t lanes_per_proof = 2 * tp;
@@ -391,15 +446,15 @@ k_g1_msm(H2vDevPlan plan, uint32_t n, uint32_t tp /* pow2 >= n_terms, <= 64 */, 
     const uint32_t sub = tid % lanes_per_proof;       // position inside the proof's segment
     const uint32_t term = sub >> 1, half = sub & 1;
     const uint32_t i = blockIdx.x * per_block + tid / lanes_per_proof;
-    const bool active = i < n && term < plan.n_terms;
+    const bool active = i < n && term < ma.n_terms;
     G1J acc;
     g1j_set_inf(acc);
     if (active) {
         // terms[] as uploaded by h2v_plan_load: kind is VK base (1) or per-proof slot (0); the committed instance has
         // been rewritten to slot n_points there.  Two-way integer selects only: a nested three-way pointer select was
         // miscompiled by ROCm 7.2 (the copy of i feeding the scalar address was left undefined on the third path).
-        const uint32_t kind = plan.terms[2 * term], idx = plan.terms[2 * term + 1];
-        const uint32_t slots = plan.n_points + plan.n_ci;
+        const uint32_t kind = ma.terms[2 * (ma.term_base + term)], idx = ma.terms[2 * (ma.term_base + term) + 1];
+        const uint32_t slots = ma.slots;
         const bool is_vk = kind == H2V_TERM_VK_BASE;
         const uint32_t *src = is_vk ? plan.vk_bases : pts;
         const size_t elem = is_vk ? (size_t)idx : (size_t)i * slots + idx;
@@ -408,7 +463,7 @@ k_g1_msm(H2vDevPlan plan, uint32_t n, uint32_t tp /* pow2 >= n_terms, <= 64 */, 
 #pragma unroll
         for (int k = 0; k < 12; k++) { base.x.v[k] = bp[k]; base.y.v[k] = bp[12 + k]; }
         uint32_t s[8], k1[4], k2[4], kk[4];
-        const uint32_t *sp = scalars + ((size_t)i * plan.n_terms + term) * 8;
+        const uint32_t *sp = scalars + ((size_t)i * ma.scal_stride + ma.scal_col_base + term) * 8;
 #pragma unroll
         for (int k = 0; k < 8; k++) s[k] = sp[k];
         glv_split(k1, k2, s);
@@ -434,7 +489,7 @@ k_g1_msm(H2vDevPlan plan, uint32_t n, uint32_t tp /* pow2 >= n_terms, <= 64 */, 
             // table[m-1] = m*P, m = 1..8, in a per-lane slab of the workspace: [lane][entry][36 dwords], so that the
             // digit-indexed read of one entry is 144 contiguous bytes.  (A private-memory table is dword-interleaved
             // across lanes: with per-lane digits every 4-byte read pulled its own sector, 2.4 GB fetched per launch.)
-            G1J28 *tab = reinterpret_cast<G1J28 *>(tabws + (((size_t)i * plan.n_terms + term) * 2 + half) * (8 * 42));
+            G1J28 *tab = reinterpret_cast<G1J28 *>(tabws + (((size_t)i * ma.n_terms + term) * 2 + half) * (8 * 42));
             {
                 G1J28 t1, t2, t3, t4, tq;
                 g1j28_from_affine(t1, base);          // bases are points of G1 (validated / VK constants): every
@@ -564,11 +619,11 @@ H2V_DN bool final_exp_is_one(const Fp12 &f) {
 
 extern "C" __global__ void __launch_bounds__(64)
 k_pairing_check(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid,
-                const uint32_t *__restrict__ er_jac, uint32_t *__restrict__ status, uint8_t *__restrict__ accept,
-                uint32_t *__restrict__ dbg) {
+                const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac /* folded el (recursion) or NULL */,
+                uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t slots = plan.n_points + plan.n_ci;
+    const uint32_t slots = H2V_SLOTS(plan);
     uint32_t st = status[i];
     for (uint32_t j = 0; j < slots; j++)
         if (!valid[(size_t)i * slots + j]) st |= H2V_ST_BAD_POINT;
@@ -582,6 +637,11 @@ k_pairing_check(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, c
             ej.x.v[k] = er_jac[(size_t)i * 36 + k]; ej.y.v[k] = er_jac[(size_t)i * 36 + 12 + k]; ej.z.v[k] = er_jac[(size_t)i * 36 + 24 + k];
         }
         g1j_to_affine(er, ej);
+        if (el_jac) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) { ej.x.v[k] = el_jac[(size_t)i * 36 + k]; ej.y.v[k] = el_jac[(size_t)i * 36 + 12 + k]; ej.z.v[k] = el_jac[(size_t)i * 36 + 24 + k]; }
+            g1j_to_affine(el, ej);
+        }
         const bool el_inf = g1a_is_inf(el), er_inf = g1a_is_inf(er);
         fp_neg(er.y, er.y);  // -er (harmless on the infinity sentinel: skipped below)
         Fp12 f;
@@ -599,6 +659,103 @@ k_pairing_check(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, c
     }
     status[i] = st;
     accept[i] = st == 0 ? 1 : 0;
+}
+
+// ============================================================================ K4b: recursion (IVC) batching challenge
+// c = LE(blake2b_256(compress(el) || compress(er) || compress(acc_left) || compress(acc_right_final))) mod r
+// (emitters/aiken.rs:743-748).  One lane per proof: the three Jacobian sums are normalised with ONE inversion
+// (Montgomery's trick), compressed (x big-endian + flags, sign = "y > (p-1)/2"), hashed, and the four affine points and
+// the scalars {1, c, 1, c} are written for the two fold MSMs  el' = el + c acc_left ,  er' = er + c acc_right_final.
+H2V_DN void g1_compress_dev(uint8_t (&out)[48], const G1A &a) {
+    if (g1a_is_inf(a)) {
+#pragma unroll
+        for (int k = 0; k < 48; k++) out[k] = 0;
+        out[0] = 0xc0;
+        return;
+    }
+    Fp x;
+    fp_from_mont(x, a.x);
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const uint32_t wv = x.v[11 - k];
+        out[4 * k] = wv >> 24; out[4 * k + 1] = wv >> 16; out[4 * k + 2] = wv >> 8; out[4 * k + 3] = wv;
+    }
+    out[0] |= fp_is_lex_larger(a.y) ? 0xa0 : 0x80;
+}
+extern "C" __global__ void __launch_bounds__(64)
+k_ivc_challenge(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint32_t *__restrict__ er_jac,
+                const uint32_t *__restrict__ accl_jac, const uint32_t *__restrict__ accr_jac,
+                uint32_t *__restrict__ fold_pts /* n x 4 x 24 */, uint32_t *__restrict__ fold_scal /* n x 4 x 8 */) {
+    __shared__ uint32_t sbuf[32 * 64];
+    const int lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * 64 + lane;
+    const bool live = i < n;
+    const uint32_t ii = live ? i : n - 1;
+    const uint32_t slots = H2V_SLOTS(plan);
+    G1A p[4];   // el, er, acc_left, acc_right_final
+    {
+        const uint32_t *pp = pts + ((size_t)ii * slots + plan.pi_point) * 24;
+#pragma unroll
+        for (int k = 0; k < 12; k++) { p[0].x.v[k] = pp[k]; p[0].y.v[k] = pp[12 + k]; }
+    }
+    {
+        // batch normalisation of the three Jacobian points; a point at infinity contributes Z := 1 to the product
+        G1J j[3];
+        const uint32_t *src[3] = {er_jac, accl_jac, accr_jac};
+        Fp z[3], pre[3], inv, t;
+        bool inf[3];
+        for (int q = 0; q < 3; q++) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) { j[q].x.v[k] = src[q][(size_t)ii * 36 + k]; j[q].y.v[k] = src[q][(size_t)ii * 36 + 12 + k]; j[q].z.v[k] = src[q][(size_t)ii * 36 + 24 + k]; }
+            inf[q] = g1j_is_inf(j[q]);
+            z[q] = j[q].z;
+            if (inf[q]) fp_set_one(z[q]);
+        }
+        pre[0] = z[0];
+        fp_mul(pre[1], pre[0], z[1]);
+        fp_mul(pre[2], pre[1], z[2]);
+        (void)fp_inv(inv, pre[2]);          // never zero: every factor is a non-zero Z or 1
+        for (int q = 2; q >= 0; q--) {
+            Fp zi;
+            if (q > 0) { fp_mul(zi, inv, pre[q - 1]); fp_mul(t, inv, z[q]); inv = t; } else zi = inv;
+            G1A &o = p[q + 1];
+            if (inf[q]) { g1a_set_inf(o); continue; }
+            Fp zi2;
+            fp_sqr(zi2, zi);
+            fp_mul(o.x, j[q].x, zi2);
+            fp_mul(zi2, zi2, zi);
+            fp_mul(o.y, j[q].y, zi2);
+        }
+    }
+    Transcript tr;
+    tr_init(tr);
+#pragma unroll 1
+    for (int q = 0; q < 4; q++) {
+        uint8_t enc[48];
+        g1_compress_dev(enc, p[q]);
+#pragma unroll 1
+        for (int k = 0; k < 48; k++) tr_put(tr, sbuf, lane, enc[k]);
+    }
+    uint64_t h[4];
+    tr_digest(tr, sbuf, lane, h);
+    Fr c, cm;
+#pragma unroll
+    for (int l = 0; l < 4; l++) { c.v[2 * l] = (uint32_t)h[l]; c.v[2 * l + 1] = (uint32_t)(h[l] >> 32); }
+    FrF::to_mont(cm, c);     // reduces the 256-bit integer mod r
+    FrF::from_mont(c, cm);
+    if (live) {
+        const int order[4] = {0, 2, 1, 3};   // fold points: el, acc_left, er, acc_right_final
+#pragma unroll 1
+        for (int q = 0; q < 4; q++) {
+            const G1A &o = p[order[q]];
+            uint32_t *dp = fold_pts + ((size_t)i * 4 + q) * 24;
+            uint32_t *ds = fold_scal + ((size_t)i * 4 + q) * 8;
+#pragma unroll
+            for (int k = 0; k < 12; k++) { dp[k] = o.x.v[k]; dp[12 + k] = o.y.v[k]; }
+#pragma unroll
+            for (int l = 0; l < 8; l++) ds[l] = (q & 1) ? c.v[l] : (l == 0 ? 1u : 0u);
+        }
+    }
 }
 
 // ============================================================================ primitive probes (parity tests)

@@ -325,8 +325,8 @@ H2V_DI F28 coop_inv(const Coop &c, const F28 &f, bool &ok) {
 // the spills around every call).
 extern "C" __global__ void __launch_bounds__(64, 2)
 k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid,
-               const uint32_t *__restrict__ er_jac, uint32_t *__restrict__ status, uint8_t *__restrict__ accept,
-               uint32_t *__restrict__ dbg) {
+               const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac /* folded el (recursion) or NULL */,
+               uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
     const int lane = threadIdx.x, grp = lane >> 5;
     Coop c;
     c.g = lane & 15;
@@ -337,7 +337,7 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
     const uint32_t i = blockIdx.x * COOP_GROUPS_PER_WAVE + grp;
     const bool live = i < n;
     const uint32_t ii = live ? i : n - 1;  // dead groups shadow the last proof, never write
-    const uint32_t slots = plan.n_points + plan.n_ci;
+    const uint32_t slots = H2V_SLOTS(plan);
 
     // operand tables -> LDS
     {
@@ -367,6 +367,12 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
         }
         if (st != 0) { g1a_set_inf(el); g1j_set_inf(ej); }  // rejected already: keep the arithmetic well-defined
         g1j_to_affine(er, ej);
+        if (el_jac && st == 0) {
+            G1J lj;
+#pragma unroll
+            for (int k = 0; k < 12; k++) { lj.x.v[k] = el_jac[(size_t)ii * 36 + k]; lj.y.v[k] = el_jac[(size_t)ii * 36 + 12 + k]; lj.z.v[k] = el_jac[(size_t)ii * 36 + 24 + k]; }
+            g1j_to_affine(el, lj);
+        }
         if (g1a_is_inf(el)) flags |= 1;
         if (g1a_is_inf(er)) flags |= 2;
         fp_neg(er.y, er.y);

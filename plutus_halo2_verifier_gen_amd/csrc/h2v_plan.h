@@ -6,8 +6,8 @@
 #include <stdint.h>
 
 #define H2V_PLAN_MAGIC "H2VPLAN1"
-#define H2V_PLAN_VERSION 2u
-#define H2V_PLAN_HDR_WORDS 34
+#define H2V_PLAN_VERSION 3u
+#define H2V_PLAN_HDR_WORDS 46
 #define H2V_MILLER_LINES 68  // 63 doublings + 5 additions for |x| = 0xd201000000010000
 
 // header words (uint32 little-endian) after the 8-byte magic
@@ -16,16 +16,20 @@ enum {
     H2V_HW_N_POINTS, H2V_HW_N_VK_BASES, H2V_HW_N_TERMS, H2V_HW_N_TRACE, H2V_HW_PI_POINT, H2V_HW_N_SQUEEZES,
     H2V_HW_STREAM_LEN,
     H2V_HW_OFF_INSTR, H2V_HW_OFF_CONSTS, H2V_HW_OFF_POINTS, H2V_HW_OFF_VK_BASES, H2V_HW_OFF_TERMS, H2V_HW_OFF_LINES_SG2,
-    H2V_HW_OFF_LINES_G2, H2V_HW_OFF_TRACE, H2V_HW_TOTAL_LEN, H2V_HW_OFF_LINES28_SG2, H2V_HW_OFF_LINES28_G2
+    H2V_HW_OFF_LINES_G2, H2V_HW_OFF_TRACE, H2V_HW_TOTAL_LEN, H2V_HW_OFF_LINES28_SG2, H2V_HW_OFF_LINES28_G2,
+    // recursion (IVC; plan.py / ivc.py): flag, number of terms of the proof's own MSM, and the public-input positions
+    // (x_hi, x_lo, y_hi, y_lo) of the two accumulator points
+    H2V_HW_IVC, H2V_HW_N_MAIN_TERMS, H2V_HW_ACC_IDX0 /* .. +7 */
 };
 
 // opcodes of the transcript + Fr-combiner program (8-byte instructions: op, pad, dst, a, b)
 enum {
     H2V_OP_END = 0, H2V_OP_ABSORB_REG, H2V_OP_ABSORB_CI, H2V_OP_LOAD_INSTANCE, H2V_OP_READ_POINT, H2V_OP_READ_SCALAR,
     H2V_OP_SQUEEZE, H2V_OP_CONST, H2V_OP_ADD, H2V_OP_SUB, H2V_OP_MUL, H2V_OP_NEG, H2V_OP_INV, H2V_OP_OUT_SCALAR,
+    H2V_OP_ASSERT_ZERO,  // status |= H2V_ST_RECURSION unless reg a == 0 (verifying-key hash check of the IVC fold)
     H2V_OP_COUNT
 };
-enum { H2V_TERM_PROOF_POINT = 0, H2V_TERM_VK_BASE = 1, H2V_TERM_COMMITTED_INSTANCE = 2 };
+enum { H2V_TERM_PROOF_POINT = 0, H2V_TERM_VK_BASE = 1, H2V_TERM_COMMITTED_INSTANCE = 2, H2V_TERM_ACC_POINT = 3 };
 
 // per-proof status bits produced on the device: H2V_ST_* of include/h2v.h (0 = nothing wrong so far)
 #ifndef H2V_ST_BAD_SCALAR
@@ -34,6 +38,9 @@ enum { H2V_TERM_PROOF_POINT = 0, H2V_TERM_VK_BASE = 1, H2V_TERM_COMMITTED_INSTAN
 #define H2V_ST_SHORT_PROOF 4u
 #define H2V_ST_BAD_POINT 8u
 #define H2V_ST_PAIRING 16u
+#endif
+#ifndef H2V_ST_RECURSION
+#define H2V_ST_RECURSION 32u
 #endif
 
 struct H2vInstr {
@@ -54,4 +61,11 @@ struct H2vDevPlan {
     const uint32_t *lines28_sg2; // 68 * 8 operand slots of 16 dwords (28-bit limbs): cooperative pairing engine
     const uint32_t *lines28_g2;
     const uint32_t *trace;     // n_trace * 2    (slot id, register)
+    // recursion (IVC): terms [0, n_main_terms) are the proof's own MSM, term n_main_terms is acc_left, the rest
+    // acc_right and its fixed bases; acc_idx = public-input positions of (x_hi, x_lo, y_hi, y_lo) x (left, right)
+    uint32_t ivc, n_main_terms;
+    uint32_t acc_idx[8];
+    const uint32_t *fold_terms;  // 4 x (kind, index): el + c*acc_left, er + c*acc_right over the fold's own point buffer
 };
+// per-proof point slots: the proof's G1 elements, the committed instance, then (recursion) the two accumulator points
+#define H2V_SLOTS(plan) ((plan).n_points + (plan).n_ci + 2u * (plan).ivc)

@@ -43,12 +43,12 @@ R = bls.R
 
 # ---- opcodes (mirrored in csrc/h2v_plan.h)
 OP_END, OP_ABSORB_REG, OP_ABSORB_CI, OP_LOAD_INSTANCE, OP_READ_POINT, OP_READ_SCALAR, OP_SQUEEZE, OP_CONST, \
-    OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_INV, OP_OUT_SCALAR = range(14)
+    OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_INV, OP_OUT_SCALAR, OP_ASSERT_ZERO = range(15)
 OP_NAMES = ["END", "ABSORB_REG", "ABSORB_CI", "LOAD_INSTANCE", "READ_POINT", "READ_SCALAR", "SQUEEZE", "CONST",
-            "ADD", "SUB", "MUL", "NEG", "INV", "OUT_SCALAR"]
+            "ADD", "SUB", "MUL", "NEG", "INV", "OUT_SCALAR", "ASSERT_ZERO"]
 
-# ---- MSM term kinds
-TERM_PROOF_POINT, TERM_VK_BASE, TERM_COMMITTED_INSTANCE = 0, 1, 2
+# ---- MSM term kinds (ACC_POINT: the two accumulator points rebuilt from the public inputs, recursion only)
+TERM_PROOF_POINT, TERM_VK_BASE, TERM_COMMITTED_INSTANCE, TERM_ACC_POINT = 0, 1, 2, 3
 
 # ---- trace slots (same order as the oracle's trace struct; expressions start at TRACE_EXPR0)
 TRACE_NAMES = ["theta", "beta", "gamma", "trash", "y", "x", "x1", "x2", "x3", "x4", "x_prev", "x_next", "x_last", "xn",
@@ -58,8 +58,8 @@ MAX_TRACE_EXPR = 256
 
 MILLER_LINES = 68
 PLAN_MAGIC = b"H2VPLAN1"
-PLAN_VERSION = 2
-PLAN_HDR_WORDS = 34  # 8 + 4*34 = 144 bytes: keeps every 16-byte-padded section 16-byte aligned
+PLAN_VERSION = 3
+PLAN_HDR_WORDS = 46  # 8 + 4*46 = 192 bytes: keeps every 16-byte-padded section 16-byte aligned
 
 ROT_LAST = "last"  # rotation key of x_last = w^-(bf+1) x
 
@@ -84,6 +84,18 @@ class Plan:
     trace: List[Tuple[int, int]]  # (slot id, register)
     n_squeezes: int = 0
     stream_len: int = 0  # bytes hashed by the transcript
+    # recursion (ivc.py): terms[:n_main_terms] is the proof's own MSM; then one term for acc_left, then acc_right
+    # followed by its fixed bases.  acc_coords: public-input positions (x_hi, x_lo, y_hi, y_lo) x (left, right).
+    n_main_terms: int = -1
+    acc_coords: Optional[List[int]] = None
+
+    def __post_init__(self):
+        if self.n_main_terms < 0:
+            self.n_main_terms = len(self.terms)
+
+    @property
+    def is_recursive(self) -> bool:
+        return self.acc_coords is not None
 
     @property
     def n_terms(self) -> int:
@@ -126,6 +138,7 @@ class Plan:
                                             "trace")]
         fields += sect + [hdr_len + len(body)]
         fields += [hdr_len + offs["lines28_sg2"], hdr_len + offs["lines28_g2"]]
+        fields += [1 if self.is_recursive else 0, self.n_main_terms] + list(self.acc_coords or [0] * 8)
         fields += [0] * (PLAN_HDR_WORDS - len(fields))
         return PLAN_MAGIC + struct.pack("<%dI" % PLAN_HDR_WORDS, *fields) + bytes(body)
 
@@ -665,6 +678,28 @@ def compile_plan(vk: VerifyingKey) -> Plan:
     add_term(TERM_VK_BASE, vk_base(("neg_g1", 0), bls.g1_neg(bls.G1_GEN)), v, "neg_g1_generator")
     add_term(TERM_PROOF_POINT, pi_pt, x3, "pi")
 
+    # ---- recursion: accumulator terms + verifying-key hash check (ivc.py; emitters/aiken.rs:648-757)
+    n_main_terms = len(terms)
+    acc_coords = None
+    if vk.recursion_vks is not None:
+        from . import ivc
+        lay = ivc.layout(vk)
+        b.emit(OP_ASSERT_ZERO, 0, b.sub(pis[lay["vk_hash"]], b.const(vk.transcript_repr)), 0)
+        add_term(TERM_ACC_POINT, 0, pis[lay["left_scalar"]], "acc_left")
+        add_term(TERM_ACC_POINT, 1, pis[lay["right_scalar"]], "acc_right")
+        keys = [("neg_g1", 0)] + [("fixed", i) for i in range(len(fixed_pts))] + [("common", i) for i in range(len(perm_cpts))]
+        names = ["neg_g1_generator"] + ["f%d_commitment" % (i + 1) for i in range(len(fixed_pts))] + \
+                ["p%d_commitment" % (i + 1) for i in range(len(perm_cpts))]
+        for inner in vk.recursion_vks:
+            for i in range(len(inner["fixed_commitments"])):
+                keys.append(("inner_f", inner["name"], i)); names.append("f%d_%s" % (i + 1, inner["name"]))
+            for i in range(len(inner["permutation_commitments"])):
+                keys.append(("inner_p", inner["name"], i)); names.append("p%d_%s" % (i + 1, inner["name"]))
+        for key, name, h, k in zip(keys, names, ivc.fixed_bases(vk), lay["fixed_scalars"]):
+            add_term(TERM_VK_BASE, vk_base(key, bls.g1_decompress(bytes.fromhex(h))), pis[k], name)
+        acc_coords = [lay["left_x"][0], lay["left_x"][1], lay["left_y"][0], lay["left_y"][1],
+                      lay["right_x"][0], lay["right_x"][1], lay["right_y"][0], lay["right_y"][1]]
+
     for t, reg in enumerate(term_scalar):
         b.emit(OP_OUT_SCALAR, t, reg, 0)
     b.emit(OP_END)
@@ -688,6 +723,7 @@ def compile_plan(vk: VerifyingKey) -> Plan:
         consts=b.consts, points=points, point_names=point_names, vk_bases=vk_bases, terms=terms,
         term_names=term_names, pi_point=pi_pt, lines_sg2=bls.g2_line_table(s_g2),
         lines_g2=bls.g2_line_table(bls.G2_GEN), trace=trace, n_squeezes=n_squeezes, stream_len=stream_len,
+        n_main_terms=n_main_terms, acc_coords=acc_coords,
     )
     return plan
 
@@ -695,7 +731,7 @@ def compile_plan(vk: VerifyingKey) -> Plan:
 def _uses(op, dst, a, b):
     if op in (OP_ADD, OP_SUB, OP_MUL):
         return (a, b)
-    if op in (OP_NEG, OP_INV, OP_ABSORB_REG, OP_OUT_SCALAR):
+    if op in (OP_NEG, OP_INV, OP_ABSORB_REG, OP_OUT_SCALAR, OP_ASSERT_ZERO):
         return (a,)
     return ()
 
@@ -724,7 +760,7 @@ def _allocate(b: _Builder, keep_alive):
         pa, pc = a, c
         if op in (OP_ADD, OP_SUB, OP_MUL):
             pa, pc = mapping[a], mapping[c]
-        elif op in (OP_NEG, OP_INV, OP_ABSORB_REG, OP_OUT_SCALAR):
+        elif op in (OP_NEG, OP_INV, OP_ABSORB_REG, OP_OUT_SCALAR, OP_ASSERT_ZERO):
             pa = mapping[a]
         # release registers whose last use is this instruction BEFORE allocating dst (dst may reuse a source:
         # every op reads its sources fully before writing)
@@ -819,6 +855,9 @@ def run_plan(plan: Plan, proof: bytes, instances: List[int], committed: Optional
                 regs[d] = pow(regs[a], R - 2, R)
         elif op == OP_OUT_SCALAR:
             scalars[d] = regs[a]
+        elif op == OP_ASSERT_ZERO:
+            if regs[a] != 0:
+                status = status or "recursion"
         else:
             raise ValueError("bad opcode %d" % op)
     return scalars, regs, status

@@ -134,13 +134,20 @@ def _forge_with_plan(vk: VerifyingKey, td: Trapdoor, plan: Plan, lo: int, hi: in
     # dlog of every VK base in plan order: fixed / permutation commitments via the trapdoor, -G1 -> -1
     fixed_pts = {bls.g1_decompress(bytes.fromhex(h), False): d for h, d in zip(vk.fixed_commitments, td.fixed_dlogs)}
     perm_pts = {bls.g1_decompress(bytes.fromhex(h), False): d for h, d in zip(vk.permutation_commitments, td.perm_dlogs)}
+    rec_pts = {}
+    if vk.recursion_vks is not None:
+        from . import ivc
+        n_own = 1 + len(vk.fixed_commitments) + len(vk.permutation_commitments)
+        rec_pts = {bls.g1_decompress(bytes.fromhex(h), False): d for h, d in zip(ivc.fixed_bases(vk)[n_own:], td.rec_dlogs)}
     for pt in plan.vk_bases:
         if pt == bls.g1_neg(bls.G1_GEN):
             vk_dlogs.append(R - 1)
         elif pt in fixed_pts:
             vk_dlogs.append(fixed_pts[pt])
-        else:
+        elif pt in perm_pts:
             vk_dlogs.append(perm_pts[pt])
+        else:
+            vk_dlogs.append(rec_pts[pt])
     proofs, insts, cis = [], [], []
     for i in range(lo, hi):
         rng = random.Random((seed << 20) ^ i)
@@ -164,6 +171,8 @@ def _forge_with_plan(vk: VerifyingKey, td: Trapdoor, plan: Plan, lo: int, hi: in
             inst = [42] * vk.n_public_inputs  # the literal inputs of examples/simple_mul.rs:68
         else:
             inst = [rng.randrange(R) for _ in range(vk.n_public_inputs)]
+        if vk.recursion_vks is not None:
+            ivc.make_accumulator(vk, td, rng, inst)  # a valid accumulator: the fold keeps the pairing equation true
         ci_bytes, ci_dlog = None, 0
         if vk.n_committed_instances:
             if ci_identity:
@@ -176,7 +185,7 @@ def _forge_with_plan(vk: VerifyingKey, td: Trapdoor, plan: Plan, lo: int, hi: in
             assert status is None, status
             total = 0
             x3 = None
-            for t, (kind, idx) in enumerate(plan.terms):
+            for t, (kind, idx) in enumerate(plan.terms[:plan.n_main_terms]):
                 if kind == TERM_PROOF_POINT and idx == pi_pt:
                     x3 = scalars[t]
                     continue
@@ -226,7 +235,9 @@ def forge_batch(vk: VerifyingKey, td: Trapdoor, n: int, seed: int = 1, workers: 
 
 # ----------------------------------------------------------------------------- negative cases
 CORRUPTIONS = ("flip_first_scalar", "flip_last_scalar", "bad_point_flag", "point_not_on_curve", "point_not_in_subgroup",
-               "noncanonical_scalar", "wrong_public_input", "wrong_pi", "truncated", "infinity_commitment")
+               "noncanonical_scalar", "wrong_public_input", "wrong_pi", "truncated", "infinity_commitment",
+               # recursion (IVC) only; None for plans without an accumulator
+               "acc_limb", "acc_scalar", "acc_fixed_scalar", "acc_sign", "acc_vk_hash")
 
 
 def _first_scalar_offset(plan: Plan) -> int:
@@ -289,6 +300,32 @@ def corrupt(plan: Plan, proof: bytes, inst: bytes, kind: str, rng: random.Random
         buf = buf[:-1]
     elif kind == "infinity_commitment":
         buf[plan.points[0]:plan.points[0] + 48] = bls.g1_compress(None)
+    elif kind.startswith("acc_"):
+        if not plan.is_recursive:
+            return None
+        lx_hi, lx_lo, ly_hi, ly_lo, rx_hi, rx_lo, ry_hi, ry_lo = plan.acc_coords
+        geti = lambda k: int.from_bytes(inst[32 * k:32 * k + 32], "little")
+
+        def seti(k, v):
+            inst[32 * k:32 * k + 32] = (v % R).to_bytes(32, "little")
+
+        # scalar positions follow the coordinates (ivc.layout): left scalar after left y, right scalar after right y
+        if kind == "acc_limb":          # another x: off the curve, outside the subgroup, or simply a different point
+            seti(lx_lo, geti(lx_lo) + 1 + rng.randrange(1 << 32))
+        elif kind == "acc_scalar":
+            seti(ly_hi + 1, geti(ly_hi + 1) + 1)
+        elif kind == "acc_fixed_scalar":
+            seti(ry_hi + 2 + rng.randrange(3), rng.randrange(R))
+        elif kind == "acc_sign":        # y -> p - y: the same x with the other parity flag = the negated point
+            from . import ivc
+            y = ivc.coord(geti(ry_hi), geti(ry_lo))
+            hi, lo = ivc.split_coord(bls.P - y)
+            seti(ry_hi, hi)
+            seti(ry_lo, lo)
+        elif kind == "acc_vk_hash":
+            seti(0, geti(0) ^ 1)
+        else:
+            raise ValueError(kind)
     else:
         raise ValueError(kind)
     return bytes(buf), bytes(inst)

@@ -58,6 +58,9 @@ class VerifyingKey:
     s_g2: str  # hex of 96-byte compressed G2
     n_public_inputs: int
     n_committed_instances: int = 0  # 0 or 1
+    # IVC / recursion (instantiation_data.rs:40,117-135): None = no accumulator in the public inputs; a list (possibly
+    # empty) of inner verifying keys {name, transcript_repr, fixed_commitments, permutation_commitments} otherwise.
+    recursion_vks: Optional[list] = None
 
     # ---- derived (instantiation_data.rs:84-103)
     @property
@@ -138,10 +141,12 @@ class VerifyingKey:
 
 @dataclass
 class Trapdoor:
-    """Test-SRS secret + discrete logs of the VK commitments (synthetic workloads only)."""
+    """Test-SRS secret + discrete logs of the VK commitments (synthetic workloads only).
+    rec_dlogs: discrete logs of the inner verifying keys' commitments, in ivc.fixed_bases order."""
     s: int
     fixed_dlogs: List[int] = field(default_factory=list)
     perm_dlogs: List[int] = field(default_factory=list)
+    rec_dlogs: List[int] = field(default_factory=list)
 
 
 # ----------------------------------------------------------------------------- expression helpers
@@ -372,10 +377,31 @@ def secp256k1_vk(seed: int = 0x48325635):
                       gate_ops={"mul": 641, "add": 476, "neg": 67}, adv_rot_sets=adv, n_pi=4, n_ci=1)
 
 
+def ivc_vk(seed: int = 0x48325636):
+    """IVC-shaped circuit (examples/ivc.rs, src/circuits/ivc_circuit.rs): a small chip mix whose public inputs carry
+    the verifying-key hash, the collapsed accumulator of the previous step and the fixed-base scalars
+    (emitters/aiken.rs:648-757, docs/algorithms.html "Recursion (IVC)"), with one inner verifying key."""
+    adv = [[0, 1]] * 2 + [[0]] * 3
+    rng = random.Random(seed ^ 0x1)
+    inner_f_d, inner_f = _commitments(rng, 2)
+    inner_p_d, inner_p = _commitments(rng, 2)
+    inner = [{"name": "inner", "transcript_repr": rng.randrange(bls.R), "fixed_commitments": inner_f,
+              "permutation_commitments": inner_p}]
+    n_fix, n_cc = 6, 4
+    f_len = 1 + n_fix + n_cc + 4          # -G1, this key's commitments, the inner key's
+    n_pi = 2 + f_len + 10 + 1             # two key hashes, fixed-base scalars, serialised accumulator, one app input
+    vk, td = _shaped_vk("ivc", seed, k=10, degree=5, n_adv=5, n_fix=n_fix, n_cc=n_cc, lookup_arg_exprs=[2],
+                        gate_exprs=4, gate_ops={"mul": 24, "add": 20, "neg": 4}, adv_rot_sets=adv, n_pi=n_pi, n_ci=0)
+    vk.recursion_vks = inner
+    td.rec_dlogs = inner_f_d + inner_p_d
+    return vk, td
+
+
 BUILDERS = {
     "simple_mul": simple_mul_vk,
     "lookup_table": lookup_table_vk,
     "atms_with_lookups": atms_with_lookups_vk,
     "sha256": sha256_vk,
     "secp256k1": secp256k1_vk,
+    "ivc": ivc_vk,
 }
