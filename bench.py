@@ -35,6 +35,7 @@ WORKLOADS = {
     "atms_with_lookups": ("atms_with_lookups", 2048, "atms_with_lookups x2048 (half of BASELINE configs[2])"),
     "sha256": ("sha256", 1024, "sha256-shaped x1024 per GPU (BASELINE configs[3])"),
     "secp256k1": ("secp256k1", 512, "secp256k1-shaped x512 per GPU (BASELINE configs[4])"),
+    "ivc": ("ivc", 1024, "IVC-shaped recursive circuit x1024 per GPU (accumulator fold, DESIGN.md section 10)"),
 }
 
 

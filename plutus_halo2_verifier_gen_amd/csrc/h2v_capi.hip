@@ -67,12 +67,6 @@ struct h2v_workspace {
 };
 
 static uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
-static uint32_t next_pow2(uint32_t v) {
-    uint32_t p = 1;
-    while (p < v) p <<= 1;
-    return p;
-}
-
 // ---------------------------------------------------------------------------------------------- plan
 extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_plan **out) {
     if (!blob || !out) return fail(H2V_E_ARG, "null argument");
@@ -290,11 +284,17 @@ extern "C" void h2v_workspace_free(h2v_workspace *w) {
 // MSM launch geometry: 2 lanes per (proof, term); block = max(64, 2*tp) threads, LDS 144 B per thread.
 static void launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const uint32_t *scalars, const uint32_t *pts,
                              uint32_t *out, uint32_t *tabws, hipStream_t st) {
-    const uint32_t tp = next_pow2(ma.n_terms);
-    const uint32_t bs = 2 * tp < 64 ? 64 : 2 * tp;
-    const uint32_t per_block = bs / (2 * tp);
+    // 2 lanes per term; block = the multiple of 64 (<= 512) that wastes the smallest fraction of its lanes
+    const uint32_t lpp = 2 * ma.n_terms;
+    uint32_t bs = 64, best_waste = ~0u;
+    for (uint32_t cand = 64; cand <= 512; cand += 64) {
+        if (cand < lpp) continue;
+        const uint32_t waste = (cand - cand / lpp * lpp) * 4096 / cand;   // idle fraction, fixed point
+        if (waste < best_waste) { best_waste = waste; bs = cand; }
+    }
+    const uint32_t per_block = bs / lpp;
     const uint32_t blocks = (n + per_block - 1) / per_block;
-    hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 144, st, d, ma, n, tp, scalars, pts, out, tabws);
+    hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 144, st, d, ma, n, per_block, scalars, pts, out, tabws);
 }
 // the proof's own MSM: terms [0, n_main_terms) of the plan's table, scalars from the combiner, points from decompression
 static void launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, uint32_t *er, uint32_t *tabws, hipStream_t st) {

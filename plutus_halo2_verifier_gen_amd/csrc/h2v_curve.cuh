@@ -37,26 +37,6 @@ H2V_DI void g1j_dbl_inl(G1J &r, const G1J &p) {
     r.x = X; r.y = Y; r.z = Z;
 }
 H2V_DN void g1j_dbl(G1J &r, const G1J &p) { g1j_dbl_inl(r, p); }
-// mixed addition r = p + q (q affine, may be infinity): 8M + 3S on the generic path
-H2V_DN void g1j_add_affine(G1J &r, const G1J &p, const G1A &q) {
-    if (g1a_is_inf(q)) { r = p; return; }
-    if (g1j_is_inf(p)) { r.x = q.x; r.y = q.y; fp_set_one(r.z); return; }
-    Fp z1z1, u2, s2, h, rr, hh, hhh, v, t, x3, y3, z3;
-    fp_sqr(z1z1, p.z);
-    fp_mul(u2, q.x, z1z1);
-    fp_mul(s2, q.y, p.z); fp_mul(s2, s2, z1z1);
-    fp_sub(h, u2, p.x);
-    fp_sub(rr, s2, p.y);
-    if (fp_is_zero(h)) {
-        if (fp_is_zero(rr)) { g1j_dbl(r, p); return; }
-        g1j_set_inf(r); return;
-    }
-    fp_sqr(hh, h); fp_mul(hhh, hh, h); fp_mul(v, p.x, hh);
-    fp_sqr(x3, rr); fp_sub(x3, x3, hhh); fp_dbl(t, v); fp_sub(x3, x3, t);
-    fp_sub(t, v, x3); fp_mul(y3, rr, t); fp_mul(t, p.y, hhh); fp_sub(y3, y3, t);
-    fp_mul(z3, p.z, h);
-    r.x = x3; r.y = y3; r.z = z3;
-}
 // full addition: 12M + 4S on the generic path.  q is read through the reference where it is needed (it lives in the
 // ladder's table in private memory) and negated on the fly when neg_q; at most six field elements are live at a call.
 H2V_DI void g1j_add_signed_inl(G1J &r, const G1J &p, const G1J &q, const bool neg_q) {
@@ -96,36 +76,6 @@ H2V_DN void g1j_to_affine(G1A &r, const G1J &p) {
     fp_mul(zi2, zi2, zi);
     fp_mul(r.y, p.y, zi2);
 }
-// [|x|]P for the BLS parameter |x| = 0xd201000000010000 (uniform control flow)
-H2V_DN void g1j_mul_x_abs(G1J &r, const G1J &p) {
-    G1J acc = p;
-    for (int i = 62; i >= 0; i--) {
-        g1j_dbl(acc, acc);
-        if ((BLS_X_ABS >> i) & 1) g1j_add(acc, acc, p);
-    }
-    r = acc;
-}
-// Is the affine, on-curve, finite point in the r-torsion?  sigma(P) = (beta x, y) == [-x^2]P
-// (forces (sigma^2+sigma+1)P = [r]P = O; r does not divide the cofactor, so the test is exact).
-H2V_DN bool g1a_in_subgroup(const G1A &a) {
-    G1J p, t;
-    g1j_from_affine(p, a);
-    g1j_mul_x_abs(t, p);
-    g1j_mul_x_abs(t, t);  // [x^2]P
-    if (g1j_is_inf(t)) return false;
-    // compare (beta x, y) with -t = (X, -Y, Z):  beta x Z^2 == X  and  y Z^3 == -Y
-    Fp beta, z2, z3, l, ny;
-#pragma unroll
-    for (int i = 0; i < 12; i++) beta.v[i] = FP_BETA[i];
-    fp_sqr(z2, t.z);
-    fp_mul(z3, z2, t.z);
-    fp_mul(l, a.x, beta); fp_mul(l, l, z2);
-    if (!fp_eq(l, t.x)) return false;
-    fp_mul(l, a.y, z3);
-    fp_neg(ny, t.y);
-    return fp_eq(l, ny);
-}
-
 // ------------------------------------------------------------------ GLV scalar split
 // phi(x, y) = (beta' x, y) is [lambda] on G1 with lambda = x^2 - 1 ~ sqrt(r), so an Fr scalar k < r splits by plain
 // division k = k2*lambda + k1 into two halves below 2^128: [k]P = [k1]P + [k2]phi(P).  Barrett estimate

@@ -117,8 +117,8 @@ H2V_DN void g1j28_mul_x_abs(G1J28 &r, bool &r_inf, const G1J28 &p, const bool p_
     r = acc;
     r_inf = inf;
 }
-// Same statement as g1a_in_subgroup (h2v_curve.cuh): sigma(P) = (beta x, y) == [-x^2]P, for a finite affine point of
-// an a = 0 curve; the two 63-step chains run on the lazily reduced field, the final comparison on canonical limbs.
+// Is the finite affine point of an a = 0 curve in the r-torsion?  sigma(P) = (beta x, y) == [-x^2]P (forces
+// (sigma^2 + sigma + 1)P = [r]P = O; r does not divide the cofactor, so the test is exact); the two 63-step chains run on the lazily reduced field, the final comparison on canonical limbs.
 H2V_DN bool g1a_in_subgroup28(const G1A &a) {
     G1J28 p, t;
     bool tinf = false;

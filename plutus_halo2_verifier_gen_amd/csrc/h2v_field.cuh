@@ -323,75 +323,9 @@ H2V_DI void fp_from_mont(Fp &r, const Fp &a) {
     one.v[0] = 1;
     fp_mul(r, a, one);
 }
-// a^e for a fixed public exponent given as limbs (uniform control flow across lanes)
-template <int EL>
-H2V_DN void fp_pow_const(Fp &r, const Fp &a, const uint32_t (&e)[EL]) {
-    Fp acc;
-    fp_set_one(acc);
-    bool started = false;
-    for (int i = EL * 32 - 1; i >= 0; i--) {
-        if (started) fp_sqr(acc, acc);
-        if ((e[i >> 5] >> (i & 31)) & 1) {
-            if (started) fp_mul(acc, acc, a);
-            else { acc = a; started = true; }
-        }
-    }
-    r = acc;
-}
-// ------------------------------------------------------------------ inversion: Kaliski's almost-Montgomery inverse
-// A Fermat chain costs ~570 dependent multiplications (about 3.5 M cycles on a lone lane); the binary
-// extended-Euclid form below is ~bits..2*bits iterations of word-level add / sub / shift.  Phase 1 yields
-// abar^-1 * 2^k mod m with k in [bits, 2*bits]; one Montgomery product by 2^(3*RBITS-k) (table) finishes the job.
-// Any exact inverse is the same field element as the reference's recip (BlsTypes.hs:201-212 / recip_eea, bls_utils.ak:98-117).
-template <int N>
-H2V_DI bool big_is_zero(const uint32_t (&a)[N]) {
-    uint32_t x = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) x |= a[i];
-    return x == 0;
-}
-template <int N>
-H2V_DI bool big_gt(const uint32_t (&a)[N], const uint32_t (&b)[N]) {  // a > b  <=>  b - a borrows
-    uint64_t br = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t d = (uint64_t)b[i] - a[i] - br;
-        br = (d >> 63) & 1;
-    }
-    return br != 0;
-}
-template <int N>
-H2V_DI void big_sub(uint32_t (&r)[N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
-    uint64_t br = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t d = (uint64_t)a[i] - b[i] - br;
-        r[i] = (uint32_t)d;
-        br = (d >> 63) & 1;
-    }
-}
-template <int N>
-H2V_DI void big_add(uint32_t (&r)[N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        c += (uint64_t)a[i] + b[i];
-        r[i] = (uint32_t)c;
-        c >>= 32;
-    }
-}
-template <int N>
-H2V_DI void big_shr1(uint32_t (&a)[N]) {
-#pragma unroll
-    for (int i = 0; i < N - 1; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 31);
-    a[N - 1] >>= 1;
-}
-template <int N>
-H2V_DI void big_shl1(uint32_t (&a)[N]) {
-#pragma unroll
-    for (int i = N - 1; i > 0; i--) a[i] = (a[i] << 1) | (a[i - 1] >> 31);
-    a[0] <<= 1;
-}
+// ------------------------------------------------------------------ inversion
+// Any exact inverse is the same field element as the reference's recip (BlsTypes.hs:201-212 / recip_eea,
+// bls_utils.ak:98-117).
 #include "h2v_modinv.cuh"
 // Inversion: batched division steps (h2v_modinv.cuh).  The operand is a Montgomery residue aR; its integer
 // inverse is a^-1 R^-1, and one Montgomery product with R^3 returns a^-1 R.  Returns false when a == 0.

@@ -435,18 +435,20 @@ struct H2vMsmArgs {
     uint32_t scal_col_base;    // column of the range's first term
     uint32_t slots;            // point slots per proof in `pts`
 };
-extern "C" __global__ void __launch_bounds__(128, 2)
-k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t tp /* pow2 >= ma.n_terms, <= 64 */,
+// A proof owns exactly 2 * n_terms consecutive lanes of a block (no power-of-two padding: 34 terms used to occupy
+// 128 lanes); the block holds as many whole proofs as fit, the rest of its lanes idle.
+extern "C" __global__ void __launch_bounds__(512, 2)
+k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
          const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ out,
          uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];  // Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t]
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
-    const uint32_t lanes_per_proof = 2 * tp;
-    const uint32_t per_block = bs / lanes_per_proof;
-    const uint32_t sub = tid % lanes_per_proof;       // position inside the proof's segment
+    const uint32_t lanes_per_proof = 2 * ma.n_terms;
+    const uint32_t seg = tid / lanes_per_proof;       // which of the block's proofs
+    const uint32_t sub = tid - seg * lanes_per_proof; // position inside the proof's segment
     const uint32_t term = sub >> 1, half = sub & 1;
-    const uint32_t i = blockIdx.x * per_block + tid / lanes_per_proof;
-    const bool active = i < n && term < ma.n_terms;
+    const uint32_t i = blockIdx.x * per_block + seg;
+    const bool active = seg < per_block && i < n;
     G1J acc;
     g1j_set_inf(acc);
     if (active) {
@@ -527,8 +529,10 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t tp /* pow2 >= ma.n
         red[(24 + k) * bs + tid] = acc.z.v[k];
     }
     __syncthreads();
-    for (uint32_t s = lanes_per_proof >> 1; s >= 1; s >>= 1) {
-        if (sub < s) {
+    uint32_t top = 1;
+    while (top < lanes_per_proof) top <<= 1;
+    for (uint32_t s = top >> 1; s >= 1; s >>= 1) {
+        if (seg < per_block && sub < s && sub + s < lanes_per_proof) {
             G1J other;
 #pragma unroll
             for (int k = 0; k < 12; k++) {
@@ -546,7 +550,7 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t tp /* pow2 >= ma.n
         }
         __syncthreads();
     }
-    if (sub == 0 && i < n) {
+    if (sub == 0 && seg < per_block && i < n) {
 #pragma unroll
         for (int k = 0; k < 12; k++) {
             out[(size_t)i * 36 + k] = acc.x.v[k];
