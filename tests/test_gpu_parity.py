@@ -71,6 +71,22 @@ def test_g1_decompress(be, orc, kats):
         raw = bytearray(rng.randrange(P).to_bytes(48, "big"))
         raw[0] |= 0x80 | (0x20 if rng.random() < 0.5 else 0)
         cases.append(bytes(raw))
+    # points of small order (the cofactor is 3 * 11^2 * 10177^2 * ...): the subgroup test's double-and-add chain meets
+    # P + (-P) and the point at infinity in the middle of the ladder
+    h = 0x396c8c005555e1568c00aaab0000aaab            # #E(Fp) = h * r
+    assert h % 3 == 0 and h % 11 == 0 and h % 10177 == 0
+    found = 0
+    x = 1
+    while found < 6:
+        x += 1
+        y = bls.fp_sqrt((x * x * x + 4) % P)
+        if y is None:
+            continue
+        for q in (3, 11, 10177):
+            t = bls.g1_mul((x, y), h * R // q)
+            if t is not None:
+                cases.append(bls.g1_compress(t))
+                found += 1
     got = be.probe_g1_decompress(cases)
     for c, (ok, pt) in zip(cases, got):
         ook, opt = orc.g1_decompress(c)
@@ -97,6 +113,12 @@ def test_g1_msm(be, orc):
                 ss[1] = ss[0]
             if g == 4:
                 ps[0] = None                      # infinity base
+                # GLV / window edge scalars: halves that vanish, lambda +- 1, digits at the window borders
+                lam = bls.GLV_LAMBDA
+                edge = [1, 2, 7, 8, 9, 15, 16, 17, lam - 1, lam, lam + 1, 2 * lam, R - lam, (1 << 128) - 1, 1 << 128,
+                        (1 << 255) % R, 0x8888888888888888888888888888888888888888888888888888888888888888 % R]
+                for t in range(1, T):
+                    ss[t] = edge[(t - 1) % len(edge)]
             groups_s.append(ss)
             pts.append(ps)
             groups_b.append([bls.g1_compress(p) for p in ps])
