@@ -72,12 +72,13 @@ H2V_DI void coop_load28(uint32_t (&l)[14], const uint32_t *p) {
 }
 
 // Values between engine calls are lazily reduced F28 elements (h2v_fp28.cuh).  Bounds, in that header's (v, lam)
-// notation:  every Fp12 variable has lam = 1 and v <= 6 (engine outputs 2, conj 3..6, frob 5, inverse 1; the
+// notation:  every Fp12 variable has lam = 1 and v <= 6 (engine outputs 3, conj 6, frob 5, inverse 3; the
 // generated program is checked for this by tools/gen_coop_program.py).  Operand slots must hold carried limbs: a
 // MUL column sums 12 terms x 14 products, which fills the 64-bit accumulator at lam = 1.  Staged operands:
 //   A = a (6)   NA = 7p - a_im (7)   B = b (6)   XB = (b0 - b1 + 7p, b0 + b1) (13)   D = 2a (12)   ND = 13p - 2 a_im (13)
-// so the engine's result is below (12 * 7 * 13 / 2520 + 1) p < 2p for MUL and (3 * 6 * 7 * 13 / 2520 + 1) p < 2p for
-// the tripled cyclotomic squaring (p / R < 1/2520).
+// Each of the two lanes sharing a coefficient reduces its half of the terms on its own: a half is below
+// (6 * 7 * 13 / 2520 + 1) p = 1.22 p for MUL and (3 * 3 * 7 * 13 / 2520 + 1) p = 1.33 p for the tripled cyclotomic
+// squaring (p / R < 1/2520), so the engine's result (the sum of the two halves) is below 3p.
 
 // out = sum_t X[tab[2t]] * Y[tab[2t+1]]  (mod p), one Montgomery reduction.  NT <= 12 (accumulator headroom).
 // TRIPLE: the column accumulators are multiplied by 3 before the reduction (6 terms * 3 still fits 64 bits).
@@ -111,26 +112,15 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
 #pragma unroll
             for (int j = 0; j < 14; j++) acc[i + j] += (uint64_t)x[i] * y[j];
     }
-    // add the partner lane's half of the sum (lane ^ 16), still unreduced.  v_permlane16_swap exchanges the odd
-    // 16-lane rows of its first operand with the even rows of its second: called on two copies of a register, one
-    // copy ends up holding (own | partner) and the other (partner | own) by row, so their sum is own + partner in
-    // every lane - a VALU-rate exchange (ds_bpermute cost 56 LDS round trips per call).
+    if (TRIPLE) {   // x3 as one shift-add per column (the compiler's choice was two v_mad_u64_u32 per column)
 #pragma unroll
-    for (int i = 0; i < 28; i++) {
-        const uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
-        const auto sl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        const auto sh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        uint32_t cy;
-        const uint32_t slo = __builtin_addc(sl[0], sl[1], 0u, &cy);
-        const uint32_t shi = sh[0] + sh[1] + cy;
-        acc[i] = (uint64_t)slo | ((uint64_t)shi << 32);
-        if (TRIPLE) {   // x3 as one shift-add (the compiler's choice was two v_mad_u64_u32 per column)
+        for (int i = 0; i < 28; i++) {
             uint64_t t3;
             asm("v_lshl_add_u64 %0, %1, 1, %1" : "=v"(t3) : "v"(acc[i]));
             acc[i] = t3;
         }
     }
-    // Montgomery reduction of the 28-column accumulator (operand scanning), R = 2^392
+    // Montgomery reduction of this lane's half of the sum (operand scanning), R = 2^392
 #pragma unroll
     for (int k = 0; k < 14; k++) {
         const uint32_t m = ((uint32_t)acc[k] * FP_N0_28) & FP28_MASK;
@@ -148,6 +138,16 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
     }
     carry += acc[27];
     r.l[13] = (uint32_t)carry;
+    // The reduction is linear, so the two lanes of a coefficient (lane ^ 16) reduce their halves separately and
+    // exchange 14 reduced limbs instead of 28 64-bit columns.  v_permlane16_swap exchanges the odd 16-lane rows of
+    // its first operand with the even rows of its second: called on two copies of a register, one copy ends up
+    // holding (own | partner) and the other (partner | own) by row, so their sum is own + partner in every lane.
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(r.l[i], r.l[i], false, false);
+        r.l[i] = sw[0] + sw[1];
+    }
+    f28_carry(r);   // value < 2 * 1.33 p, limbs back below 2^28
     return f28_pack(r);
 }
 template <int NT, bool TRIPLE>

@@ -71,7 +71,7 @@ def build_program():
 
 def check_bounds(prog):
     """Static check of the value bounds the kernel's lazily reduced field relies on (h2v_pairing_coop.cuh): with
-    `v` = the multiple of p a variable may reach, engine results are 2, CONJ needs v <= 5 and gives 6, FROB gives 5,
+    `v` = the multiple of p a variable may reach, engine results are 3, CONJ needs v <= 5 and gives 6, FROB gives 5,
     and every staged operand needs v <= 6."""
     v = [None] * N_VARS
     for op, d, a, b in prog:
@@ -81,13 +81,13 @@ def check_bounds(prog):
             v[d] = 1
         elif op == OP_MUL:
             assert v[a] <= 6 and v[b] <= 6
-            v[d] = 2
+            v[d] = 3
         elif op == OP_CSQR:
             assert v[a] <= 6
-            v[d] = 2
+            v[d] = 3
         elif op == OP_LINE:
             assert v[F] <= 6
-            v[F] = 2
+            v[F] = 3
         elif op == OP_CONJ:
             assert v[a] <= 5, "CONJ of a value that is not an engine / FROB result"
             v[d] = 6
@@ -96,7 +96,7 @@ def check_bounds(prog):
             v[d] = 5
         elif op == OP_INV:
             assert v[a] <= 5
-            v[d] = 2
+            v[d] = 3
         elif op == OP_MOV:
             v[d] = v[a]
         elif op == OP_WARMUP:
