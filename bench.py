@@ -244,6 +244,21 @@ def cpu_baseline(vk, batch, pl, sample, gpu_accept):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # a container may see every host CPU but be allowed only a share of them (cgroup v2 cpu.max / v1 cfs quota):
+    # threads beyond the share only time-slice, so the thread count follows the share
+    try:
+        quota = None
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = None if q == "max" else float(q) / float(per)
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+        if quota:
+            cores = max(1, min(cores, int(quota + 0.5)))
+    except Exception:
+        pass
     n = min(max(sample, 8 * cores), batch.n)  # at least 8 proofs per thread
     n_pi = vk.n_public_inputs
     proofs = batch.proofs[:batch.proof_off[n]]
