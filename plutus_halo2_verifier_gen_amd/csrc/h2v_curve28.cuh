@@ -32,26 +32,32 @@ H2V_DI void g1j28_to_g1j(G1J &r, const G1J28 &p, const bool inf) {
 }
 // dbl-2009-l, 2M + 5S.  p must not be infinity and must not have y == 0 (no 2-torsion on these curves: the group
 // order is odd).  In: X (<=43, 1), Y (<=45, 1), Z (v_Y v_Z <= 2048, lam <= 2).  Out: X (31,1) Y (19,1) Z (4,2).
-H2V_DI void g1j28_dbl(G1J28 &r, const G1J28 &p) {
+#define F28_MUL_(r, a, b) do { if (INL) f28_mul_inl(r, a, b); else f28_mul(r, a, b); } while (0)
+#define F28_SQR_(r, a) do { if (INL) f28_sqr_inl(r, a); else f28_sqr(r, a); } while (0)
+template <bool INL>
+H2V_DI void g1j28_dbl_t(G1J28 &r, const G1J28 &p) {
     F28 X = p.x, Y = p.y, Z = p.z, A, B, C, D, t;
-    f28_mul(Z, Y, Z); f28_mul_small<2>(Z, Z);        // Z3 = 2 Y Z                      (4, 2)
-    f28_sqr(A, X);                                   // A = X^2                          (2, 1)
-    f28_sqr(B, Y);                                   // B = Y^2                          (2, 1)
-    f28_add(t, X, B); f28_sqr(t, t);                 // (X + B)^2, operand (v_X+2, 2)    (2, 1)
-    f28_sqr(C, B);                                   // C = B^2                          (2, 1)
+    F28_MUL_(Z, Y, Z); f28_mul_small<2>(Z, Z);        // Z3 = 2 Y Z                      (4, 2)
+    F28_SQR_(A, X);                                   // A = X^2                          (2, 1)
+    F28_SQR_(B, Y);                                   // B = Y^2                          (2, 1)
+    f28_add(t, X, B); F28_SQR_(t, t);                 // (X + B)^2, operand (v_X+2, 2)    (2, 1)
+    F28_SQR_(C, B);                                   // C = B^2                          (2, 1)
     f28_add(D, A, C);                                //                                  (4, 2)
     F28_SUB(t, t, D, 5, 2);                          // (X+B)^2 - A - C                  (7, 5)
     f28_mul_small<2>(D, t); f28_carry(D);            // D                                (14, 1)
     f28_mul_small<3>(A, A);                          // E = 3A                           (6, 3)
-    f28_sqr(X, A);                                   // E^2   lam 9, v 36                (2, 1)
+    F28_SQR_(X, A);                                   // E^2   lam 9, v 36                (2, 1)
     f28_mul_small<2>(t, D);                          // 2D                               (28, 2)
     F28_SUB(X, X, t, 29, 2); f28_carry(X);           // X3 = E^2 - 2D                    (31, 1)
     F28_SUB(t, D, X, 32, 1);                         // D - X3                           (46, 4)
-    f28_mul(Y, A, t);                                // E (D - X3)  lam 12, v 276        (2, 1)
+    F28_MUL_(Y, A, t);                                // E (D - X3)  lam 12, v 276        (2, 1)
     f28_mul_small<8>(C, C);                          // 8C                               (16, 8)
     F28_SUB(Y, Y, C, 17, 8); f28_carry(Y);           // Y3                               (19, 1)
     r.x = X; r.y = Y; r.z = Z;
 }
+#undef F28_MUL_
+#undef F28_SQR_
+H2V_DI void g1j28_dbl(G1J28 &r, const G1J28 &p) { g1j28_dbl_t<false>(r, p); }
 // r = p + (neg_q ? -q : q), 12M + 4S; neither operand is infinity (the callers keep the flags).
 // Returns 0: generic sum in r; 1: p == +-q with equal y -> r = 2p; 2: p == -(+-q) -> the sum is infinity (r untouched).
 // In: both operands with the stored-point bounds.  Out: X (10,1) Y (5,1) Z (2,1).
@@ -111,7 +117,7 @@ H2V_DN void g1j28_mul_x_abs(G1J28 &r, bool &r_inf, const G1J28 &p, const bool p_
     bool inf = p_inf;
 #pragma unroll 1
     for (int i = 62; i >= 0; i--) {
-        if (!inf) g1j28_dbl(acc, acc);
+        if (!inf) g1j28_dbl_t<true>(acc, acc);   // the chain's 63 doublings with the multiplier inlined
         if (((BLS_X_ABS >> i) & 1) && !p_inf) g1j28_acc_add(acc, inf, p, false);
     }
     r = acc;

@@ -61,6 +61,9 @@ H2V_DI void f28_sqr(F28 &r, const F28 &a) {
     const F28Regs z = f28_sqr_raw(x.a, x.b, x.c, x.d);
     r = f28_unpack(z.a, z.b, z.c, z.d);
 }
+// inlined forms (no call, no argument marshalling) for the one loop that is short enough to afford the code size
+H2V_DI void f28_mul_inl(F28 &r, const F28 &a, const F28 &b) { F28 t; fp_mont28(t.l, a.l, b.l); r = t; }
+H2V_DI void f28_sqr_inl(F28 &r, const F28 &a) { F28 t; fp_montsqr28(t.l, a.l); r = t; }
 H2V_DI void f28_add(F28 &r, const F28 &a, const F28 &b) {
 #pragma unroll
     for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + b.l[i];

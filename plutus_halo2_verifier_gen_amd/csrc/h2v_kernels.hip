@@ -513,7 +513,7 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
             for (int q = 32; q >= 0; q--) {
                 if (q != 32 && !lad_inf) {
 #pragma unroll 1
-                    for (int rep = 0; rep < 4; rep++) g1j28_dbl(lad, lad);
+                    for (int rep = 0; rep < 4; rep++) g1j28_dbl_t<true>(lad, lad);   // multiplier inlined: no argument marshalling
                 }
                 const int d = dg[q];
                 if (d != 0) g1j28_acc_add(lad, lad_inf, tab[(d < 0 ? -d : d) - 1], d < 0);
