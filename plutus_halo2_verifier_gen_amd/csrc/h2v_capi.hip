@@ -233,6 +233,7 @@ static void ws_release(h2v_workspace *w) {
     for (hipEvent_t e : w->ev_done) if (e) (void)hipEventDestroy(e);
     for (auto &call : w->ring) for (auto &set : call) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
 }
+static uint32_t vm_lds_slots(const H2vDevPlan &d);
 static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bool with_trace, h2v_workspace **out) {
     if (max_batch == 0 || max_batch > (1ull << 24)) return fail(H2V_E_ARG, "max_batch out of range");
     HIPCHK(hipSetDevice(device));
@@ -243,7 +244,7 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     const uint64_t slots = H2V_SLOTS(d);
 #define WSALLOC(field, bytes)                                                                  \
     if (hipMalloc((void **)&w->field, (bytes)) != hipSuccess) { ws_release(w); delete w; return fail(H2V_E_DEVICE, "hipMalloc(" #field ") failed"); }
-    WSALLOC(regs, (size_t)d.n_regs * 8 * w->stride * 4)
+    if (vm_lds_slots(d) == 0) { WSALLOC(regs, (size_t)d.n_regs * 8 * w->stride * 4) }  // else the register file lives in LDS
     WSALLOC(scalars, (size_t)max_batch * d.n_terms * 32)
     WSALLOC(pts, (size_t)max_batch * slots * 96)
     WSALLOC(valid, (size_t)max_batch * slots)
@@ -279,6 +280,27 @@ extern "C" void h2v_workspace_free(h2v_workspace *w) {
     if (!w) return;
     ws_release(w);
     delete w;
+}
+
+// Transcript + combiner launch: register file in LDS when P >= 8 proofs per block fit beside the 8 KB hash buffer
+// (160 KB of LDS per CU; the kernel has 64 waves' worth of work, so one block per CU is all it ever needs), otherwise in
+// the workspace's global buffer.
+static uint32_t vm_lds_slots(const H2vDevPlan &d) {
+    uint32_t P = 64;
+    while (P >= 8 && (size_t)d.n_regs * 32 * P + 8192 + 1024 > 160 * 1024) P >>= 1;
+    return P >= 8 ? P : 0;
+}
+static int launch_vm(const H2vDevPlan &d, uint32_t n, uint32_t stride, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst,
+                     const uint8_t *ci, uint32_t *regs, uint32_t *scalars, uint32_t *status, uint32_t *trace, hipStream_t st) {
+    const uint32_t P = vm_lds_slots(d);
+    if (P == 0) {
+        hipLaunchKernelGGL(k_transcript_combiner, dim3((n + 63) / 64), dim3(64), 0, st, d, n, stride, proofs, off, inst, ci, regs, scalars, status, trace);
+        return H2V_OK;
+    }
+    const size_t lds = (size_t)d.n_regs * 32 * P;
+    HIPCHK(hipFuncSetAttribute((const void *)k_transcript_combiner_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_transcript_combiner_lds, dim3((n + P - 1) / P), dim3(64), lds, st, d, n, P, proofs, off, inst, ci, scalars, status, trace);
+    return H2V_OK;
 }
 
 // MSM launch geometry: 2 lanes per (proof, term); block = max(64, 2*tp) threads, LDS 144 B per thread.
@@ -352,7 +374,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipDeviceSynchronize());                                                         \
         fprintf(stderr, "[h2v] %s done\n", name); fflush(stderr);
         DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(128), 0, st, d, n, proofs, off, ci, inst, w->pts, w->valid))
-        DBG_STAGE("k_transcript_combiner", hipLaunchKernelGGL(k_transcript_combiner, dim3(vm_blocks), dim3(64), 0, st, d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace))
+        DBG_STAGE("k_transcript_combiner", { int rcv = launch_vm(d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace, st); if (rcv) return rcv; })
         DBG_STAGE("k_g1_msm", launch_msm(d, n, w->scalars, w->pts, w->er, w->msm_tab, st))
         if (d.ivc) {
             const IvcBufs ib = {w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2};
@@ -392,7 +414,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipEventRecord(ev[3], ps));
         HIPCHK(hipEventRecord(w->ev_join[k], ps));
         HIPCHK(hipEventRecord(ev[0], pm));
-        hipLaunchKernelGGL(k_transcript_combiner, dim3((m + 63) / 64), dim3(64), 0, pm, d, m, w->stride, proofs, off_k, inst_k, ci_k, regs_k, scal_k, status_k, trace);
+        { int rcv = launch_vm(d, m, w->stride, proofs, off_k, inst_k, ci_k, regs_k, scal_k, status_k, trace, pm); if (rcv) return rcv; }
         HIPCHK(hipEventRecord(ev[1], pm));
         HIPCHK(hipStreamWaitEvent(pm, w->ev_join[k], 0));
         HIPCHK(hipEventRecord(ev[4], pm));

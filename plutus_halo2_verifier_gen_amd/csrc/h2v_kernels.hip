@@ -129,6 +129,27 @@ H2V_DI void reg_store(uint32_t *regs, uint32_t r, uint32_t stride, uint32_t i, c
 #pragma unroll
     for (int l = 0; l < 8; l++) regs[(size_t)(r * 8 + l) * stride + i] = v.v[l];
 }
+// The same register file in LDS when the plan is small enough for a few dozen proofs per CU: limb l of register r of
+// the block's proof slot q at vm_lds[(r*8 + l)*P + q].  With 64 waves on a 256-CU chip this kernel is pure latency, and
+// a dependent global load + store per instruction was most of it.
+extern __shared__ uint32_t vm_lds[];
+struct RegsGlobal {
+    uint32_t *regs;
+    uint32_t stride, i_load, i_store;
+    H2V_DI void load(Fr &v, uint32_t r) const { reg_load(v, regs, r, stride, i_load); }
+    H2V_DI void store(uint32_t r, const Fr &v) const { reg_store(regs, r, stride, i_store, v); }
+};
+struct RegsLds {
+    uint32_t P, q;
+    H2V_DI void load(Fr &v, uint32_t r) const {
+#pragma unroll
+        for (int l = 0; l < 8; l++) v.v[l] = vm_lds[(r * 8 + l) * P + q];
+    }
+    H2V_DI void store(uint32_t r, const Fr &v) const {
+#pragma unroll
+        for (int l = 0; l < 8; l++) vm_lds[(r * 8 + l) * P + q] = v.v[l];
+    }
+};
 H2V_DI void fr_const(Fr &v, const uint32_t *c) {
 #pragma unroll
     for (int l = 0; l < 8; l++) v.v[l] = c[l];
@@ -140,16 +161,11 @@ H2V_DI void tr_absorb_scalar(Transcript &s, uint32_t *sbuf, int lane, const Fr &
     for (int k = 0; k < 32; k++) tr_put(s, sbuf, lane, (plain.v[k >> 2] >> (8 * (k & 3))) & 0xff);
 }
 
-extern "C" __global__ void __launch_bounds__(64)
-k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_t *__restrict__ proofs,
-                      const uint64_t *__restrict__ proof_off, const uint8_t *__restrict__ instances,
-                      const uint8_t *__restrict__ committed, uint32_t *__restrict__ regs,
-                      uint32_t *__restrict__ scalars, uint32_t *__restrict__ status, uint32_t *__restrict__ trace) {
-    __shared__ uint32_t sbuf[32 * 64];
-    const int lane = threadIdx.x;
-    const uint32_t i = blockIdx.x * 64 + lane;
-    const bool live = i < n;
-    const uint32_t ii = live ? i : n - 1;  // dead lanes shadow the last proof (keeps control flow uniform), never write
+template <class RF>
+H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const int lane, const uint32_t i, const uint32_t ii,
+                   const bool live, const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
+                   const uint8_t *__restrict__ instances, const uint8_t *__restrict__ committed,
+                   uint32_t *__restrict__ scalars, uint32_t *__restrict__ status, uint32_t *__restrict__ trace) {
     const uint64_t off0 = proof_off[ii];
     const uint64_t plen = proof_off[ii + 1] - off0;
     uint32_t st = 0;
@@ -165,7 +181,7 @@ k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_
         if (ins.op == H2V_OP_END) break;
         switch (ins.op) {
         case H2V_OP_ABSORB_REG: {
-            reg_load(a, regs, ins.a, stride, ii);
+            rf.load(a, ins.a);
             FrF::from_mont(b, a);
             tr_absorb_scalar(tr, sbuf, lane, b);
         } break;
@@ -180,7 +196,7 @@ k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_
             for (int l = 0; l < 8; l++)
                 b.v[l] = (uint32_t)p[4 * l] | ((uint32_t)p[4 * l + 1] << 8) | ((uint32_t)p[4 * l + 2] << 16) | ((uint32_t)p[4 * l + 3] << 24);
             FrF::to_mont(r, b);  // public inputs are field elements handed over by the caller: reduced mod r
-            if (live) reg_store(regs, ins.dst, stride, i, r);
+            if (live) rf.store(ins.dst, r);
         } break;
         case H2V_OP_READ_POINT: {
             const uint32_t off = (uint32_t)ins.a | ((uint32_t)ins.b << 16);
@@ -202,7 +218,7 @@ k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_
             // canonical encodings only: the Rust reader (and Plinth's mkScalar, BlsTypes.hs:129-132) rejects >= r
             if (FrF::geq_mod(b.v)) st |= H2V_ST_BAD_SCALAR;
             FrF::to_mont(r, b);
-            if (live) reg_store(regs, ins.dst, stride, i, r);
+            if (live) rf.store(ins.dst, r);
         } break;
         case H2V_OP_SQUEEZE: {
             // adjusted_types/mod.rs:44-71: update(0x00); h = finalize; h2 = blake2b256(h);
@@ -221,37 +237,37 @@ k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_
             fr_const(k, FR_R3);
             fr_mul(b, hi, k);  // hi * 2^768 / 2^256 = (hi * 2^256) * R
             fr_add(r, a, b);
-            if (live) reg_store(regs, ins.dst, stride, i, r);
+            if (live) rf.store(ins.dst, r);
         } break;
         case H2V_OP_CONST: {
             fr_const(r, plan.consts + (size_t)ins.a * 8);
-            if (live) reg_store(regs, ins.dst, stride, i, r);
+            if (live) rf.store(ins.dst, r);
         } break;
         case H2V_OP_ADD: case H2V_OP_SUB: case H2V_OP_MUL: {
-            reg_load(a, regs, ins.a, stride, ii);
-            reg_load(b, regs, ins.b, stride, ii);
+            rf.load(a, ins.a);
+            rf.load(b, ins.b);
             if (ins.op == H2V_OP_ADD) fr_add(r, a, b);
             else if (ins.op == H2V_OP_SUB) fr_sub(r, a, b);
             else fr_mul(r, a, b);
-            if (live) reg_store(regs, ins.dst, stride, i, r);
+            if (live) rf.store(ins.dst, r);
         } break;
         case H2V_OP_NEG: {
-            reg_load(a, regs, ins.a, stride, ii);
+            rf.load(a, ins.a);
             FrF::neg(r, a);
-            if (live) reg_store(regs, ins.dst, stride, i, r);
+            if (live) rf.store(ins.dst, r);
         } break;
         case H2V_OP_INV: {
-            reg_load(a, regs, ins.a, stride, ii);
+            rf.load(a, ins.a);
             // recip_eea of zero divides by zero in the reference (bls_utils.ak:151-154) => reject
             if (!fr_inv(r, a)) st |= H2V_ST_INVERSE_OF_ZERO;
-            if (live) reg_store(regs, ins.dst, stride, i, r);
+            if (live) rf.store(ins.dst, r);
         } break;
         case H2V_OP_ASSERT_ZERO: {
-            reg_load(a, regs, ins.a, stride, ii);
+            rf.load(a, ins.a);
             if (!FrF::is_zero(a)) st |= H2V_ST_RECURSION;   // expect transcript_rep == i_1 (emitters/aiken.rs:696)
         } break;
         case H2V_OP_OUT_SCALAR: {
-            reg_load(a, regs, ins.a, stride, ii);
+            rf.load(a, ins.a);
             FrF::from_mont(r, a);
             if (live) {
 #pragma unroll
@@ -265,13 +281,43 @@ k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_
         status[i] = st;
         if (trace) {
             for (uint32_t k = 0; k < plan.n_trace; k++) {
-                reg_load(a, regs, plan.trace[2 * k + 1], stride, i);
+                rf.load(a, plan.trace[2 * k + 1]);
                 FrF::from_mont(r, a);
 #pragma unroll
                 for (int l = 0; l < 8; l++) trace[((size_t)i * plan.n_trace + k) * 8 + l] = r.v[l];
             }
         }
     }
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_t *__restrict__ proofs,
+                      const uint64_t *__restrict__ proof_off, const uint8_t *__restrict__ instances,
+                      const uint8_t *__restrict__ committed, uint32_t *__restrict__ regs,
+                      uint32_t *__restrict__ scalars, uint32_t *__restrict__ status, uint32_t *__restrict__ trace) {
+    __shared__ uint32_t sbuf[32 * 64];
+    const int lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * 64 + lane;
+    const bool live = i < n;
+    const uint32_t ii = live ? i : n - 1;  // dead lanes shadow the last proof (keeps control flow uniform), never write
+    const RegsGlobal rf = {regs, stride, ii, i};
+    vm_run(plan, rf, sbuf, lane, i, ii, live, proofs, proof_off, instances, committed, scalars, status, trace);
+}
+// P proofs per block (power of two, <= 64), register file in dynamic LDS: P * n_regs * 32 bytes
+extern "C" __global__ void __launch_bounds__(64)
+k_transcript_combiner_lds(H2vDevPlan plan, uint32_t n, uint32_t P, const uint8_t *__restrict__ proofs,
+                          const uint64_t *__restrict__ proof_off, const uint8_t *__restrict__ instances,
+                          const uint8_t *__restrict__ committed, uint32_t *__restrict__ scalars,
+                          uint32_t *__restrict__ status, uint32_t *__restrict__ trace) {
+    __shared__ uint32_t sbuf[32 * 64];
+    const int lane = threadIdx.x;
+    const uint32_t q = (uint32_t)lane & (P - 1);            // lanes >= P shadow slot q: same proof, never write
+    const uint32_t i = blockIdx.x * P + q;
+    const bool live = (uint32_t)lane < P && i < n;
+    const uint32_t ii = i < n ? i : n - 1;
+    // a dead slot of the last block shadows proof n-1 but must not touch a live slot's registers: it owns slot q anyway
+    const RegsLds rf = {P, q};
+    vm_run(plan, rf, sbuf, lane, i, ii, live, proofs, proof_off, instances, committed, scalars, status, trace);
 }
 
 // ============================================================================ K2: G1 decompression
