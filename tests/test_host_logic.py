@@ -316,3 +316,62 @@ def test_safegcd_model():
             worst = max(worst, batches)
         assert worst <= 32
     assert arr("FP_R3") == [(pow(2, 3 * bls.MONT_BITS_FP, bls.P) >> (32 * i)) & 0xFFFFFFFF for i in range(12)]
+
+
+def test_plan_loader_rejects_mutated_blobs_without_a_gpu():
+    """h2v_plan_load validates a blob completely on the host before any device work (an out-of-range register, offset or
+    term index would become an out-of-bounds access inside a kernel).  Mutated blobs must come back as H2V_E_PLAN /
+    H2V_E_LIMIT - or, when the mutation happens to leave a valid plan, as H2V_E_DEVICE on this GPU-less box - and never
+    crash the process."""
+    import struct
+    from plutus_halo2_verifier_gen_amd import backend
+    L = ctypes.CDLL(os.path.join(ROOT, "plutus_halo2_verifier_gen_amd", "libh2v_hip.so"))
+    L.h2v_plan_load.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.h2v_plan_load.restype = ctypes.c_int
+    L.h2v_plan_free.argtypes = [ctypes.c_void_p]
+    have_gpu = backend.device_count() >= 1
+    E_ARG, E_PLAN, E_DEVICE, E_LIMIT = -1, -2, -3, -4
+
+    def load(blob):
+        h = ctypes.c_void_p()
+        rc = L.h2v_plan_load(bytes(blob), len(blob), 0, ctypes.byref(h))
+        if rc == 0:
+            L.h2v_plan_free(h)
+        return rc
+
+    rng = random.Random(11)
+    for name in ("simple_mul", "ivc"):
+        vk, _ = V.BUILDERS[name]()
+        blob = PL.compile_plan(vk).to_bytes()
+        ok_rc = 0 if have_gpu else E_DEVICE
+        assert load(blob) == ok_rc
+        hdr_words = PL.PLAN_HDR_WORDS
+        w = list(struct.unpack_from("<%dI" % hdr_words, blob, 8))
+        # every header word set to hostile values
+        for k in range(hdr_words):
+            for val in (0, 1, 0x7FFFFFFF, 0xFFFFFFFF, w[k] + 1, w[k] + 16, max(0, w[k] - 1)):
+                if val == w[k]:
+                    continue
+                m = bytearray(blob)
+                struct.pack_into("<I", m, 8 + 4 * k, val & 0xFFFFFFFF)
+                assert load(m) in (E_PLAN, E_LIMIT, ok_rc), (name, k, val)
+        # instruction stream: every field of random instructions
+        off_instr, n_instr = w[14], w[5]
+        for _ in range(400):
+            m = bytearray(blob)
+            pos = off_instr + 8 * rng.randrange(n_instr) + rng.randrange(8)
+            m[pos] = rng.randrange(256)
+            assert load(m) in (E_PLAN, E_LIMIT, ok_rc)
+        # term table and point offsets
+        for sec_word, count_word, rec in ((18, 9, 8), (16, 7, 4), (21, 10, 8)):
+            for _ in range(100):
+                m = bytearray(blob)
+                if w[count_word] == 0:
+                    break
+                pos = w[sec_word] + rec * rng.randrange(w[count_word]) + rng.randrange(rec)
+                m[pos] = rng.randrange(256)
+                assert load(m) in (E_PLAN, E_LIMIT, ok_rc)
+        # truncations and garbage
+        for cut in (0, 7, 8, 100, len(blob) // 2, len(blob) - 1):
+            assert load(blob[:cut]) in (E_PLAN, E_ARG)
+        assert load(bytes(rng.randrange(256) for _ in range(4096))) == E_PLAN
