@@ -141,6 +141,15 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok_all = bool(flag.item())
 
+    # second dataset (untimed): 1 % of the proofs get the reference example's byte flip (examples/simple_mul.rs:87-95,
+    # first scalar of the proof) - exactly those proofs must be rejected
+    reject_check = None
+    if rank == 0:
+        rej = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.01, seed=77, kinds=["flip_first_scalar"])
+        got = dp.verify_batch(rej.proofs, rej.proof_off, rej.instances, rej.committed, ws=ws)
+        reject_check = {"fraction": 0.01, "corrupted": rej.expected.count(0), "rejected": int(B - sum(got)),
+                        "exactly_the_corrupted_ones": list(got) == rej.expected}
+
     if rank == 0:
         T = pl.n_terms
         slots = len(pl.points) + pl.n_ci
@@ -151,7 +160,12 @@ def main():
             "transcript_combiner": B * (pl.proof_len + 32 * pl.n_pi + 48 * pl.n_ci + 32 * T + 4),
             "pairing": B * (96 + 144 + 1 + 4) + 2 * 68 * 192,
         }
-        kname = {"g1_msm": "k_g1_msm", "g1_decompress": "k_g1_decompress", "transcript_combiner": "k_transcript_combiner",
+        # the combiner keeps its Fr register file in LDS when >= 8 proofs per block fit (h2v_capi.hip: vm_lds_slots)
+        lds_slots = 64
+        while lds_slots >= 8 and pl.n_regs * 32 * lds_slots + 8192 + 1024 > 160 * 1024:
+            lds_slots >>= 1
+        kname = {"g1_msm": "k_g1_msm", "g1_decompress": "k_g1_decompress",
+                 "transcript_combiner": "k_transcript_combiner_lds" if lds_slots >= 8 else "k_transcript_combiner",
                  "pairing": "k_pairing_coop" if os.environ.get("H2V_PAIRING") != "legacy" else "k_pairing_check"}
 
         def pmc_traffic(kernel):
@@ -218,6 +232,7 @@ def main():
             "kernel_ms": {kname[k]: round(v, 4) for k, v in kernel_ms.items()},
             "pipelines_per_step": launches,
             "all_accepted": ok_all,
+            "reject_dataset": reject_check,
             "forge_seconds": round(t_forge, 2),
         }
         if not args.no_cpu_baseline and world == 1:
