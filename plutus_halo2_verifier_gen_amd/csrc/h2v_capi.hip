@@ -305,7 +305,7 @@ static int launch_vm(const H2vDevPlan &d, uint32_t n, uint32_t stride, const uin
 
 // MSM launch geometry: 2 lanes per (proof, term); block = max(64, 2*tp) threads, LDS 144 B per thread.
 static void launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const uint32_t *scalars, const uint32_t *pts,
-                             uint32_t *out, uint32_t *tabws, hipStream_t st) {
+                             uint32_t *tabws, hipStream_t st) {
     // 2 lanes per term; block = the multiple of 64 (<= 512) that wastes the smallest fraction of its lanes
     const uint32_t lpp = 2 * ma.n_terms;
     uint32_t bs = 64, best_waste = ~0u;
@@ -316,29 +316,30 @@ static void launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t
     }
     const uint32_t per_block = bs / lpp;
     const uint32_t blocks = (n + per_block - 1) / per_block;
-    hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 144, st, d, ma, n, per_block, scalars, pts, out, tabws);
+    hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 144, st, d, ma, n, per_block, scalars, pts, tabws);
 }
-// the proof's own MSM: terms [0, n_main_terms) of the plan's table, scalars from the combiner, points from decompression
-static void launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, uint32_t *er, uint32_t *tabws, hipStream_t st) {
-    const H2vMsmArgs ma = {d.terms, 0, d.n_main_terms, d.n_terms, 0, H2V_SLOTS(d)};
-    launch_msm_range(d, ma, n, scalars, pts, er, tabws, st);
+// the proof's own MSM: terms [0, n_main_terms) of the plan's table, scalars from the combiner, points from decompression.
+// A recursive plan sums acc_left and acc_right + fixed bases in the same launch (three groups, three outputs).
+static void launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, uint32_t *er,
+                       uint32_t *accl, uint32_t *accr, uint32_t *tabws, hipStream_t st) {
+    H2vMsmArgs ma = {d.terms, 0, d.n_main_terms, d.n_terms, 0, H2V_SLOTS(d), {d.n_main_terms, d.n_main_terms, d.n_main_terms}, {er, nullptr, nullptr}};
+    if (d.ivc) {
+        ma.n_terms = d.n_terms;
+        ma.grp_end[0] = d.n_main_terms; ma.grp_end[1] = d.n_main_terms + 1; ma.grp_end[2] = d.n_terms;
+        ma.out[1] = accl; ma.out[2] = accr;
+    }
+    launch_msm_range(d, ma, n, scalars, pts, tabws, st);
 }
-// Recursion (IVC) fold between the MSM and the pairing (emitters/aiken.rs:696-757): acc_left, acc_right + fixed bases,
-// the batching challenge, then el' = el + c acc_left and er' = er + c acc_right_final.  Pointers are the chunk's.
+// Recursion (IVC) fold between the MSM and the pairing (emitters/aiken.rs:696-757): the batching challenge from
+// (el, er, acc_left, acc_right_final), then el' = el + c acc_left and er' = er + c acc_right_final in one two-group
+// launch over the fold's own point / scalar buffers.  Pointers are the chunk's.
 struct IvcBufs { uint32_t *accl, *accr, *fold_pts, *fold_scal, *el2, *er2; };
-static void launch_ivc_fold(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, const uint32_t *er,
+static void launch_ivc_fold(const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint32_t *er,
                             const IvcBufs &b, uint32_t *tabws, hipStream_t st) {
-    const uint32_t slots = H2V_SLOTS(d);
-    const H2vMsmArgs left = {d.terms, d.n_main_terms, 1, d.n_terms, d.n_main_terms, slots};
-    const H2vMsmArgs right = {d.terms, d.n_main_terms + 1, d.n_terms - d.n_main_terms - 1, d.n_terms, d.n_main_terms + 1, slots};
-    launch_msm_range(d, left, n, scalars, pts, b.accl, tabws, st);
-    launch_msm_range(d, right, n, scalars, pts, b.accr, tabws, st);
     hipLaunchKernelGGL(k_ivc_challenge, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, er, b.accl, b.accr, b.fold_pts, b.fold_scal);
-    const H2vMsmArgs fl = {d.fold_terms, 0, 2, 4, 0, 4}, fr = {d.fold_terms, 2, 2, 4, 2, 4};
-    launch_msm_range(d, fl, n, b.fold_scal, b.fold_pts, b.el2, tabws, st);
-    launch_msm_range(d, fr, n, b.fold_scal, b.fold_pts, b.er2, tabws, st);
+    const H2vMsmArgs fold = {d.fold_terms, 0, 4, 4, 0, 4, {2, 4, 4}, {b.el2, b.er2, nullptr}};
+    launch_msm_range(d, fold, n, b.fold_scal, b.fold_pts, tabws, st);
 }
-
 // Pairing kernel selection: the cooperative 16-lanes-per-proof kernel is the product path; the one-lane-per-proof
 // kernel stays as a cross-check (H2V_PAIRING=legacy, or impl = 0 in the probe).
 static void launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint32_t *er,
@@ -375,10 +376,10 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         fprintf(stderr, "[h2v] %s done\n", name); fflush(stderr);
         DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(128), 0, st, d, n, proofs, off, ci, inst, w->pts, w->valid))
         DBG_STAGE("k_transcript_combiner", { int rcv = launch_vm(d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace, st); if (rcv) return rcv; })
-        DBG_STAGE("k_g1_msm", launch_msm(d, n, w->scalars, w->pts, w->er, w->msm_tab, st))
+        DBG_STAGE("k_g1_msm", launch_msm(d, n, w->scalars, w->pts, w->er, w->accl, w->accr, w->msm_tab, st))
         if (d.ivc) {
             const IvcBufs ib = {w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2};
-            DBG_STAGE("ivc fold", launch_ivc_fold(d, n, w->scalars, w->pts, w->er, ib, w->msm_tab, st))
+            DBG_STAGE("ivc fold", launch_ivc_fold(d, n, w->pts, w->er, ib, w->msm_tab, st))
         }
         DBG_STAGE("k_pairing_check", launch_pairing(d, n, w->pts, w->valid, d.ivc ? w->er2 : w->er, d.ivc ? w->el2 : nullptr, status, accept, nullptr, st))
 #undef DBG_STAGE
@@ -419,12 +420,13 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipStreamWaitEvent(pm, w->ev_join[k], 0));
         HIPCHK(hipEventRecord(ev[4], pm));
         uint32_t *tab_k = w->msm_tab + (size_t)lo * d.n_terms * 2 * 8 * 42;
-        launch_msm(d, m, scal_k, pts_k, er_k, tab_k, pm);
+        const IvcBufs ib = {d.ivc ? w->accl + (size_t)lo * 36 : nullptr, d.ivc ? w->accr + (size_t)lo * 36 : nullptr,
+                            d.ivc ? w->fold_pts + (size_t)lo * 96 : nullptr, d.ivc ? w->fold_scal + (size_t)lo * 32 : nullptr,
+                            d.ivc ? w->el2 + (size_t)lo * 36 : nullptr, d.ivc ? w->er2 + (size_t)lo * 36 : nullptr};
+        launch_msm(d, m, scal_k, pts_k, er_k, ib.accl, ib.accr, tab_k, pm);
         const uint32_t *er_in = er_k, *el_in = nullptr;
-        if (d.ivc) {   // (timed with the MSM: it is three more sums of the same kernel plus the challenge hash)
-            const IvcBufs ib = {w->accl + (size_t)lo * 36, w->accr + (size_t)lo * 36, w->fold_pts + (size_t)lo * 96, w->fold_scal + (size_t)lo * 32,
-                                w->el2 + (size_t)lo * 36, w->er2 + (size_t)lo * 36};
-            launch_ivc_fold(d, m, scal_k, pts_k, er_k, ib, tab_k, pm);
+        if (d.ivc) {   // (timed with the MSM: the challenge hash and one more pass of the same kernel)
+            launch_ivc_fold(d, m, pts_k, er_k, ib, tab_k, pm);
             er_in = ib.er2; el_in = ib.el2;
         }
         HIPCHK(hipEventRecord(ev[5], pm));
@@ -675,7 +677,7 @@ extern "C" int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_
     HIPCHK(hipMemcpy(dsc.p, scalars, (size_t)n * T * 32, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
     if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 168)) return fail(H2V_E_DEVICE, "hipMalloc failed");
-    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), dtab.as<uint32_t>(), nullptr);
+    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), nullptr, nullptr, dtab.as<uint32_t>(), nullptr);
     hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 1, der.as<uint32_t>(), dout.as<uint8_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
@@ -709,7 +711,7 @@ extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t
     HIPCHK(hipMemset(dst.p, 0, (size_t)n * 4));
     hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
     if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 168)) return fail(H2V_E_DEVICE, "hipMalloc failed");
-    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), dtab.as<uint32_t>(), nullptr);
+    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), nullptr, nullptr, dtab.as<uint32_t>(), nullptr);
     if (ddbg.alloc(dbg ? (size_t)n * 24 * 48 : 8)) return fail(H2V_E_DEVICE, "hipMalloc failed");
     launch_pairing_impl(impl, mp.d, n, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), der.as<uint32_t>(), nullptr, dst.as<uint32_t>(), dacc.as<uint8_t>(), dbg ? ddbg.as<uint32_t>() : nullptr, nullptr);
     HIPCHK(hipGetLastError());

@@ -480,13 +480,16 @@ struct H2vMsmArgs {
     uint32_t scal_stride;      // scalars per proof in `scalars`
     uint32_t scal_col_base;    // column of the range's first term
     uint32_t slots;            // point slots per proof in `pts`
+    // the range is cut into up to three consecutive groups, each summed into its own output (recursion: the proof's
+    // MSM, acc_left and acc_right + fixed bases in ONE launch): group g = terms [grp_end[g-1], grp_end[g])
+    uint32_t grp_end[3];
+    uint32_t *out[3];          // n x 36 dwords each (Jacobian); unused groups: grp_end == n_terms
 };
 // A proof owns exactly 2 * n_terms consecutive lanes of a block (no power-of-two padding: 34 terms used to occupy
 // 128 lanes); the block holds as many whole proofs as fit, the rest of its lanes idle.
 extern "C" __global__ void __launch_bounds__(512, 2)
 k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
-         const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ out,
-         uint32_t *__restrict__ tabws) {
+         const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];  // Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t]
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
     const uint32_t lanes_per_proof = 2 * ma.n_terms;
@@ -495,6 +498,10 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
     const uint32_t term = sub >> 1, half = sub & 1;
     const uint32_t i = blockIdx.x * per_block + seg;
     const bool active = seg < per_block && i < n;
+    // this lane's group: position and length of its reduction segment inside the proof's lanes
+    const uint32_t grp = term < ma.grp_end[0] ? 0u : (term < ma.grp_end[1] ? 1u : 2u);
+    const uint32_t g_lo = grp == 0 ? 0u : ma.grp_end[grp - 1];
+    const uint32_t gsub = sub - 2 * g_lo, glen = 2 * (ma.grp_end[grp] - g_lo);
     G1J acc;
     g1j_set_inf(acc);
     if (active) {
@@ -567,7 +574,7 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
             g1j28_to_g1j(acc, lad, lad_inf);
         }
     }
-    // segmented reduction over the 2*tp lanes of each proof
+    // segmented reduction over the lanes of each (proof, group)
 #pragma unroll
     for (int k = 0; k < 12; k++) {
         red[k * bs + tid] = acc.x.v[k];
@@ -578,7 +585,7 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
     uint32_t top = 1;
     while (top < lanes_per_proof) top <<= 1;
     for (uint32_t s = top >> 1; s >= 1; s >>= 1) {
-        if (seg < per_block && sub < s && sub + s < lanes_per_proof) {
+        if (seg < per_block && gsub < s && gsub + s < glen) {
             G1J other;
 #pragma unroll
             for (int k = 0; k < 12; k++) {
@@ -596,7 +603,8 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
         }
         __syncthreads();
     }
-    if (sub == 0 && seg < per_block && i < n) {
+    if (gsub == 0 && seg < per_block && i < n) {
+        uint32_t *out = grp == 0 ? ma.out[0] : (grp == 1 ? ma.out[1] : ma.out[2]);
 #pragma unroll
         for (int k = 0; k < 12; k++) {
             out[(size_t)i * 36 + k] = acc.x.v[k];
