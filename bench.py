@@ -242,6 +242,7 @@ def main():
         print(json.dumps(result))
         sys.stdout.flush()
     if world > 1:
+        dist.barrier()   # rank 0 is still checking the reject dataset / printing: leave together
         dist.destroy_process_group()
     if not ok_all:
         raise SystemExit("bench: GPU rejected proofs of an all-accepting synthetic batch")
