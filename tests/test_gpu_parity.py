@@ -346,3 +346,26 @@ def test_exported_artefact_files_verify_on_gpu(be, circuits, tmp_path, capsys):
     swapped = [a.replace("pi0", "piX").replace("pi1", "pi0").replace("piX", "pi1") for a in args]
     assert verify_files.main(swapped) == 1
     assert capsys.readouterr().out.count("reject") == 2
+
+
+@pytest.mark.parametrize("name,n", [("lookup_table", 2048), ("atms_with_lookups", 2048), ("sha256", 1024), ("secp256k1", 512),
+                                    ("ivc", 1024)])
+def test_baseline_config_sizes(be, circuits, name, n):
+    """The other BASELINE configurations at their full batch sizes: the verdict vector equals the construction (every
+    corruption kind rejects, everything else accepts), does not depend on the order of the batch, and equals the
+    oracle's on a sample."""
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits[name]
+    n_pi = vk.n_public_inputs
+    batch = synth.forge_batch(vk, td, n, seed=90, plan=pl, workers=8)
+    batch = synth.with_rejects(pl, batch, n_pi, fraction=0.08, seed=14, kinds=list(synth.CORRUPTIONS))
+    ws = be.Workspace(dp, n)
+    got = dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws)
+    assert list(got) == batch.expected and 0 < sum(got) < n
+    order = list(range(n))
+    random.Random(15).shuffle(order)
+    perm = _permute(batch, order, n_pi)
+    assert list(dp.verify_batch(perm.proofs, perm.proof_off, perm.instances, perm.committed, ws=ws)) == [got[i] for i in order]
+    sample = sorted(random.Random(16).sample(range(n), 64))
+    sb = _permute(batch, sample, n_pi)
+    assert list(ov.verify_batch(sb.proofs, sb.proof_off, sb.instances, sb.committed, threads=16)) == [got[i] for i in sample]
