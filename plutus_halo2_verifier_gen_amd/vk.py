@@ -312,7 +312,7 @@ def _split_counts(rng, total, parts):
 
 
 def _shaped_vk(name, seed, *, k, degree, n_adv, n_fix, n_cc, lookup_arg_exprs, gate_exprs, gate_ops,
-               adv_rot_sets, n_pi, n_ci, bf=6):
+               adv_rot_sets, n_pi, n_ci, bf=6, trash_exprs=()):
     """Shape-faithful synthetic VK for circuits whose real VK cannot be extracted offline
     (needs keygen_vk; SURVEY.md §7 'Hard parts').  adv_rot_sets: per advice column the rotations queried."""
     rng = random.Random(seed)
@@ -344,8 +344,13 @@ def _shaped_vk(name, seed, *, k, degree, n_adv, n_fix, n_cc, lookup_arg_exprs, g
     while len(perm_cols) < n_cc - 1:
         perm_cols.append(("fixed", len(perm_cols) % n_fix))
     perm_cols.append(("instance", 1 if n_ci else 0))
+    # trashcans (selector expression, constraint expressions): emitters/aiken.rs:444-461
+    trash = []
+    for n_e in trash_exprs:
+        trash.append((fixed(rng.randrange(len(fq))),
+                      [_random_expr(rng, len(aq), len(fq), 1, 1, 0, 2) for _ in range(n_e)]))
     return _finish(name, rng, k=k, bf=bf, degree=degree, n_adv=n_adv, n_fix=n_fix, aq=aq, fq=fq, iq=iq,
-                   gates=gates, lookups=lookups, trash=[], perm_cols=perm_cols, n_pi=n_pi, n_ci=n_ci)
+                   gates=gates, lookups=lookups, trash=trash, perm_cols=perm_cols, n_pi=n_pi, n_ci=n_ci)
 
 
 def atms_with_lookups_vk(seed: int = 0x48325633):
@@ -377,6 +382,15 @@ def secp256k1_vk(seed: int = 0x48325635):
                       gate_ops={"mul": 641, "add": 476, "neg": 67}, adv_rot_sets=adv, n_pi=4, n_ci=1)
 
 
+def trashcan_mix_vk(seed: int = 0x48325637):
+    """Small chip mix with two trashcan arguments, a lookup and a committed instance: every optional argument kind of
+    the verifier in one key (trash squeeze + commitments proof.rs:68-75, identities emitters/aiken.rs:444-461)."""
+    adv = [[0, 1, -1]] * 1 + [[0, 1]] * 2 + [[0]] * 2
+    return _shaped_vk("trashcan_mix", seed, k=9, degree=4, n_adv=5, n_fix=7, n_cc=5, lookup_arg_exprs=[2],
+                      gate_exprs=3, gate_ops={"mul": 12, "add": 10, "neg": 2}, adv_rot_sets=adv, n_pi=5, n_ci=1,
+                      trash_exprs=(2, 1))
+
+
 def ivc_vk(seed: int = 0x48325636):
     """IVC-shaped circuit (examples/ivc.rs, src/circuits/ivc_circuit.rs): a small chip mix whose public inputs carry
     the verifying-key hash, the collapsed accumulator of the previous step and the fixed-base scalars
@@ -404,4 +418,5 @@ BUILDERS = {
     "sha256": sha256_vk,
     "secp256k1": secp256k1_vk,
     "ivc": ivc_vk,
+    "trashcan_mix": trashcan_mix_vk,
 }
