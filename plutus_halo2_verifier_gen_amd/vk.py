@@ -385,7 +385,9 @@ def secp256k1_vk(seed: int = 0x48325635):
 def trashcan_mix_vk(seed: int = 0x48325637):
     """Small chip mix with two trashcan arguments, a lookup and a committed instance: every optional argument kind of
     the verifier in one key (trash squeeze + commitments proof.rs:68-75, identities emitters/aiken.rs:444-461)."""
-    adv = [[0, 1, -1]] * 1 + [[0, 1]] * 2 + [[0]] * 2
+    # rotations beyond prev / cur / next become Custom(n) (rotation_description.rs:17-48; x_rot_2, x_rot_3 of
+    # verification_h2.hbs:35-36)
+    adv = [[0, 1, -1, 2]] * 1 + [[0, 3]] * 1 + [[0, 1]] * 1 + [[0]] * 2
     return _shaped_vk("trashcan_mix", seed, k=9, degree=4, n_adv=5, n_fix=7, n_cc=5, lookup_arg_exprs=[2],
                       gate_exprs=3, gate_ops={"mul": 12, "add": 10, "neg": 2}, adv_rot_sets=adv, n_pi=5, n_ci=1,
                       trash_exprs=(2, 1))
