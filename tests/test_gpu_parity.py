@@ -369,3 +369,20 @@ def test_baseline_config_sizes(be, circuits, name, n):
     sample = sorted(random.Random(16).sample(range(n), 64))
     sb = _permute(batch, sample, n_pi)
     assert list(ov.verify_batch(sb.proofs, sb.proof_off, sb.instances, sb.committed, threads=16)) == [got[i] for i in sample]
+
+
+def test_circuit_without_public_inputs(be):
+    """n_public_inputs == 0 with a queried instance column (the Lagrange sum is empty) and instances == NULL at the ABI."""
+    from plutus_halo2_verifier_gen_amd import backend, plan as PL, synth, vk as V
+    from oracle import binding as orc
+    adv = [[0, 1]] * 2 + [[0]] * 1
+    vk, td = V._shaped_vk("nopi", 77, k=8, degree=4, n_adv=3, n_fix=4, n_cc=3, lookup_arg_exprs=[], gate_exprs=2,
+                          gate_ops={"mul": 6, "add": 4, "neg": 1}, adv_rot_sets=adv, n_pi=0, n_ci=0)
+    pl = PL.compile_plan(vk)
+    ov = orc.OracleVK(orc.vk_desc(json.loads(vk.to_json()), vk.omega, vk.omega_inv, vk.barycentric_weight))
+    dp = backend.DevicePlan(pl.to_bytes(), 0)
+    b = synth.forge_batch(vk, td, 20, seed=3, plan=pl, workers=1)
+    b = synth.with_rejects(pl, b, 0, fraction=0.4, seed=2, kinds=["flip_first_scalar", "wrong_pi", "point_not_on_curve"])
+    got = dp.verify_batch(b.proofs, b.proof_off, b"", None)
+    assert list(got) == list(ov.verify_batch(b.proofs, b.proof_off, b"", None, threads=4)) == b.expected
+    assert 0 < sum(got) < 20
