@@ -55,7 +55,7 @@ def test_forged_proofs_accept_and_corruptions_reject(orc, name):
     pl = PL.compile_plan(vk)
     ov = _oracle_vk(orc, vk)
     assert pl.proof_len == ov.proof_len and pl.n_main_terms == ov.n_msm_terms
-    b = synth.forge_batch(vk, td, 3, seed=5, plan=pl, workers=1)
+    b = synth.forge_batch(vk, td, 3, seed=5, plan=pl, workers=1, ci_identity=(name == "sha256"))
     for i in range(b.n):
         assert ov.verify(b.proof(i), b.instance_ints(i, vk.n_public_inputs), b.ci(i))
     rng = random.Random(2)
