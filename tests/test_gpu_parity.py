@@ -387,3 +387,25 @@ def test_circuit_without_public_inputs(be):
     got = dp.verify_batch(b.proofs, b.proof_off, b"", None)
     assert list(got) == list(ov.verify_batch(b.proofs, b.proof_off, b"", None, threads=4)) == b.expected
     assert 0 < sum(got) < 20
+
+
+@pytest.mark.parametrize("env", [{"H2V_PIPES": "3"}, {"H2V_PAIRING": "legacy"}, {"H2V_DEBUG_SYNC": "1"}])
+def test_alternate_pipeline_modes(be, env, tmp_path):
+    """The experiment knobs of the pipeline (chunked sub-batches on several streams, the one-lane pairing kernel, the
+    serialised debug path) are read once per process, so each runs in a child process; same verdicts."""
+    import os
+    import subprocess
+    import sys
+    script = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from plutus_halo2_verifier_gen_amd import backend, plan as PL, synth, vk as V\n"
+        "for name in ('simple_mul', 'ivc'):\n"
+        "    vk, td = V.BUILDERS[name]()\n"
+        "    pl = PL.compile_plan(vk)\n"
+        "    b = synth.forge_batch(vk, td, 150, seed=4, plan=pl, workers=1)\n"
+        "    b = synth.with_rejects(pl, b, vk.n_public_inputs, fraction=0.3, seed=6, kinds=list(synth.CORRUPTIONS))\n"
+        "    got = backend.DevicePlan(pl.to_bytes(), 0).verify_batch(b.proofs, b.proof_off, b.instances, b.committed)\n"
+        "    assert list(got) == b.expected and 0 < sum(got) < 150, name\n"
+        "print('modes ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", script], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "modes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
