@@ -303,7 +303,7 @@ static int launch_vm(const H2vDevPlan &d, uint32_t n, uint32_t stride, const uin
     return H2V_OK;
 }
 
-// MSM launch geometry: 2 lanes per (proof, term); block = max(64, 2*tp) threads, LDS 144 B per thread.
+// MSM launch geometry: 2 lanes per (proof, term); LDS 172 B per thread (42 limbs + the infinity flag).
 static void launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const uint32_t *scalars, const uint32_t *pts,
                              uint32_t *tabws, hipStream_t st) {
     // 2 lanes per term; block = the multiple of 64 (<= 512) that wastes the smallest fraction of its lanes
@@ -316,7 +316,7 @@ static void launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t
     }
     const uint32_t per_block = bs / lpp;
     const uint32_t blocks = (n + per_block - 1) / per_block;
-    hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 144, st, d, ma, n, per_block, scalars, pts, tabws);
+    hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
 }
 // the proof's own MSM: terms [0, n_main_terms) of the plan's table, scalars from the combiner, points from decompression.
 // A recursive plan sums acc_left and acc_right + fixed bases in the same launch (three groups, three outputs).

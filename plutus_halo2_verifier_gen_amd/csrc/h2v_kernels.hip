@@ -502,8 +502,10 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
     const uint32_t grp = term < ma.grp_end[0] ? 0u : (term < ma.grp_end[1] ? 1u : 2u);
     const uint32_t g_lo = grp == 0 ? 0u : ma.grp_end[grp - 1];
     const uint32_t gsub = sub - 2 * g_lo, glen = 2 * (ma.grp_end[grp] - g_lo);
-    G1J acc;
-    g1j_set_inf(acc);
+    // this lane's partial sum, on the lazily reduced field with an explicit infinity flag (h2v_curve28.cuh); idle
+    // lanes and skipped terms contribute the point at infinity
+    G1J28 lad;
+    bool lad_inf = true;
     if (active) {
         // terms[] as uploaded by h2v_plan_load: kind is VK base (1) or per-proof slot (0); the committed instance has
         // been rewritten to slot n_points there.  Two-way integer selects only: a nested three-way pointer select was
@@ -558,10 +560,7 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
                 g1j28_dbl_ool(tq, t4); tab[7] = tq;
             }
             // The ladder runs on the lazily reduced 28-bit field (h2v_fp28.cuh / h2v_curve28.cuh) and is only ever
-            // touched by inlined code, so `lad` stays in VGPRs; the result is brought back to canonical limbs for the
-            // reduction tree below.
-            G1J28 lad;
-            bool lad_inf = true;
+            // touched by inlined code, so `lad` stays in VGPRs.
 #pragma unroll 1
             for (int q = 32; q >= 0; q--) {
                 if (q != 32 && !lad_inf) {
@@ -571,39 +570,41 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
                 const int d = dg[q];
                 if (d != 0) g1j28_acc_add(lad, lad_inf, tab[(d < 0 ? -d : d) - 1], d < 0);
             }
-            g1j28_to_g1j(acc, lad, lad_inf);
         }
     }
-    // segmented reduction over the lanes of each (proof, group)
-#pragma unroll
-    for (int k = 0; k < 12; k++) {
-        red[k * bs + tid] = acc.x.v[k];
-        red[(12 + k) * bs + tid] = acc.y.v[k];
-        red[(24 + k) * bs + tid] = acc.z.v[k];
-    }
+    // segmented reduction over the lanes of each (proof, group), still on the lazy field: 42 limbs + the flag per lane
+    // in LDS (dword d of thread t at red[d*bs + t]); only the lane that ends up with a group's sum converts it back
+#define MSM_RED_STORE()                                                                     \
+    do {                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < 14; k++) {                                    \
+            red[k * bs + tid] = lad.x.l[k]; red[(14 + k) * bs + tid] = lad.y.l[k]; red[(28 + k) * bs + tid] = lad.z.l[k]; \
+        }                                                                                   \
+        red[42 * bs + tid] = lad_inf ? 1u : 0u;                                             \
+    } while (0)
+    MSM_RED_STORE();
     __syncthreads();
     uint32_t top = 1;
     while (top < lanes_per_proof) top <<= 1;
     for (uint32_t s = top >> 1; s >= 1; s >>= 1) {
         if (seg < per_block && gsub < s && gsub + s < glen) {
-            G1J other;
+            if (red[42 * bs + tid + s] == 0) {
+                G1J28 other;
 #pragma unroll
-            for (int k = 0; k < 12; k++) {
-                other.x.v[k] = red[k * bs + tid + s];
-                other.y.v[k] = red[(12 + k) * bs + tid + s];
-                other.z.v[k] = red[(24 + k) * bs + tid + s];
-            }
-            g1j_add(acc, acc, other);
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-                red[k * bs + tid] = acc.x.v[k];
-                red[(12 + k) * bs + tid] = acc.y.v[k];
-                red[(24 + k) * bs + tid] = acc.z.v[k];
+                for (int k = 0; k < 14; k++) {
+                    other.x.l[k] = red[k * bs + tid + s];
+                    other.y.l[k] = red[(14 + k) * bs + tid + s];
+                    other.z.l[k] = red[(28 + k) * bs + tid + s];
+                }
+                g1j28_acc_add(lad, lad_inf, other, false);   // complete: equal / opposite partial sums, infinity
+                MSM_RED_STORE();
             }
         }
         __syncthreads();
     }
+#undef MSM_RED_STORE
     if (gsub == 0 && seg < per_block && i < n) {
+        G1J acc;
+        g1j28_to_g1j(acc, lad, lad_inf);
         uint32_t *out = grp == 0 ? ma.out[0] : (grp == 1 ? ma.out[1] : ma.out[2]);
 #pragma unroll
         for (int k = 0; k < 12; k++) {
