@@ -249,7 +249,7 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     WSALLOC(pts, (size_t)max_batch * slots * 96)
     WSALLOC(valid, (size_t)max_batch * slots)
     WSALLOC(er, (size_t)max_batch * 144)
-    WSALLOC(msm_tab, (size_t)max_batch * d.n_terms * 2 * 8 * 168)  // per (proof, term, half): [1..8]*P Jacobian, 3 x 14 x 28-bit limbs
+    WSALLOC(msm_tab, (size_t)max_batch * d.n_terms * 2 * 8 * 112)  // per (proof, term, half): [1..8]*P affine, 2 x 14 x 28-bit limbs
     WSALLOC(status, (size_t)max_batch * 4)
     WSALLOC(accept, (size_t)max_batch)
     if (with_trace && d.n_trace) { WSALLOC(trace, (size_t)max_batch * d.n_trace * 32) }
@@ -419,7 +419,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipEventRecord(ev[1], pm));
         HIPCHK(hipStreamWaitEvent(pm, w->ev_join[k], 0));
         HIPCHK(hipEventRecord(ev[4], pm));
-        uint32_t *tab_k = w->msm_tab + (size_t)lo * d.n_terms * 2 * 8 * 42;
+        uint32_t *tab_k = w->msm_tab + (size_t)lo * d.n_terms * 2 * 8 * 28;
         const IvcBufs ib = {d.ivc ? w->accl + (size_t)lo * 36 : nullptr, d.ivc ? w->accr + (size_t)lo * 36 : nullptr,
                             d.ivc ? w->fold_pts + (size_t)lo * 96 : nullptr, d.ivc ? w->fold_scal + (size_t)lo * 32 : nullptr,
                             d.ivc ? w->el2 + (size_t)lo * 36 : nullptr, d.ivc ? w->er2 + (size_t)lo * 36 : nullptr};
@@ -676,7 +676,7 @@ extern "C" int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_
     HIPCHK(hipMemcpy(din.p, bases_compressed, (size_t)n * T * 48, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dsc.p, scalars, (size_t)n * T * 32, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
-    if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 168)) return fail(H2V_E_DEVICE, "hipMalloc failed");
+    if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 112)) return fail(H2V_E_DEVICE, "hipMalloc failed");
     launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), nullptr, nullptr, dtab.as<uint32_t>(), nullptr);
     hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 1, der.as<uint32_t>(), dout.as<uint8_t>());
     HIPCHK(hipGetLastError());
@@ -710,7 +710,7 @@ extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t
     HIPCHK(hipMemcpy(dsc.p, one.data(), one.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dst.p, 0, (size_t)n * 4));
     hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
-    if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 168)) return fail(H2V_E_DEVICE, "hipMalloc failed");
+    if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 112)) return fail(H2V_E_DEVICE, "hipMalloc failed");
     launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), nullptr, nullptr, dtab.as<uint32_t>(), nullptr);
     if (ddbg.alloc(dbg ? (size_t)n * 24 * 48 : 8)) return fail(H2V_E_DEVICE, "hipMalloc failed");
     launch_pairing_impl(impl, mp.d, n, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), der.as<uint32_t>(), nullptr, dst.as<uint32_t>(), dacc.as<uint8_t>(), dbg ? ddbg.as<uint32_t>() : nullptr, nullptr);

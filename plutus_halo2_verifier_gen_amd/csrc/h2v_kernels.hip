@@ -543,21 +543,32 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
                 dg[q] = (int8_t)(carry ? (int)d - 16 : (int)d);
             }
             dg[32] = (int8_t)carry;
-            // table[m-1] = m*P, m = 1..8, in a per-lane slab of the workspace: [lane][entry][36 dwords], so that the
-            // digit-indexed read of one entry is 144 contiguous bytes.  (A private-memory table is dword-interleaved
-            // across lanes: with per-lane digits every 4-byte read pulled its own sector, 2.4 GB fetched per launch.)
-            G1J28 *tab = reinterpret_cast<G1J28 *>(tabws + (((size_t)i * ma.n_terms + term) * 2 + half) * (8 * 42));
+            // table[m-1] = m*P, m = 1..8, AFFINE (x, y: 2 x 14 limbs), in a per-lane slab of the workspace:
+            // [lane][entry][28 dwords], so that the digit-indexed read of one entry is 112 contiguous bytes.  (A
+            // private-memory table is dword-interleaved across lanes: with per-lane digits every 4-byte read pulled
+            // its own sector, 2.4 GB fetched per launch.)  The seven multiples are normalised with one inversion
+            // (Montgomery's trick, ~47 k instructions) so that the 33 window additions are mixed ones (11 instead of 16
+            // field multiplications each, ~82 k instructions less).
+            uint32_t *tab = tabws + (((size_t)i * ma.n_terms + term) * 2 + half) * (8 * 28);
             {
-                G1J28 t1, t2, t3, t4, tq;
+                G1J28 t1, e[7];
                 g1j28_from_affine(t1, base);          // bases are points of G1 (validated / VK constants): every
-                g1j28_dbl_ool(t2, t1);                // multiple below r is finite and the sums below are generic
-                (void)g1j28_add_ool(t3, t2, t1);
-                g1j28_dbl_ool(t4, t2);
-                tab[0] = t1; tab[1] = t2; tab[2] = t3; tab[3] = t4;
-                (void)g1j28_add_ool(tq, t4, t1); tab[4] = tq;
-                g1j28_dbl_ool(tq, t3); tab[5] = tq;
-                (void)g1j28_add_ool(tq, tq, t1); tab[6] = tq;
-                g1j28_dbl_ool(tq, t4); tab[7] = tq;
+                g1j28_dbl_ool(e[0], t1);              // multiple below r is finite and the sums below are generic
+                (void)g1j28_add_ool(e[1], e[0], t1);
+                g1j28_dbl_ool(e[2], e[0]);
+                (void)g1j28_add_ool(e[3], e[2], t1);
+                g1j28_dbl_ool(e[4], e[1]);
+                (void)g1j28_add_ool(e[5], e[4], t1);
+                g1j28_dbl_ool(e[6], e[2]);
+                F28 ax[7], ay[7];
+                g1j28_batch_to_affine<7>(ax, ay, e);
+#pragma unroll
+                for (int k = 0; k < 14; k++) { tab[k] = t1.x.l[k]; tab[14 + k] = t1.y.l[k]; }
+#pragma unroll 1
+                for (int m = 0; m < 7; m++) {
+#pragma unroll
+                    for (int k = 0; k < 14; k++) { tab[(m + 1) * 28 + k] = ax[m].l[k]; tab[(m + 1) * 28 + 14 + k] = ay[m].l[k]; }
+                }
             }
             // The ladder runs on the lazily reduced 28-bit field (h2v_fp28.cuh / h2v_curve28.cuh) and is only ever
             // touched by inlined code, so `lad` stays in VGPRs.
@@ -568,7 +579,21 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
                     for (int rep = 0; rep < 4; rep++) g1j28_dbl_t<true>(lad, lad);   // multiplier inlined: no argument marshalling
                 }
                 const int d = dg[q];
-                if (d != 0) g1j28_acc_add(lad, lad_inf, tab[(d < 0 ? -d : d) - 1], d < 0);
+                if (d != 0) {
+                    const uint32_t *ent = tab + ((d < 0 ? -d : d) - 1) * 28;
+                    F28 qx, qy;
+#pragma unroll
+                    for (int k = 0; k < 14; k++) { qx.l[k] = ent[k]; qy.l[k] = ent[14 + k]; }
+                    if (lad_inf) {
+                        lad.x = qx;
+                        lad.y = qy;
+                        if (d < 0) { F28_NEG(lad.y, qy, 3, 1); f28_carry(lad.y); }
+                        f28_set_one(lad.z);
+                        lad_inf = false;
+                    } else {
+                        g1j28_madd_ladder(lad, lad, qx, qy, d < 0);   // never an exceptional case: see its comment
+                    }
+                }
             }
         }
     }
