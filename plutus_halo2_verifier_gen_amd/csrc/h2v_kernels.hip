@@ -467,16 +467,16 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
 // (Pippenger) accumulation to pay - 2^c buckets per window would outnumber the terms - so the mapping is:
 //   * TWO lanes per (proof, term): the GLV split k = k1 + k2*lambda gives lane 0 the pair (k1, P) and lane 1
 //     (k2, phi(P) = (beta' x, y)), both scalars below 2^128 (half the doubling chain, twice the waves);
-//   * per lane a signed 4-bit window ladder: table [1..8]*P in private memory (Jacobian), 32 windows of
-//     4 doublings + one table addition (digits in [-8, 8]);
-//   * a segmented tree reduction of the 2*TP partial sums of each proof through LDS (TP = 2^ceil(log2 T)).
+//   * per lane a signed 4-bit window ladder on the lazily reduced field: table [1..8]*P, affine, in a per-lane slab
+//     of the workspace; 33 windows of 4 doublings + one mixed addition (digits in [-8, 8]);
+//   * a segmented tree reduction of the 2*T partial sums of each (proof, term group) through LDS.
 // Bytes per term: 32 (scalar) + 96 (affine base) in, 144 per proof out (Jacobian).
 // One launch sums a RANGE of a term table (the proof's own MSM; with recursion also acc_left, acc_right + fixed bases,
 // and the two folds el + c*acc_left, er + c*acc_right over the fold's own point / scalar buffers):
 struct H2vMsmArgs {
     const uint32_t *terms;     // (kind, index) pairs; kind = VK base or per-proof slot of `pts`
     uint32_t term_base;        // first term of the range
-    uint32_t n_terms;          // terms in the range (<= tp)
+    uint32_t n_terms;          // terms in the range (2 * n_terms lanes per proof, <= 512)
     uint32_t scal_stride;      // scalars per proof in `scalars`
     uint32_t scal_col_base;    // column of the range's first term
     uint32_t slots;            // point slots per proof in `pts`
