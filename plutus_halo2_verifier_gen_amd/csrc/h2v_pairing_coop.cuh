@@ -75,7 +75,7 @@ H2V_DI void coop_load28(uint32_t (&l)[14], const uint32_t *p) {
 // notation:  every Fp12 variable has lam = 1 and v <= 6 (engine outputs 3, conj 6, frob 5, inverse 3; the
 // generated program is checked for this by tools/gen_coop_program.py).  Operand slots must hold carried limbs: a
 // MUL column sums 12 terms x 14 products, which fills the 64-bit accumulator at lam = 1.  Staged operands:
-//   A = a (6)   NA = 7p - a_im (7)   B = b (6)   XB = (b0 - b1 + 7p, b0 + b1) (13)   D = 2a (12)   ND = 13p - 2 a_im (13)
+//   A = a (6)   NA = 7p - a_im (7)   B = b (6)   XB = (b0 - b1 + 7p, b0 + b1) (13)   D = 2a (12)
 // Each of the two lanes sharing a coefficient reduces its half of the terms on its own: a half is below
 // (6 * 7 * 13 / 2520 + 1) p = 1.22 p for MUL and (3 * 3 * 7 * 13 / 2520 + 1) p = 1.33 p for the tripled cyclotomic
 // squaring (p / R < 1/2520), so the engine's result (the sum of the two halves) is below 3p.
@@ -197,20 +197,15 @@ H2V_DI F28 coop_mul(const Coop &c, const F28 &a, const F28 &b) {
     return r;
 }
 // a^2 for a in the cyclotomic subgroup (Granger-Scott; formulas and table: tools/gen_coop_tables.py: csqr_table).
-// Operands: A = a, NA = -a_im (half 0 lanes), D = 2a and ND = -2 a_im (half 1 lanes), and the shared constants
-// +-2/3: the engine returns 3 (Q_k -/+ (2/3) a_k) = 3 Q_k -/+ 2 a_k already reduced.
+// Operands: A = a, NA = -a_im (half 0 lanes), D = 2a (half 1 lanes; -2 a_im b is taken as (-a_im)(2b)), and the shared
+// constants +-2/3: the engine returns 3 (Q_k -/+ (2/3) a_k) = 3 Q_k -/+ 2 a_k already reduced.
 H2V_DI F28 coop_csqr(const Coop &c, const F28 &a) {
     coop_stage_a(c, a);
     if (c.g < 12 && c.h == 1) {
-        F28 d2, n;
+        F28 d2;
         f28_mul_small<2>(d2, a);               // (12, 2)
-        F28_NEG(n, d2, 13, 2);                 // (13, 4)
         f28_carry(d2);
         coop_store28(coop_slot(c, COOP_SLOT_D + c.g), d2);
-        if (c.g & 1) {
-            f28_carry(n);
-            coop_store28(coop_slot(c, COOP_SLOT_ND + (c.g >> 1)), n);
-        }
     }
     __syncthreads();
     const F28 r = coop_engine<COOP_N_CSQR_TERMS, true>(c, COOP_TAB_CSQR_B + c.g * 2 * COOP_N_CSQR_TERMS);

@@ -43,7 +43,8 @@ LN_NL0, LN_NL1, LN_NXL0, LN_NXL1, LN_C0, LN_C1, LN_XC0, LN_XC1 = range(8)
 N_MUL_TERMS = 12
 N_LINE_TERMS = 6
 N_CSQR_TERMS = 6
-# cyclotomic squaring reuses the B / XB areas for the doubled operand: D = 2*g (12 slots), ND = -2*g_k1 (6 slots)
+# cyclotomic squaring reuses the B area for the doubled operand D = 2*g (12 slots); products with -2*g_k1 are taken
+# as (-g_k1) * (2*g): no separate negated-doubled operand is staged (ND kept as a name for the simulation only)
 SLOT_D = SLOT_B
 SLOT_ND = SLOT_XB
 
@@ -137,7 +138,7 @@ def csqr_table():
             ty, a, b = kind[k]
             if ty == "even":    # a^2 + xi b^2
                 if part == 0:
-                    terms = [(A(a, 0), A(a, 0)), (NA(a), A(a, 1)), (A(b, 0), A(b, 0)), (NA(b), A(b, 1)), (A(b, 0), ND(b))]
+                    terms = [(A(a, 0), A(a, 0)), (NA(a), A(a, 1)), (A(b, 0), A(b, 0)), (NA(b), A(b, 1)), (NA(b), D(b, 0))]
                 else:
                     terms = [(A(a, 0), D(a, 1)), (A(b, 0), A(b, 0)), (NA(b), A(b, 1)), (A(b, 0), D(b, 1))]
             elif ty == "odd":   # 2 a b
@@ -147,7 +148,7 @@ def csqr_table():
                     terms = [(A(a, 0), D(b, 1)), (A(a, 1), D(b, 0))]
             else:               # 2 xi a b
                 if part == 0:
-                    terms = [(A(a, 0), D(b, 0)), (NA(a), D(b, 1)), (A(a, 0), ND(b)), (NA(a), D(b, 0))]
+                    terms = [(A(a, 0), D(b, 0)), (NA(a), D(b, 1)), (NA(b), D(a, 0)), (NA(a), D(b, 0))]
                 else:
                     terms = [(A(a, 0), D(b, 0)), (NA(a), D(b, 1)), (A(a, 0), D(b, 1)), (A(a, 1), D(b, 0))]
         if g < 12:
