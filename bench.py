@@ -194,11 +194,12 @@ def main():
                     "algorithmic_bytes_per_launch": bytes_per_launch[k] // launches}
 
         # analytical multiply-add counts per launch (lane-level v_mad_u64_u32), see DESIGN.md section 6
-        msm_lane = 4 * MAD_DBL + 3 * MAD_ADD + 40 * MAD_MUL + 14 * MAD_SQR + 128 * MAD_DBL + 31 * MAD_MADD + MAD_MUL  # table + its normalisation, 32 windows (mixed additions), phi
+        msm_lane = 128 * MAD_DBL + 31 * MAD_MADD          # 32 windows: 4 doublings + one mixed addition (tables are built ahead)
+        tab_point = 4 * MAD_DBL + 3 * MAD_ADD + 48 * MAD_MUL + 14 * MAD_SQR    # window tables of one point: [1..8]P, normalised, and x beta
         mads = {
             "g1_msm": B * T * 2 * msm_lane + B * (2 * T - 1) * MAD_ADD + B * 3 * MAD_MUL,
             "pairing": B * 32 * (98 * (6 * 196 + 196) + (315 + 136) * (3 * 196 + 196)),     # coop program: MUL / CSQR+LINE
-            "g1_decompress": B * slots * (380 * MAD_SQR + 190 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD),
+            "g1_decompress": B * slots * (380 * MAD_SQR + 190 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD + tab_point),
             "transcript_combiner": B * sum(128 for ins in pl.instrs if ins[0] == PL.OP_MUL),
         }
 

@@ -37,6 +37,7 @@ struct h2v_plan {
     H2vDevPlan d{};            // device view
     void *blob = nullptr;      // one device allocation holding every section
     void *fold_terms = nullptr;  // recursion: the 4-entry term table of the two fold MSMs
+    void *vk_tab = nullptr;      // window tables of the VK bases (k_vk_tables at load)
     uint32_t n_squeezes = 0, stream_len = 0;
     std::vector<uint32_t> trace_slots;
 };
@@ -48,6 +49,7 @@ struct h2v_workspace {
     uint32_t *regs = nullptr, *scalars = nullptr, *pts = nullptr, *er = nullptr, *status = nullptr, *trace = nullptr, *msm_tab = nullptr;
     // recursion (IVC): acc_left / acc_right_final sums, the fold's points + scalars, and the folded el / er
     uint32_t *accl = nullptr, *accr = nullptr, *fold_pts = nullptr, *fold_scal = nullptr, *el2 = nullptr, *er2 = nullptr;
+    uint32_t *pt_tab = nullptr;  // MSM window tables of every per-proof point, written by the decompression kernel
     uint8_t *valid = nullptr, *accept = nullptr;
     // staging for the host-buffer entry point
     uint8_t *in_proofs = nullptr, *in_inst = nullptr, *in_ci = nullptr;
@@ -192,6 +194,23 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
     d.ivc = ivc; d.n_main_terms = n_main;
     for (int k = 0; k < 8; k++) d.acc_idx[k] = w[H2V_HW_ACC_IDX0 + k];
     d.fold_terms = (const uint32_t *)p->fold_terms;
+    // window tables of the VK bases for the MSM ladder: [1..8]B and [1..8]phi(B), affine, computed once per plan
+    if (hipMalloc(&p->vk_tab, (size_t)n_bases * 448 * 4 + 16) != hipSuccess || hipMemset(p->vk_tab, 0, (size_t)n_bases * 448 * 4 + 16) != hipSuccess) {
+        if (p->vk_tab) (void)hipFree(p->vk_tab);
+        if (p->fold_terms) (void)hipFree(p->fold_terms);
+        (void)hipFree(p->blob); delete p;
+        return fail(H2V_E_DEVICE, "hipMalloc(vk tables) failed");
+    }
+    if (n_bases) {
+        hipLaunchKernelGGL(k_vk_tables, dim3((n_bases + 63) / 64), dim3(64), 0, nullptr, d.vk_bases, n_bases, (uint32_t *)p->vk_tab);
+        if (hipDeviceSynchronize() != hipSuccess) {
+            (void)hipFree(p->vk_tab);
+            if (p->fold_terms) (void)hipFree(p->fold_terms);
+            (void)hipFree(p->blob); delete p;
+            return fail(H2V_E_DEVICE, "VK window-table kernel failed");
+        }
+    }
+    d.vk_tab = (const uint32_t *)p->vk_tab;
     p->n_squeezes = n_sq;
     p->stream_len = w[H2V_HW_STREAM_LEN];
     for (uint32_t k = 0; k < n_trace; k++) p->trace_slots.push_back(rd32(trp + 8 * k));
@@ -203,6 +222,7 @@ extern "C" void h2v_plan_free(h2v_plan *p) {
     (void)hipSetDevice(p->device);
     if (p->blob) (void)hipFree(p->blob);
     if (p->fold_terms) (void)hipFree(p->fold_terms);
+    if (p->vk_tab) (void)hipFree(p->vk_tab);
     delete p;
 }
 extern "C" int h2v_plan_info(const h2v_plan *p, uint32_t *proof_len, uint32_t *n_pi, uint32_t *n_ci, uint32_t *n_terms) {
@@ -224,7 +244,7 @@ extern "C" int h2v_plan_trace_slots(const h2v_plan *p, uint32_t *slot_ids, uint3
 static void ws_release(h2v_workspace *w) {
     (void)hipSetDevice(w->device);
     void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off, w->msm_tab,
-                    w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2};
+                    w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2, w->pt_tab};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipStream_t q : w->pmain) if (q) (void)hipStreamDestroy(q);
     for (hipStream_t q : w->pside) if (q) (void)hipStreamDestroy(q);
@@ -249,7 +269,8 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     WSALLOC(pts, (size_t)max_batch * slots * 96)
     WSALLOC(valid, (size_t)max_batch * slots)
     WSALLOC(er, (size_t)max_batch * 144)
-    WSALLOC(msm_tab, (size_t)max_batch * d.n_terms * 2 * 8 * 112)  // per (proof, term, half): [1..8]*P affine, 2 x 14 x 28-bit limbs
+    WSALLOC(pt_tab, (size_t)max_batch * slots * 448 * 4)             // per (proof, slot): [1..8]P and [1..8]phi(P), affine, 2 x 14 x 28-bit limbs
+    if (d.ivc) { WSALLOC(msm_tab, (size_t)max_batch * 4 * 2 * 8 * 112) }  // fold MSMs build their four tables on the spot
     WSALLOC(status, (size_t)max_batch * 4)
     WSALLOC(accept, (size_t)max_batch)
     if (with_trace && d.n_trace) { WSALLOC(trace, (size_t)max_batch * d.n_trace * 32) }
@@ -320,15 +341,16 @@ static void launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t
 }
 // the proof's own MSM: terms [0, n_main_terms) of the plan's table, scalars from the combiner, points from decompression.
 // A recursive plan sums acc_left and acc_right + fixed bases in the same launch (three groups, three outputs).
-static void launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, uint32_t *er,
-                       uint32_t *accl, uint32_t *accr, uint32_t *tabws, hipStream_t st) {
-    H2vMsmArgs ma = {d.terms, 0, d.n_main_terms, d.n_terms, 0, H2V_SLOTS(d), {d.n_main_terms, d.n_main_terms, d.n_main_terms}, {er, nullptr, nullptr}};
+static void launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, const uint32_t *pt_tab,
+                       uint32_t *er, uint32_t *accl, uint32_t *accr, hipStream_t st) {
+    H2vMsmArgs ma = {d.terms, 0, d.n_main_terms, d.n_terms, 0, H2V_SLOTS(d), {d.n_main_terms, d.n_main_terms, d.n_main_terms}, {er, nullptr, nullptr},
+                     pt_tab, d.vk_tab};
     if (d.ivc) {
         ma.n_terms = d.n_terms;
         ma.grp_end[0] = d.n_main_terms; ma.grp_end[1] = d.n_main_terms + 1; ma.grp_end[2] = d.n_terms;
         ma.out[1] = accl; ma.out[2] = accr;
     }
-    launch_msm_range(d, ma, n, scalars, pts, tabws, st);
+    launch_msm_range(d, ma, n, scalars, pts, nullptr, st);
 }
 // Recursion (IVC) fold between the MSM and the pairing (emitters/aiken.rs:696-757): the batching challenge from
 // (el, er, acc_left, acc_right_final), then el' = el + c acc_left and er' = er + c acc_right_final in one two-group
@@ -337,7 +359,7 @@ struct IvcBufs { uint32_t *accl, *accr, *fold_pts, *fold_scal, *el2, *er2; };
 static void launch_ivc_fold(const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint32_t *er,
                             const IvcBufs &b, uint32_t *tabws, hipStream_t st) {
     hipLaunchKernelGGL(k_ivc_challenge, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, er, b.accl, b.accr, b.fold_pts, b.fold_scal);
-    const H2vMsmArgs fold = {d.fold_terms, 0, 4, 4, 0, 4, {2, 4, 4}, {b.el2, b.er2, nullptr}};
+    const H2vMsmArgs fold = {d.fold_terms, 0, 4, 4, 0, 4, {2, 4, 4}, {b.el2, b.er2, nullptr}, nullptr, nullptr};
     launch_msm_range(d, fold, n, b.fold_scal, b.fold_pts, tabws, st);
 }
 // Pairing kernel selection: the cooperative 16-lanes-per-proof kernel is the product path; the one-lane-per-proof
@@ -374,9 +396,9 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipGetLastError());                                                              \
         HIPCHK(hipDeviceSynchronize());                                                         \
         fprintf(stderr, "[h2v] %s done\n", name); fflush(stderr);
-        DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(128), 0, st, d, n, proofs, off, ci, inst, w->pts, w->valid))
+        DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(128), 0, st, d, n, proofs, off, ci, inst, w->pts, w->valid, w->pt_tab))
         DBG_STAGE("k_transcript_combiner", { int rcv = launch_vm(d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace, st); if (rcv) return rcv; })
-        DBG_STAGE("k_g1_msm", launch_msm(d, n, w->scalars, w->pts, w->er, w->accl, w->accr, w->msm_tab, st))
+        DBG_STAGE("k_g1_msm", launch_msm(d, n, w->scalars, w->pts, w->pt_tab, w->er, w->accl, w->accr, st))
         if (d.ivc) {
             const IvcBufs ib = {w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2};
             DBG_STAGE("ivc fold", launch_ivc_fold(d, n, w->pts, w->er, ib, w->msm_tab, st))
@@ -411,7 +433,8 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipStreamWaitEvent(ps, w->ev_fork, 0));
         // decompression (many short waves) runs beside the transcript+combiner kernel (few long waves)
         HIPCHK(hipEventRecord(ev[2], ps));
-        hipLaunchKernelGGL(k_g1_decompress, dim3((m * slots + 63) / 64), dim3(128), 0, ps, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k);
+        uint32_t *pt_tab_k = w->pt_tab + (size_t)lo * slots * 448;
+        hipLaunchKernelGGL(k_g1_decompress, dim3((m * slots + 63) / 64), dim3(128), 0, ps, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, pt_tab_k);
         HIPCHK(hipEventRecord(ev[3], ps));
         HIPCHK(hipEventRecord(w->ev_join[k], ps));
         HIPCHK(hipEventRecord(ev[0], pm));
@@ -419,11 +442,11 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipEventRecord(ev[1], pm));
         HIPCHK(hipStreamWaitEvent(pm, w->ev_join[k], 0));
         HIPCHK(hipEventRecord(ev[4], pm));
-        uint32_t *tab_k = w->msm_tab + (size_t)lo * d.n_terms * 2 * 8 * 28;
+        uint32_t *tab_k = d.ivc ? w->msm_tab + (size_t)lo * 4 * 2 * 8 * 28 : nullptr;   // fold MSMs only
         const IvcBufs ib = {d.ivc ? w->accl + (size_t)lo * 36 : nullptr, d.ivc ? w->accr + (size_t)lo * 36 : nullptr,
                             d.ivc ? w->fold_pts + (size_t)lo * 96 : nullptr, d.ivc ? w->fold_scal + (size_t)lo * 32 : nullptr,
                             d.ivc ? w->el2 + (size_t)lo * 36 : nullptr, d.ivc ? w->er2 + (size_t)lo * 36 : nullptr};
-        launch_msm(d, m, scal_k, pts_k, er_k, ib.accl, ib.accr, tab_k, pm);
+        launch_msm(d, m, scal_k, pts_k, pt_tab_k, er_k, ib.accl, ib.accr, pm);
         const uint32_t *er_in = er_k, *el_in = nullptr;
         if (d.ivc) {   // (timed with the MSM: the challenge hash and one more pass of the same kernel)
             launch_ivc_fold(d, m, pts_k, er_k, ib, tab_k, pm);
@@ -656,7 +679,7 @@ extern "C" int h2v_probe_g1_decompress(int device, uint32_t n, const uint8_t *co
     if (mp.build(1, 0, nullptr, nullptr) || upload_offsets(doff, n, 48) || din.alloc((size_t)n * 48) || dpts.alloc((size_t)n * 96) ||
         dvalid.alloc(n) || dout.alloc((size_t)n * 96)) return fail(H2V_E_DEVICE, "probe setup failed");
     HIPCHK(hipMemcpy(din.p, compressed, (size_t)n * 48, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_g1_decompress, dim3((n + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 0, dpts.as<uint32_t>(), dout.as<uint8_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
@@ -675,9 +698,9 @@ extern "C" int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_
         return fail(H2V_E_DEVICE, "probe setup failed");
     HIPCHK(hipMemcpy(din.p, bases_compressed, (size_t)n * T * 48, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dsc.p, scalars, (size_t)n * T * 32, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
-    if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 112)) return fail(H2V_E_DEVICE, "hipMalloc failed");
-    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), nullptr, nullptr, dtab.as<uint32_t>(), nullptr);
+    if (dtab.alloc((size_t)n * T * 448 * 4)) return fail(H2V_E_DEVICE, "hipMalloc failed");
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), dtab.as<uint32_t>());
+    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), dtab.as<uint32_t>(), der.as<uint32_t>(), nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 1, der.as<uint32_t>(), dout.as<uint8_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
@@ -709,9 +732,9 @@ extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t
     HIPCHK(hipMemcpy(din.p, in.data(), in.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dsc.p, one.data(), one.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dst.p, 0, (size_t)n * 4));
-    hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>());
-    if (dtab.alloc((size_t)n * mp.d.n_terms * 2 * 8 * 112)) return fail(H2V_E_DEVICE, "hipMalloc failed");
-    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), der.as<uint32_t>(), nullptr, nullptr, dtab.as<uint32_t>(), nullptr);
+    if (dtab.alloc((size_t)n * 2 * 448 * 4)) return fail(H2V_E_DEVICE, "hipMalloc failed");
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), dtab.as<uint32_t>());
+    launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), dtab.as<uint32_t>(), der.as<uint32_t>(), nullptr, nullptr, nullptr);
     if (ddbg.alloc(dbg ? (size_t)n * 24 * 48 : 8)) return fail(H2V_E_DEVICE, "hipMalloc failed");
     launch_pairing_impl(impl, mp.d, n, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), der.as<uint32_t>(), nullptr, dst.as<uint32_t>(), dacc.as<uint8_t>(), dbg ? ddbg.as<uint32_t>() : nullptr, nullptr);
     HIPCHK(hipGetLastError());

@@ -153,6 +153,53 @@ H2V_DI void g1j28_batch_to_affine(F28 (&ax)[N], F28 (&ay)[N], const G1J28 (&pts)
         f28_mul(ay[i], pts[i].y, z2);
     }
 }
+// out-of-line forms for the cold paths (window-table construction)
+H2V_DN void g1j28_dbl_ool(G1J28 &r, const G1J28 &p) { g1j28_dbl(r, p); }
+H2V_DN int g1j28_add_ool(G1J28 &r, const G1J28 &p, const G1J28 &q) { return g1j28_add(r, p, q, false); }
+// Window table of a base point for the MSM ladder: tab[m-1] = m * P, m = 1..8, AFFINE (x, y: 2 x 14 carried limbs,
+// 28 dwords per entry, 224 per table).  4 doublings + 3 additions, then one inversion for the seven multiples
+// (Montgomery's trick).  `base` is a finite curve point; for a point of G1 every multiple is finite.  (For a curve
+// point outside G1 - the decompression kernel builds tables before the subgroup verdict is known - a multiple may be
+// the point at infinity: the inversion then yields zeros, nothing faults, and the slot is marked invalid anyway.)
+H2V_DN void g1_build_window_table(uint32_t *tab, const G1A &base) {
+    G1J28 t1, e[7];
+    g1j28_from_affine(t1, base);
+    g1j28_dbl_ool(e[0], t1);
+    (void)g1j28_add_ool(e[1], e[0], t1);
+    g1j28_dbl_ool(e[2], e[0]);
+    (void)g1j28_add_ool(e[3], e[2], t1);
+    g1j28_dbl_ool(e[4], e[1]);
+    (void)g1j28_add_ool(e[5], e[4], t1);
+    g1j28_dbl_ool(e[6], e[2]);
+    F28 ax[7], ay[7];
+    g1j28_batch_to_affine<7>(ax, ay, e);
+#pragma unroll
+    for (int k = 0; k < 14; k++) { tab[k] = t1.x.l[k]; tab[14 + k] = t1.y.l[k]; }
+#pragma unroll 1
+    for (int m = 0; m < 7; m++) {
+#pragma unroll
+        for (int k = 0; k < 14; k++) { tab[(m + 1) * 28 + k] = ax[m].l[k]; tab[(m + 1) * 28 + 14 + k] = ay[m].l[k]; }
+    }
+}
+// both tables of a point: [0] for P, [1] for phi(P) = (beta' x, y) (the GLV halves of the MSM)
+H2V_DN void g1_build_window_tables_glv(uint32_t *tab2, const G1A &base) {
+    g1_build_window_table(tab2, base);
+    Fp beta;
+#pragma unroll
+    for (int k = 0; k < 12; k++) beta.v[k] = FP_BETA_GLV[k];
+    F28 b28;
+    f28_from_fp(b28, beta);
+    // phi commutes with scalar multiplication: the second table is the first with every x multiplied by beta'
+#pragma unroll 1
+    for (int m = 0; m < 8; m++) {
+        F28 x, bx;
+#pragma unroll
+        for (int k = 0; k < 14; k++) x.l[k] = tab2[m * 28 + k];
+        f28_mul(bx, x, b28);
+#pragma unroll
+        for (int k = 0; k < 14; k++) { tab2[224 + m * 28 + k] = bx.l[k]; tab2[224 + m * 28 + 14 + k] = tab2[m * 28 + 14 + k]; }
+    }
+}
 // acc (+flag) += (neg ? -q : q), q finite
 H2V_DI void g1j28_acc_add(G1J28 &acc, bool &acc_inf, const G1J28 &q, const bool neg) {
     if (acc_inf) {
@@ -164,9 +211,6 @@ H2V_DI void g1j28_acc_add(G1J28 &acc, bool &acc_inf, const G1J28 &q, const bool 
     const int k = g1j28_add(acc, acc, q, neg);
     if (k == 2) acc_inf = true;
 }
-// out-of-line forms for the cold paths (window-table construction)
-H2V_DN void g1j28_dbl_ool(G1J28 &r, const G1J28 &p) { g1j28_dbl(r, p); }
-H2V_DN int g1j28_add_ool(G1J28 &r, const G1J28 &p, const G1J28 &q) { return g1j28_add(r, p, q, false); }
 
 // [|x|]P, |x| = 0xd201000000010000, complete (P of any order on an a = 0 curve of odd order)
 H2V_DN void g1j28_mul_x_abs(G1J28 &r, bool &r_inf, const G1J28 &p, const bool p_inf) {

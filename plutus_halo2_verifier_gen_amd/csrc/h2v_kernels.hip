@@ -328,7 +328,7 @@ k_transcript_combiner_lds(H2vDevPlan plan, uint32_t n, uint32_t P, const uint8_t
 //
 // TWO waves per 64 points (block = 128 threads, the role is wave-uniform), because the square root and the subgroup
 // test are the two long serial chains and the second does not need y:
-//   wave 0: y = c^((p+1)/4) with c = x^3 + 4, y^2 == c, sign selection;
+//   wave 0: y = c^((p+1)/4) with c = x^3 + 4, y^2 == c, sign selection; then the point's MSM window tables;
 //   wave 1: r-torsion test sigma(P) == [-x^2]P carried to the isomorphic curve E': Y^2 = X^3 + 4c^3 through
 //           (x, y) -> (y^2 x, y^3 y) = (c x, c^2), which is known without the root.  The a = 0 group law does not
 //           involve b, and the isomorphism commutes with sigma (X -> beta X), so the test on E' is the test on E for
@@ -365,7 +365,7 @@ H2V_DN void acc_coordinate(Fp &r, const uint8_t *ins, uint32_t idx_hi, uint32_t 
 extern "C" __global__ void __launch_bounds__(128, 2)
 k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
                 const uint8_t *__restrict__ committed, const uint8_t *__restrict__ instances,
-                uint32_t *__restrict__ pts, uint8_t *__restrict__ valid) {
+                uint32_t *__restrict__ pts, uint8_t *__restrict__ valid, uint32_t *__restrict__ pt_tab /* or NULL */) {
     __shared__ uint8_t sub_ok[H2V_DEC_PTS];
     const uint32_t slots = H2V_SLOTS(plan);
     const uint32_t role = threadIdx.x >> 6;
@@ -440,6 +440,9 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
             if (ok) {
                 if (fp_is_lex_larger(y) != ((flags & 1) != 0)) fp_neg(y, y);
                 out.x = x; out.y = y;
+                // this wave is done at ~55 % of the subgroup wave's chain: it spends the slack on the MSM's window
+                // tables of the point ([1..8]P and [1..8]phi(P), affine), which depend on the point alone
+                if (pt_tab) g1_build_window_tables_glv(pt_tab + (size_t)gid * 448, out);
             }
         } else {
             ok = !fp_is_zero(c);
@@ -484,6 +487,10 @@ struct H2vMsmArgs {
     // MSM, acc_left and acc_right + fixed bases in ONE launch): group g = terms [grp_end[g-1], grp_end[g])
     uint32_t grp_end[3];
     uint32_t *out[3];          // n x 36 dwords each (Jacobian); unused groups: grp_end == n_terms
+    // window tables built ahead of the MSM (2 x 224 dwords per point: P and phi(P)): per-proof slots by the
+    // decompression kernel, VK bases at plan load.  NULL: every lane builds its own table into `tabws` (fold MSMs).
+    const uint32_t *pt_tab;    // [proof][slot][2][224]
+    const uint32_t *vk_tab;    // [base][2][224]
 };
 // A proof owns exactly 2 * n_terms consecutive lanes of a block (no power-of-two padding: 34 terms used to occupy
 // 128 lanes); the block holds as many whole proofs as fit, the rest of its lanes idle.
@@ -527,12 +534,6 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
 #pragma unroll
         for (int k = 0; k < 4; k++) kk[k] = half ? k2[k] : k1[k];
         if (!g1a_is_inf(base) && (kk[0] | kk[1] | kk[2] | kk[3]) != 0) {
-            if (half) {  // phi(P)
-                Fp beta;
-#pragma unroll
-                for (int k = 0; k < 12; k++) beta.v[k] = FP_BETA_GLV[k];
-                fp_mul(base.x, base.x, beta);
-            }
             // signed 4-bit recoding, least significant digit first: digit = dg[q] in [-8, 8]
             int8_t dg[33];
             uint32_t carry = 0;
@@ -543,32 +544,24 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
                 dg[q] = (int8_t)(carry ? (int)d - 16 : (int)d);
             }
             dg[32] = (int8_t)carry;
-            // table[m-1] = m*P, m = 1..8, AFFINE (x, y: 2 x 14 limbs), in a per-lane slab of the workspace:
-            // [lane][entry][28 dwords], so that the digit-indexed read of one entry is 112 contiguous bytes.  (A
-            // private-memory table is dword-interleaved across lanes: with per-lane digits every 4-byte read pulled
-            // its own sector, 2.4 GB fetched per launch.)  The seven multiples are normalised with one inversion
-            // (Montgomery's trick, ~47 k instructions) so that the 33 window additions are mixed ones (11 instead of 16
-            // field multiplications each, ~82 k instructions less).
-            uint32_t *tab = tabws + (((size_t)i * ma.n_terms + term) * 2 + half) * (8 * 28);
-            {
-                G1J28 t1, e[7];
-                g1j28_from_affine(t1, base);          // bases are points of G1 (validated / VK constants): every
-                g1j28_dbl_ool(e[0], t1);              // multiple below r is finite and the sums below are generic
-                (void)g1j28_add_ool(e[1], e[0], t1);
-                g1j28_dbl_ool(e[2], e[0]);
-                (void)g1j28_add_ool(e[3], e[2], t1);
-                g1j28_dbl_ool(e[4], e[1]);
-                (void)g1j28_add_ool(e[5], e[4], t1);
-                g1j28_dbl_ool(e[6], e[2]);
-                F28 ax[7], ay[7];
-                g1j28_batch_to_affine<7>(ax, ay, e);
+            // table[m-1] = m*P (half 0) or m*phi(P) (half 1), m = 1..8, AFFINE (x, y: 2 x 14 limbs), 112 contiguous
+            // bytes per entry.  Normally it was built ahead of this kernel - per-proof points by the decompression
+            // kernel (its square-root wave has the slack), VK bases at plan load - and is only read here; the fold
+            // MSMs of the recursion path build theirs on the spot in a per-lane slab of the workspace.  The multiples
+            // are affine (one inversion through Montgomery's trick) so that the 33 window additions are mixed ones.
+            const uint32_t *tab;
+            if (ma.pt_tab) {
+                tab = (is_vk ? ma.vk_tab + (size_t)idx * 448 : ma.pt_tab + ((size_t)i * slots + idx) * 448) + half * 224;
+            } else {
+                uint32_t *mine = tabws + (((size_t)i * ma.n_terms + term) * 2 + half) * 224;
+                if (half) {  // phi(P)
+                    Fp beta;
 #pragma unroll
-                for (int k = 0; k < 14; k++) { tab[k] = t1.x.l[k]; tab[14 + k] = t1.y.l[k]; }
-#pragma unroll 1
-                for (int m = 0; m < 7; m++) {
-#pragma unroll
-                    for (int k = 0; k < 14; k++) { tab[(m + 1) * 28 + k] = ax[m].l[k]; tab[(m + 1) * 28 + 14 + k] = ay[m].l[k]; }
+                    for (int k = 0; k < 12; k++) beta.v[k] = FP_BETA_GLV[k];
+                    fp_mul(base.x, base.x, beta);
                 }
+                g1_build_window_table(mine, base);
+                tab = mine;
             }
             // The ladder runs on the lazily reduced 28-bit field (h2v_fp28.cuh / h2v_curve28.cuh) and is only ever
             // touched by inlined code, so `lad` stays in VGPRs.
@@ -840,6 +833,18 @@ k_ivc_challenge(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, c
             for (int l = 0; l < 8; l++) ds[l] = (q & 1) ? c.v[l] : (l == 0 ? 1u : 0u);
         }
     }
+}
+
+// ============================================================================ plan load: window tables of the VK bases
+extern "C" __global__ void __launch_bounds__(64)
+k_vk_tables(const uint32_t *__restrict__ vk_bases, uint32_t n, uint32_t *__restrict__ vk_tab) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    G1A base;
+#pragma unroll
+    for (int k = 0; k < 12; k++) { base.x.v[k] = vk_bases[(size_t)b * 24 + k]; base.y.v[k] = vk_bases[(size_t)b * 24 + 12 + k]; }
+    if (g1a_is_inf(base)) return;   // the MSM skips an infinite base before it looks at the table
+    g1_build_window_tables_glv(vk_tab + (size_t)b * 448, base);
 }
 
 // ============================================================================ primitive probes (parity tests)

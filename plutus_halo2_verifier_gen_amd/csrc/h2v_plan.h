@@ -66,6 +66,7 @@ struct H2vDevPlan {
     uint32_t ivc, n_main_terms;
     uint32_t acc_idx[8];
     const uint32_t *fold_terms;  // 4 x (kind, index): el + c*acc_left, er + c*acc_right over the fold's own point buffer
+    const uint32_t *vk_tab;      // n_vk_bases x 2 x 224: affine window tables [1..8]B and [1..8]phi(B), built at plan load
 };
 // per-proof point slots: the proof's G1 elements, the committed instance, then (recursion) the two accumulator points
 #define H2V_SLOTS(plan) ((plan).n_points + (plan).n_ci + 2u * (plan).ivc)
