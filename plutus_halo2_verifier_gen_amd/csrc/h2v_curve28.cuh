@@ -156,6 +156,16 @@ H2V_DI void g1j28_batch_to_affine(F28 (&ax)[N], F28 (&ay)[N], const G1J28 (&pts)
 // out-of-line forms for the cold paths (window-table construction)
 H2V_DN void g1j28_dbl_ool(G1J28 &r, const G1J28 &p) { g1j28_dbl(r, p); }
 H2V_DN int g1j28_add_ool(G1J28 &r, const G1J28 &p, const G1J28 &q) { return g1j28_add(r, p, q, false); }
+H2V_DI void g1_store_table_entry(uint32_t *dst, const F28 &x, const F28 &y) {
+    uint4 *q = reinterpret_cast<uint4 *>(dst);
+    q[0] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+    q[1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    q[2] = make_uint4(x.l[8], x.l[9], x.l[10], x.l[11]);
+    q[3] = make_uint4(x.l[12], x.l[13], y.l[0], y.l[1]);
+    q[4] = make_uint4(y.l[2], y.l[3], y.l[4], y.l[5]);
+    q[5] = make_uint4(y.l[6], y.l[7], y.l[8], y.l[9]);
+    q[6] = make_uint4(y.l[10], y.l[11], y.l[12], y.l[13]);
+}
 // Window table of a base point for the MSM ladder: tab[m-1] = m * P, m = 1..8, AFFINE (x, y: 2 x 14 carried limbs,
 // 28 dwords per entry, 224 per table).  4 doublings + 3 additions, then one inversion for the seven multiples
 // (Montgomery's trick).  `base` is a finite curve point; for a point of G1 every multiple is finite.  (For a curve
@@ -164,22 +174,21 @@ H2V_DN int g1j28_add_ool(G1J28 &r, const G1J28 &p, const G1J28 &q) { return g1j2
 H2V_DN void g1_build_window_table(uint32_t *tab, const G1A &base) {
     G1J28 t1, e[7];
     g1j28_from_affine(t1, base);
-    g1j28_dbl_ool(e[0], t1);
-    (void)g1j28_add_ool(e[1], e[0], t1);
-    g1j28_dbl_ool(e[2], e[0]);
-    (void)g1j28_add_ool(e[3], e[2], t1);
-    g1j28_dbl_ool(e[4], e[1]);
-    (void)g1j28_add_ool(e[5], e[4], t1);
-    g1j28_dbl_ool(e[6], e[2]);
+    // odd multiples by mixed additions of P itself (affine): never exceptional for a point of G1 (m P = +-P only for
+    // m = 0, 2 mod r); for a curve point outside G1 the entries may be garbage, which nobody reads (see above)
+    g1j28_dbl(e[0], t1);
+    g1j28_madd_ladder(e[1], e[0], t1.x, t1.y, false);
+    g1j28_dbl(e[2], e[0]);
+    g1j28_madd_ladder(e[3], e[2], t1.x, t1.y, false);
+    g1j28_dbl(e[4], e[1]);
+    g1j28_madd_ladder(e[5], e[4], t1.x, t1.y, false);
+    g1j28_dbl(e[6], e[2]);
     F28 ax[7], ay[7];
     g1j28_batch_to_affine<7>(ax, ay, e);
-#pragma unroll
-    for (int k = 0; k < 14; k++) { tab[k] = t1.x.l[k]; tab[14 + k] = t1.y.l[k]; }
+    // 112-byte entries written as seven 16-byte stores (a table is 16-byte aligned: 896-byte stride)
+    g1_store_table_entry(tab, t1.x, t1.y);
 #pragma unroll 1
-    for (int m = 0; m < 7; m++) {
-#pragma unroll
-        for (int k = 0; k < 14; k++) { tab[(m + 1) * 28 + k] = ax[m].l[k]; tab[(m + 1) * 28 + 14 + k] = ay[m].l[k]; }
-    }
+    for (int m = 0; m < 7; m++) g1_store_table_entry(tab + (m + 1) * 28, ax[m], ay[m]);
 }
 // both tables of a point: [0] for P, [1] for phi(P) = (beta' x, y) (the GLV halves of the MSM)
 H2V_DN void g1_build_window_tables_glv(uint32_t *tab2, const G1A &base) {
@@ -192,12 +201,11 @@ H2V_DN void g1_build_window_tables_glv(uint32_t *tab2, const G1A &base) {
     // phi commutes with scalar multiplication: the second table is the first with every x multiplied by beta'
 #pragma unroll 1
     for (int m = 0; m < 8; m++) {
-        F28 x, bx;
+        F28 x, y, bx;
 #pragma unroll
-        for (int k = 0; k < 14; k++) x.l[k] = tab2[m * 28 + k];
+        for (int k = 0; k < 14; k++) { x.l[k] = tab2[m * 28 + k]; y.l[k] = tab2[m * 28 + 14 + k]; }
         f28_mul(bx, x, b28);
-#pragma unroll
-        for (int k = 0; k < 14; k++) { tab2[224 + m * 28 + k] = bx.l[k]; tab2[224 + m * 28 + 14 + k] = tab2[m * 28 + 14 + k]; }
+        g1_store_table_entry(tab2 + 224 + m * 28, bx, y);
     }
 }
 // acc (+flag) += (neg ? -q : q), q finite
