@@ -375,3 +375,26 @@ def test_plan_loader_rejects_mutated_blobs_without_a_gpu():
         for cut in (0, 7, 8, 100, len(blob) // 2, len(blob) - 1):
             assert load(blob[:cut]) in (E_PLAN, E_ARG)
         assert load(bytes(rng.randrange(256) for _ in range(4096))) == E_PLAN
+
+
+def test_generated_headers_are_current(tmp_path):
+    """csrc/bls_consts.h, coop_tables.h and coop_program.h are generated (and self-checked against big-integer
+    arithmetic) by tools/gen_*.py; the committed copies must be what the generators produce today."""
+    import shutil
+    csrc = os.path.join(ROOT, "plutus_halo2_verifier_gen_amd", "csrc")
+    names = {"gen_device_consts.py": "bls_consts.h", "gen_coop_tables.py": "coop_tables.h", "gen_coop_program.py": "coop_program.h"}
+    backup = {h: open(os.path.join(csrc, h)).read() for h in names.values()}
+    stamps = {h: os.stat(os.path.join(csrc, h)) for h in names.values()}
+    try:
+        for script, header in names.items():
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", script)], stdout=subprocess.DEVNULL)
+            assert open(os.path.join(csrc, header)).read() == backup[header], "%s is stale: run tools/%s" % (header, script)
+    finally:
+        for h, text in backup.items():
+            with open(os.path.join(csrc, h), "w") as f:
+                f.write(text)
+            os.utime(os.path.join(csrc, h), ns=(stamps[h].st_atime_ns, stamps[h].st_mtime_ns))   # no spurious rebuild
+    # the program generator also checks statically the value bounds the kernel's lazy field arithmetic relies on
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_coop_program
+    assert gen_coop_program.check_bounds(gen_coop_program.build_program())
