@@ -124,9 +124,11 @@ def main():
     k_steps = min(args.steps, 64)
     acc = {"transcript_combiner": 0.0, "g1_decompress": 0.0, "g1_msm": 0.0, "pairing": 0.0}
     launches = 1
+    msm_lpt = 2
     for back in range(k_steps):
         tm = ws.timings(back)
         launches = max(1, tm.launches)
+        msm_lpt = tm.msm_lanes_per_term or 2
         acc["transcript_combiner"] += tm.transcript_combiner_ms
         acc["g1_decompress"] += tm.g1_decompress_ms
         acc["g1_msm"] += tm.g1_msm_ms
@@ -164,7 +166,7 @@ def main():
         lds_slots = 64
         while lds_slots >= 8 and pl.n_regs * 32 * lds_slots + 8192 + 1024 > 160 * 1024:
             lds_slots >>= 1
-        kname = {"g1_msm": "k_g1_msm", "g1_decompress": "k_g1_decompress",
+        kname = {"g1_msm": "k_g1_msm_merged" if msm_lpt == 1 else "k_g1_msm", "g1_decompress": "k_g1_decompress",
                  "transcript_combiner": "k_transcript_combiner_lds" if lds_slots >= 8 else "k_transcript_combiner",
                  "pairing": "k_pairing_coop" if os.environ.get("H2V_PAIRING") != "legacy" else "k_pairing_check"}
 
@@ -194,10 +196,13 @@ def main():
                     "algorithmic_bytes_per_launch": bytes_per_launch[k] // launches}
 
         # analytical multiply-add counts per launch (lane-level v_mad_u64_u32), see DESIGN.md section 6
-        msm_lane = 128 * MAD_DBL + 31 * MAD_MADD          # 32 windows: 4 doublings + one mixed addition (tables are built ahead)
+        # per MSM lane: 32 windows of 4 doublings + one mixed addition per GLV half the lane carries (tables are built
+        # ahead); the launcher reports whether a term ran on two lanes (one half each) or on one (both halves)
+        msm_halves = 2 // msm_lpt
+        msm_lane = 128 * MAD_DBL + (32 * msm_halves - 1) * MAD_MADD
         tab_point = 4 * MAD_DBL + 3 * MAD_ADD + 48 * MAD_MUL + 14 * MAD_SQR    # window tables of one point: [1..8]P, normalised, and x beta
         mads = {
-            "g1_msm": B * T * 2 * msm_lane + B * (2 * T - 1) * MAD_ADD + B * 3 * MAD_MUL,
+            "g1_msm": B * T * msm_lpt * msm_lane + B * (msm_lpt * T - 1) * MAD_ADD + B * 3 * MAD_MUL,
             "pairing": B * 32 * (98 * (6 * 196 + 196) + (315 + 136) * (3 * 196 + 196)),     # coop program: MUL / CSQR+LINE
             "g1_decompress": B * slots * (380 * MAD_SQR + 190 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD + tab_point),
             "transcript_combiner": B * sum(128 for ins in pl.instrs if ins[0] == PL.OP_MUL),
@@ -231,7 +236,7 @@ def main():
             "int_roofline": int_roof(dominant),
             "msm_int_roofline": int_roof("g1_msm"),
             "kernel_ms": {kname[k]: round(v, 4) for k, v in kernel_ms.items()},
-            "pipelines_per_step": launches,
+            "pipelines_per_step": launches, "msm_lanes_per_term": msm_lpt,
             "all_accepted": ok_all,
             "reject_dataset": reject_check,
             "forge_seconds": round(t_forge, 2),

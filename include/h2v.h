@@ -59,10 +59,14 @@ typedef struct {
 
 /* optional per-stage device timings (milliseconds, HIP events on the streams the kernels run on).  A large batch is
  * cut into `launches` chunks that run as overlapping pipelines when H2V_PIPES > 1 (default 1): each *_ms is
- * the SUM of that kernel's launch durations over the chunks, total_ms the span from the first launch to the last end. */
+ * the SUM of that kernel's launch durations over the chunks, total_ms the span from the first launch to the last end.
+ * g1_decompress_ms is the longer of the decompression kernel's two concurrent launches (square roots + window tables
+ * on one stream, subgroup tests on another).  msm_lanes_per_term is the shape the MSM launcher chose for the call:
+ * 2 = one lane per GLV half, 1 = both halves on one lane (shared doublings). */
 typedef struct {
     float transcript_combiner_ms, g1_decompress_ms, g1_msm_ms, pairing_ms, total_ms;
     uint32_t launches;
+    uint32_t msm_lanes_per_term;
 } h2v_timings;
 
 /* ---- plan (VerifyingKey) lifecycle -------------------------------------------------------------------------

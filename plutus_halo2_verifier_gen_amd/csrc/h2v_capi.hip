@@ -50,7 +50,7 @@ struct h2v_workspace {
     // recursion (IVC): acc_left / acc_right_final sums, the fold's points + scalars, and the folded el / er
     uint32_t *accl = nullptr, *accr = nullptr, *fold_pts = nullptr, *fold_scal = nullptr, *el2 = nullptr, *er2 = nullptr;
     uint32_t *pt_tab = nullptr;  // MSM window tables of every per-proof point, written by the decompression kernel
-    uint8_t *valid = nullptr, *accept = nullptr;
+    uint8_t *valid = nullptr, *valid_sub = nullptr, *accept = nullptr;
     // staging for the host-buffer entry point
     uint8_t *in_proofs = nullptr, *in_inst = nullptr, *in_ci = nullptr;
     uint64_t *in_off = nullptr;
@@ -58,13 +58,14 @@ struct h2v_workspace {
     // A batch is cut into up to MAXP chunks that run as independent pipelines on their own stream pairs, so that one
     // chunk's decompression / transcript kernels (few waves) overlap another chunk's MSM / pairing kernels.
     static constexpr int MAXP = 4;
-    hipStream_t pmain[MAXP] = {}, pside[MAXP] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[MAXP] = {}, ev_done[MAXP] = {};
+    hipStream_t pmain[MAXP] = {}, pside[MAXP] = {}, psub[MAXP] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAXP] = {}, ev_sub[MAXP] = {}, ev_done[MAXP] = {};
     // ring of per-call, per-chunk event sets: [0]/[1] around the transcript+combiner kernel, [2]/[3] around the
-    // decompression kernel (side stream), [4]/[5] around the MSM, [5]/[6] around the pairing kernel
-    static constexpr int RING = 64, NEV = 7;
+    // decompression kernel's square-root half (side stream), [4]/[5] around the MSM, [5]/[6] around the pairing kernel,
+    // [7]/[8] around the decompression kernel's subgroup half (third stream)
+    static constexpr int RING = 64, NEV = 9;
     hipEvent_t ring[RING][MAXP][NEV] = {};
-    uint8_t ring_pipes[RING] = {};
+    uint8_t ring_pipes[RING] = {}, ring_split[RING] = {}, ring_lpt[RING] = {};
     uint64_t calls = 0;
 };
 
@@ -243,11 +244,13 @@ extern "C" int h2v_plan_trace_slots(const h2v_plan *p, uint32_t *slot_ids, uint3
 // ---------------------------------------------------------------------------------------------- workspace
 static void ws_release(h2v_workspace *w) {
     (void)hipSetDevice(w->device);
-    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off, w->msm_tab,
+    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off, w->msm_tab,
                     w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2, w->pt_tab};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipStream_t q : w->pmain) if (q) (void)hipStreamDestroy(q);
     for (hipStream_t q : w->pside) if (q) (void)hipStreamDestroy(q);
+    for (hipStream_t q : w->psub) if (q) (void)hipStreamDestroy(q);
+    for (hipEvent_t e : w->ev_sub) if (e) (void)hipEventDestroy(e);
     if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
     for (hipEvent_t e : w->ev_join) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : w->ev_done) if (e) (void)hipEventDestroy(e);
@@ -268,6 +271,7 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     WSALLOC(scalars, (size_t)max_batch * d.n_terms * 32)
     WSALLOC(pts, (size_t)max_batch * slots * 96)
     WSALLOC(valid, (size_t)max_batch * slots)
+    WSALLOC(valid_sub, (size_t)max_batch * slots)
     WSALLOC(er, (size_t)max_batch * 144)
     WSALLOC(pt_tab, (size_t)max_batch * slots * 448 * 4)             // per (proof, slot): [1..8]P and [1..8]phi(P), affine, 2 x 14 x 28-bit limbs
     if (d.ivc) { WSALLOC(msm_tab, (size_t)max_batch * 4 * 2 * 8 * 112) }  // fold MSMs build their four tables on the spot
@@ -286,6 +290,7 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     bool ok = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < h2v_workspace::MAXP && ok; k++)
         ok = hipStreamCreateWithFlags(&w->pmain[k], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&w->pside[k], hipStreamNonBlocking) == hipSuccess &&
+             hipStreamCreateWithFlags(&w->psub[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&w->ev_sub[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&w->ev_join[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->ev_done[k], hipEventDisableTiming) == hipSuccess;
     for (auto &call : w->ring) for (auto &set : call) for (hipEvent_t &e : set)
         if (ok) ok = hipEventCreate(&e) == hipSuccess;
@@ -325,23 +330,52 @@ static int launch_vm(const H2vDevPlan &d, uint32_t n, uint32_t stride, const uin
 }
 
 // MSM launch geometry: 2 lanes per (proof, term); LDS 172 B per thread (42 limbs + the infinity flag).
-static void launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const uint32_t *scalars, const uint32_t *pts,
-                             uint32_t *tabws, hipStream_t st) {
-    // 2 lanes per term; block = the multiple of 64 (<= 512) that wastes the smallest fraction of its lanes
-    const uint32_t lpp = 2 * ma.n_terms;
-    uint32_t bs = 64, best_waste = ~0u;
-    for (uint32_t cand = 64; cand <= 512; cand += 64) {
-        if (cand < lpp) continue;
-        const uint32_t waste = (cand - cand / lpp * lpp) * 4096 / cand;   // idle fraction, fixed point
-        if (waste < best_waste) { best_waste = waste; bs = cand; }
+static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const uint32_t *scalars, const uint32_t *pts,
+                                 uint32_t *tabws, hipStream_t st) {
+    // Launch shape from a cost model fitted to MI355X measurements:
+    //  * lanes per term: 2 = one lane per GLV half, chain of ~1250 multiplications; 1 = both halves on one accumulator,
+    //    chain ~1600 but 36 % less work per proof and half the waves;
+    //  * a wave alone on its SIMD runs ~1.7x faster than two sharing one (2048 proofs: 1.50 ms, 4096: 2.6 ms), and the
+    //    dispatcher only spreads one wave per SIMD for 64- and 256-thread blocks (128 / 192 / 320 / 384 / 448 / 512
+    //    put two waves of a block on the same SIMD: 2.5 ms where 64 / 256 take 1.5 ms at 1024 waves).
+    // cost = chain x (1 if every wave can sit alone, else 1.7 x whole rounds of two waves per SIMD: the waves of a
+    // launch all take the same time, so a partly filled round costs a full one); ties go to one-wave blocks, then to
+    // fewer idle lanes.
+    static const int env_lpt = []() { const char *e = getenv("H2V_MSM_LPT"); return e ? atoi(e) : 0; }();
+    static const uint32_t env_bs = []() { const char *e = getenv("H2V_MSM_BS"); return e ? (uint32_t)atoi(e) : 0u; }();
+    static const double n_simd = []() {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return 4.0 * cus;
+    }();
+    uint32_t lpt = 2, bs = 64;
+    double best = 1e300;
+    for (uint32_t cl = 2; cl >= 1; cl--) {
+        if (env_lpt && (uint32_t)env_lpt != cl) continue;
+        const uint32_t lpp_c = cl * ma.n_terms;
+        for (uint32_t cand = 64; cand <= 512; cand += 64) {
+            if (cand < lpp_c || (env_bs && cand != env_bs)) continue;
+            const uint32_t pb = cand / lpp_c;
+            const double waves = (double)((n + pb - 1) / pb) * (cand / 64), rho = waves / n_simd;
+            const bool spreads = cand == 64 || cand == 256;
+            const double chain = cl == 2 ? 1250.0 : 1600.0;
+            const double rounds = rho > 2.0 ? (double)(uint64_t)((rho + 1.999) / 2.0) : 1.0;
+            double cost = chain * ((spreads && rho <= 1.0) ? 1.0 : 1.7 * rounds);
+            cost *= 1.0 + (cand == 64 ? 0.0 : 0.01) + 0.005 * (double)(cand - pb * lpp_c) / cand;
+            if (cost < best) { best = cost; lpt = cl; bs = cand; }
+        }
     }
+    if (best == 1e300) { lpt = 2; bs = 512; }   // forced shape that does not fit: fall back to the widest block
+    const uint32_t lpp = lpt * ma.n_terms;
     const uint32_t per_block = bs / lpp;
     const uint32_t blocks = (n + per_block - 1) / per_block;
-    hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+    if (lpt == 1) hipLaunchKernelGGL(k_g1_msm_merged, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+    else hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+    return lpt;
 }
 // the proof's own MSM: terms [0, n_main_terms) of the plan's table, scalars from the combiner, points from decompression.
 // A recursive plan sums acc_left and acc_right + fixed bases in the same launch (three groups, three outputs).
-static void launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, const uint32_t *pt_tab,
+static uint32_t launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, const uint32_t *pt_tab,
                        uint32_t *er, uint32_t *accl, uint32_t *accr, hipStream_t st) {
     H2vMsmArgs ma = {d.terms, 0, d.n_main_terms, d.n_terms, 0, H2V_SLOTS(d), {d.n_main_terms, d.n_main_terms, d.n_main_terms}, {er, nullptr, nullptr},
                      pt_tab, d.vk_tab};
@@ -350,7 +384,7 @@ static void launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars,
         ma.grp_end[0] = d.n_main_terms; ma.grp_end[1] = d.n_main_terms + 1; ma.grp_end[2] = d.n_terms;
         ma.out[1] = accl; ma.out[2] = accr;
     }
-    launch_msm_range(d, ma, n, scalars, pts, nullptr, st);
+    return launch_msm_range(d, ma, n, scalars, pts, nullptr, st);
 }
 // Recursion (IVC) fold between the MSM and the pairing (emitters/aiken.rs:696-757): the batching challenge from
 // (el, er, acc_left, acc_right_final), then el' = el + c acc_left and er' = er + c acc_right_final in one two-group
@@ -364,15 +398,15 @@ static void launch_ivc_fold(const H2vDevPlan &d, uint32_t n, const uint32_t *pts
 }
 // Pairing kernel selection: the cooperative 16-lanes-per-proof kernel is the product path; the one-lane-per-proof
 // kernel stays as a cross-check (H2V_PAIRING=legacy, or impl = 0 in the probe).
-static void launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint32_t *er,
+static void launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
                                 const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st) {
-    if (impl == 0) hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, er, el_jac, status, accept, dbg);
-    else hipLaunchKernelGGL(k_pairing_coop, dim3((n + 1) / 2), dim3(64), 0, st, d, n, pts, valid, er, el_jac, status, accept, dbg);
+    if (impl == 0) hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
+    else hipLaunchKernelGGL(k_pairing_coop, dim3((n + 1) / 2), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
 }
-static void launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint32_t *er,
+static void launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
                            const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st) {
     static const int impl = []() { const char *e = getenv("H2V_PAIRING"); return (e && strcmp(e, "legacy") == 0) ? 0 : 1; }();
-    launch_pairing_impl(impl, d, n, pts, valid, er, el_jac, status, accept, dbg, st);
+    launch_pairing_impl(impl, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, st);
 }
 
 // ---------------------------------------------------------------------------------------------- pipeline
@@ -396,14 +430,14 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipGetLastError());                                                              \
         HIPCHK(hipDeviceSynchronize());                                                         \
         fprintf(stderr, "[h2v] %s done\n", name); fflush(stderr);
-        DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(128), 0, st, d, n, proofs, off, ci, inst, w->pts, w->valid, w->pt_tab))
+        DBG_STAGE("k_g1_decompress", hipLaunchKernelGGL(k_g1_decompress, dim3(dec_blocks), dim3(128), 0, st, d, n, proofs, off, ci, inst, w->pts, w->valid, w->pt_tab, 0u, (uint8_t *)nullptr))
         DBG_STAGE("k_transcript_combiner", { int rcv = launch_vm(d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, status, trace, st); if (rcv) return rcv; })
         DBG_STAGE("k_g1_msm", launch_msm(d, n, w->scalars, w->pts, w->pt_tab, w->er, w->accl, w->accr, st))
         if (d.ivc) {
             const IvcBufs ib = {w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2};
             DBG_STAGE("ivc fold", launch_ivc_fold(d, n, w->pts, w->er, ib, w->msm_tab, st))
         }
-        DBG_STAGE("k_pairing_check", launch_pairing(d, n, w->pts, w->valid, d.ivc ? w->er2 : w->er, d.ivc ? w->el2 : nullptr, status, accept, nullptr, st))
+        DBG_STAGE("k_pairing_check", launch_pairing(d, n, w->pts, w->valid, nullptr, d.ivc ? w->er2 : w->er, d.ivc ? w->el2 : nullptr, status, accept, nullptr, st))
 #undef DBG_STAGE
         if (status_out) HIPCHK(hipMemcpyAsync(status_out, status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         return H2V_OK;
@@ -411,12 +445,14 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
     // number of chunks (H2V_PIPES).  Default 1: measured on MI355X, 2/3/4 concurrent pipelines of a 4096-proof batch
     // took 14.2 / 20.7 / 29.1 ms against 13.5 ms for one (kernels with different private-segment sizes alternating on
     // several queues cost more than the idle SIMDs they fill), so the split is kept as an experiment knob only.
+    static const bool split_dec = []() { const char *e = getenv("H2V_SPLIT_DEC"); return e ? atoi(e) != 0 : true; }();
     static const int env_pipes = []() { const char *e = getenv("H2V_PIPES"); return e ? atoi(e) : 0; }();
     int pipes = env_pipes > 0 ? env_pipes : 1;
     if (pipes > h2v_workspace::MAXP) pipes = h2v_workspace::MAXP;
     if (want_trace || (uint32_t)pipes > n) pipes = 1;
     const int slot = (int)(w->calls % h2v_workspace::RING);
     w->ring_pipes[slot] = (uint8_t)pipes;
+    w->ring_split[slot] = split_dec ? 1 : 0;
     w->calls++;
     HIPCHK(hipEventRecord(w->ev_fork, st));
     for (int k = 0; k < pipes; k++) {
@@ -432,28 +468,58 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         HIPCHK(hipStreamWaitEvent(pm, w->ev_fork, 0));
         HIPCHK(hipStreamWaitEvent(ps, w->ev_fork, 0));
         // decompression (many short waves) runs beside the transcript+combiner kernel (few long waves)
-        HIPCHK(hipEventRecord(ev[2], ps));
         uint32_t *pt_tab_k = w->pt_tab + (size_t)lo * slots * 448;
-        hipLaunchKernelGGL(k_g1_decompress, dim3((m * slots + 63) / 64), dim3(128), 0, ps, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, pt_tab_k);
-        HIPCHK(hipEventRecord(ev[3], ps));
-        HIPCHK(hipEventRecord(w->ev_join[k], ps));
-        HIPCHK(hipEventRecord(ev[0], pm));
-        { int rcv = launch_vm(d, m, w->stride, proofs, off_k, inst_k, ci_k, regs_k, scal_k, status_k, trace, pm); if (rcv) return rcv; }
-        HIPCHK(hipEventRecord(ev[1], pm));
+        uint8_t *vsub_k = split_dec ? w->valid_sub + (size_t)lo * slots : nullptr;
+        const uint32_t dec_grid = (m * slots + 63) / 64;
+        int rcv = 0;
+        auto vm = [&]() {
+            HIPCHK(hipEventRecord(ev[0], pm));
+            rcv = launch_vm(d, m, w->stride, proofs, off_k, inst_k, ci_k, regs_k, scal_k, status_k, trace, pm);
+            HIPCHK(hipEventRecord(ev[1], pm));
+            return 0;
+        };
+        auto sqrt_half = [&]() {
+            HIPCHK(hipEventRecord(ev[2], ps));
+            if (split_dec) hipLaunchKernelGGL(k_g1_decompress, dim3(dec_grid), dim3(64), 0, ps, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, pt_tab_k, 1u, (uint8_t *)nullptr);
+            else hipLaunchKernelGGL(k_g1_decompress, dim3(dec_grid), dim3(128), 0, ps, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, pt_tab_k, 0u, (uint8_t *)nullptr);
+            HIPCHK(hipEventRecord(ev[3], ps));
+            HIPCHK(hipEventRecord(w->ev_join[k], ps));
+            return 0;
+        };
+        auto sub_half = [&]() {
+            // the MSM needs coordinates and window tables only: the (longer) subgroup chain gets its own launch and is
+            // joined before the pairing kernel, which is where the verdict on the points is read
+            if (!split_dec) return 0;
+            hipStream_t pb = w->psub[k];
+            HIPCHK(hipStreamWaitEvent(pb, w->ev_fork, 0));
+            HIPCHK(hipEventRecord(ev[7], pb));
+            hipLaunchKernelGGL(k_g1_decompress, dim3(dec_grid), dim3(64), 0, pb, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, (uint32_t *)nullptr, 2u, vsub_k);
+            HIPCHK(hipEventRecord(ev[8], pb));
+            HIPCHK(hipEventRecord(w->ev_sub[k], pb));
+            return 0;
+        };
+        // launch order measured on MI355X (the dispatcher gives the first grid the emptier SIMDs): square roots first,
+        // so that the MSM's inputs are the part that finishes early
+        const int rco = sqrt_half() || sub_half() || vm();
+        if (rco) return rco;
+        if (rcv) return rcv;
         HIPCHK(hipStreamWaitEvent(pm, w->ev_join[k], 0));
+        // The MSM also waits for the subgroup launch although it does not read its result: a merged-halves MSM relies on
+        // finding every SIMD empty (one wave each: 1.9 ms; a SIMD shared with a leftover wave: 2.2 ms for the launch)
+        if (split_dec) HIPCHK(hipStreamWaitEvent(pm, w->ev_sub[k], 0));
         HIPCHK(hipEventRecord(ev[4], pm));
         uint32_t *tab_k = d.ivc ? w->msm_tab + (size_t)lo * 4 * 2 * 8 * 28 : nullptr;   // fold MSMs only
         const IvcBufs ib = {d.ivc ? w->accl + (size_t)lo * 36 : nullptr, d.ivc ? w->accr + (size_t)lo * 36 : nullptr,
                             d.ivc ? w->fold_pts + (size_t)lo * 96 : nullptr, d.ivc ? w->fold_scal + (size_t)lo * 32 : nullptr,
                             d.ivc ? w->el2 + (size_t)lo * 36 : nullptr, d.ivc ? w->er2 + (size_t)lo * 36 : nullptr};
-        launch_msm(d, m, scal_k, pts_k, pt_tab_k, er_k, ib.accl, ib.accr, pm);
+        w->ring_lpt[slot] = (uint8_t)launch_msm(d, m, scal_k, pts_k, pt_tab_k, er_k, ib.accl, ib.accr, pm);
         const uint32_t *er_in = er_k, *el_in = nullptr;
         if (d.ivc) {   // (timed with the MSM: the challenge hash and one more pass of the same kernel)
             launch_ivc_fold(d, m, pts_k, er_k, ib, tab_k, pm);
             er_in = ib.er2; el_in = ib.el2;
         }
         HIPCHK(hipEventRecord(ev[5], pm));
-        launch_pairing(d, m, pts_k, valid_k, er_in, el_in, status_k, accept_k, nullptr, pm);
+        launch_pairing(d, m, pts_k, valid_k, vsub_k, er_in, el_in, status_k, accept_k, nullptr, pm);
         HIPCHK(hipEventRecord(ev[6], pm));
         HIPCHK(hipEventRecord(w->ev_done[k], pm));
         HIPCHK(hipStreamWaitEvent(st, w->ev_done[k], 0));
@@ -502,6 +568,7 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
     const int pipes = w->ring_pipes[slot];
     memset(tm, 0, sizeof *tm);
     tm->launches = (uint32_t)pipes;
+    tm->msm_lanes_per_term = w->ring_lpt[slot];
     float first_start = 0, last_end = 0;
     for (int k = 0; k < pipes; k++) {
         hipEvent_t *ev = w->ring[slot][k];
@@ -509,6 +576,17 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
         float a, b, c, e, t0 = 0, t1 = 0;
         HIPCHK(hipEventElapsedTime(&a, ev[0], ev[1]));
         HIPCHK(hipEventElapsedTime(&b, ev[2], ev[3]));
+        if (getenv("H2V_TIMELINE")) {
+            const int ne = w->ring_split[slot] ? 9 : 7;
+            fprintf(stderr, "[h2v timeline]");
+            for (int q = 0; q < ne; q++) { float t; HIPCHK(hipEventElapsedTime(&t, ev[0], ev[q])); fprintf(stderr, " e%d=%.3f", q, t); }
+            fprintf(stderr, "\n");
+        }
+        if (w->ring_split[slot]) {   // two concurrent launches: report the longer one
+            float b2;
+            HIPCHK(hipEventElapsedTime(&b2, ev[7], ev[8]));
+            if (b2 > b) b = b2;
+        }
         HIPCHK(hipEventElapsedTime(&c, ev[4], ev[5]));
         HIPCHK(hipEventElapsedTime(&e, ev[5], ev[6]));
         tm->transcript_combiner_ms += a; tm->g1_decompress_ms += b; tm->g1_msm_ms += c; tm->pairing_ms += e;
@@ -679,7 +757,7 @@ extern "C" int h2v_probe_g1_decompress(int device, uint32_t n, const uint8_t *co
     if (mp.build(1, 0, nullptr, nullptr) || upload_offsets(doff, n, 48) || din.alloc((size_t)n * 48) || dpts.alloc((size_t)n * 96) ||
         dvalid.alloc(n) || dout.alloc((size_t)n * 96)) return fail(H2V_E_DEVICE, "probe setup failed");
     HIPCHK(hipMemcpy(din.p, compressed, (size_t)n * 48, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_g1_decompress, dim3((n + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), (uint32_t *)nullptr, 0u, (uint8_t *)nullptr);
     hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 0, dpts.as<uint32_t>(), dout.as<uint8_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
@@ -699,7 +777,7 @@ extern "C" int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_
     HIPCHK(hipMemcpy(din.p, bases_compressed, (size_t)n * T * 48, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dsc.p, scalars, (size_t)n * T * 32, hipMemcpyHostToDevice));
     if (dtab.alloc((size_t)n * T * 448 * 4)) return fail(H2V_E_DEVICE, "hipMalloc failed");
-    hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), dtab.as<uint32_t>());
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), dtab.as<uint32_t>(), 0u, (uint8_t *)nullptr);
     launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), dtab.as<uint32_t>(), der.as<uint32_t>(), nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 1, der.as<uint32_t>(), dout.as<uint8_t>());
     HIPCHK(hipGetLastError());
@@ -733,10 +811,10 @@ extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t
     HIPCHK(hipMemcpy(dsc.p, one.data(), one.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dst.p, 0, (size_t)n * 4));
     if (dtab.alloc((size_t)n * 2 * 448 * 4)) return fail(H2V_E_DEVICE, "hipMalloc failed");
-    hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), dtab.as<uint32_t>());
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n * 2 + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), dtab.as<uint32_t>(), 0u, (uint8_t *)nullptr);
     launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), dtab.as<uint32_t>(), der.as<uint32_t>(), nullptr, nullptr, nullptr);
     if (ddbg.alloc(dbg ? (size_t)n * 24 * 48 : 8)) return fail(H2V_E_DEVICE, "hipMalloc failed");
-    launch_pairing_impl(impl, mp.d, n, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), der.as<uint32_t>(), nullptr, dst.as<uint32_t>(), dacc.as<uint8_t>(), dbg ? ddbg.as<uint32_t>() : nullptr, nullptr);
+    launch_pairing_impl(impl, mp.d, n, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), nullptr, der.as<uint32_t>(), nullptr, dst.as<uint32_t>(), dacc.as<uint8_t>(), dbg ? ddbg.as<uint32_t>() : nullptr, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, dacc.p, n, hipMemcpyDeviceToHost));

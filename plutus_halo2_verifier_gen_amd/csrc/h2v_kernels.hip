@@ -365,10 +365,14 @@ H2V_DN void acc_coordinate(Fp &r, const uint8_t *ins, uint32_t idx_hi, uint32_t 
 extern "C" __global__ void __launch_bounds__(128, 2)
 k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
                 const uint8_t *__restrict__ committed, const uint8_t *__restrict__ instances,
-                uint32_t *__restrict__ pts, uint8_t *__restrict__ valid, uint32_t *__restrict__ pt_tab /* or NULL */) {
+                uint32_t *__restrict__ pts, uint8_t *__restrict__ valid, uint32_t *__restrict__ pt_tab /* or NULL */,
+                uint32_t mode, uint8_t *__restrict__ valid_sub) {
+    // mode 0: both roles in one 128-thread block (valid = on curve && in G1);  modes 1 / 2: one role per launch
+    // (64-thread blocks) so that the MSM, which needs coordinates and tables only, does not wait for the longer
+    // subgroup chain: 1 = square root + tables (valid = encoding / on curve), 2 = subgroup test (valid_sub)
     __shared__ uint8_t sub_ok[H2V_DEC_PTS];
     const uint32_t slots = H2V_SLOTS(plan);
-    const uint32_t role = threadIdx.x >> 6;
+    const uint32_t role = mode == 0 ? threadIdx.x >> 6 : mode - 1;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t gid = blockIdx.x * H2V_DEC_PTS + lane;
     const bool live = gid < n * slots;
@@ -454,10 +458,16 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
             }
         }
     }
-    if (role == 1) sub_ok[lane] = ok ? 1 : 0;
-    __syncthreads();
+    if (mode == 2) {
+        if (live) valid_sub[gid] = ok ? 1 : 0;
+        return;
+    }
+    if (mode == 0) {
+        if (role == 1) sub_ok[lane] = ok ? 1 : 0;
+        __syncthreads();
+    }
     if (role == 0 && live) {
-        ok = ok && sub_ok[lane] != 0;
+        if (mode == 0) ok = ok && sub_ok[lane] != 0;
         if (!ok) g1a_set_inf(out);
 #pragma unroll
         for (int k = 0; k < 12; k++) { pts[(size_t)gid * 24 + k] = out.x.v[k]; pts[(size_t)gid * 24 + 12 + k] = out.y.v[k]; }
@@ -492,23 +502,30 @@ struct H2vMsmArgs {
     const uint32_t *pt_tab;    // [proof][slot][2][224]
     const uint32_t *vk_tab;    // [base][2][224]
 };
-// A proof owns exactly 2 * n_terms consecutive lanes of a block (no power-of-two padding: 34 terms used to occupy
+// A proof owns exactly LPT * n_terms consecutive lanes of a block (no power-of-two padding: 34 terms used to occupy
 // 128 lanes); the block holds as many whole proofs as fit, the rest of its lanes idle.
-extern "C" __global__ void __launch_bounds__(512, 2)
-k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
-         const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
-    extern __shared__ uint32_t red[];  // Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t]
+//
+// LPT = lanes per term.  2: one lane per GLV half (shortest chain: 128 doublings + 33 additions per lane).
+// 1: one lane runs both halves of its term on ONE accumulator, so the 128 doublings are shared (128 doublings + 66
+// additions per lane, 36 % less work per proof, half the waves).  Measured on MI355X one wave per SIMD of this code
+// already reaches 85 % of what two deliver (2048 proofs: 1.54 ms, 4096: 2.60 ms with LPT = 2), so whenever the batch
+// still fills the SIMDs with one lane per term the smaller total wins; the launcher picks (h2v_capi.hip).
+template <int LPT>
+H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, uint32_t per_block,
+                     const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws,
+                     uint32_t *red /* Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t] */) {
+    constexpr int NH = 2 / LPT;   // GLV halves per lane
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
-    const uint32_t lanes_per_proof = 2 * ma.n_terms;
+    const uint32_t lanes_per_proof = LPT * ma.n_terms;
     const uint32_t seg = tid / lanes_per_proof;       // which of the block's proofs
     const uint32_t sub = tid - seg * lanes_per_proof; // position inside the proof's segment
-    const uint32_t term = sub >> 1, half = sub & 1;
+    const uint32_t term = LPT == 2 ? sub >> 1 : sub, half = LPT == 2 ? sub & 1 : 0;
     const uint32_t i = blockIdx.x * per_block + seg;
     const bool active = seg < per_block && i < n;
     // this lane's group: position and length of its reduction segment inside the proof's lanes
     const uint32_t grp = term < ma.grp_end[0] ? 0u : (term < ma.grp_end[1] ? 1u : 2u);
     const uint32_t g_lo = grp == 0 ? 0u : ma.grp_end[grp - 1];
-    const uint32_t gsub = sub - 2 * g_lo, glen = 2 * (ma.grp_end[grp] - g_lo);
+    const uint32_t gsub = sub - LPT * g_lo, glen = LPT * (ma.grp_end[grp] - g_lo);
     // this lane's partial sum, on the lazily reduced field with an explicit infinity flag (h2v_curve28.cuh); idle
     // lanes and skipped terms contribute the point at infinity
     G1J28 lad;
@@ -526,33 +543,46 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
         G1A base;
 #pragma unroll
         for (int k = 0; k < 12; k++) { base.x.v[k] = bp[k]; base.y.v[k] = bp[12 + k]; }
-        uint32_t s[8], k1[4], k2[4], kk[4];
+        uint32_t s[8], k1[4], k2[4];
         const uint32_t *sp = scalars + ((size_t)i * ma.scal_stride + ma.scal_col_base + term) * 8;
 #pragma unroll
         for (int k = 0; k < 8; k++) s[k] = sp[k];
         glv_split(k1, k2, s);
+        uint32_t any = 0;
+        if (LPT == 2) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) kk[k] = half ? k2[k] : k1[k];
-        if (!g1a_is_inf(base) && (kk[0] | kk[1] | kk[2] | kk[3]) != 0) {
-            // signed 4-bit recoding, least significant digit first: digit = dg[q] in [-8, 8]
-            int8_t dg[33];
-            uint32_t carry = 0;
+            for (int k = 0; k < 4; k++) any |= half ? k2[k] : k1[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) any |= k1[k] | k2[k];
+        }
+        if (!g1a_is_inf(base) && any != 0) {
+            // signed 4-bit recoding, least significant digit first: digit = dg[h][q] in [-8, 8]
+            int8_t dg[NH][33];
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                uint32_t kk[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) kk[k] = (LPT == 2 ? half != 0 : h != 0) ? k2[k] : k1[k];
+                uint32_t carry = 0;
 #pragma unroll 1
-            for (int q = 0; q < 32; q++) {
-                uint32_t d = ((kk[q >> 3] >> (4 * (q & 7))) & 15u) + carry;
-                carry = d > 8 ? 1u : 0u;
-                dg[q] = (int8_t)(carry ? (int)d - 16 : (int)d);
+                for (int q = 0; q < 32; q++) {
+                    uint32_t d = ((kk[q >> 3] >> (4 * (q & 7))) & 15u) + carry;
+                    carry = d > 8 ? 1u : 0u;
+                    dg[h][q] = (int8_t)(carry ? (int)d - 16 : (int)d);
+                }
+                dg[h][32] = (int8_t)carry;
             }
-            dg[32] = (int8_t)carry;
             // table[m-1] = m*P (half 0) or m*phi(P) (half 1), m = 1..8, AFFINE (x, y: 2 x 14 limbs), 112 contiguous
-            // bytes per entry.  Normally it was built ahead of this kernel - per-proof points by the decompression
-            // kernel (its square-root wave has the slack), VK bases at plan load - and is only read here; the fold
-            // MSMs of the recursion path build theirs on the spot in a per-lane slab of the workspace.  The multiples
-            // are affine (one inversion through Montgomery's trick) so that the 33 window additions are mixed ones.
-            const uint32_t *tab;
+            // bytes per entry, the two halves 224 dwords apart.  Normally it was built ahead of this kernel -
+            // per-proof points by the decompression kernel (its square-root wave has the slack), VK bases at plan
+            // load - and is only read here; the fold MSMs of the recursion path build theirs on the spot in a per-lane
+            // slab of the workspace.  The multiples are affine (one inversion through Montgomery's trick) so that the
+            // window additions are mixed ones.
+            const uint32_t *tab;   // of this lane's first half
             if (ma.pt_tab) {
                 tab = (is_vk ? ma.vk_tab + (size_t)idx * 448 : ma.pt_tab + ((size_t)i * slots + idx) * 448) + half * 224;
-            } else {
+            } else if (LPT == 2) {
                 uint32_t *mine = tabws + (((size_t)i * ma.n_terms + term) * 2 + half) * 224;
                 if (half) {  // phi(P)
                     Fp beta;
@@ -562,18 +592,32 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
                 }
                 g1_build_window_table(mine, base);
                 tab = mine;
+            } else {
+                uint32_t *mine = tabws + ((size_t)i * ma.n_terms + term) * 448;
+                g1_build_window_tables_glv(mine, base);
+                tab = mine;
             }
             // The ladder runs on the lazily reduced 28-bit field (h2v_fp28.cuh / h2v_curve28.cuh) and is only ever
             // touched by inlined code, so `lad` stays in VGPRs.
+            //
+            // Exceptional additions.  The accumulator is [a]P + [b]phi(P) = [a + b lambda]P with (a, b) the signed
+            // prefixes read so far (not both zero once a digit was non-zero: a signed-digit prefix with a non-zero
+            // leading digit is non-zero).  Adding [d]P (or [d]phi(P)) is exceptional iff (a -+ d, b) (or (a, b -+ d))
+            // lies in the lattice {(u, v): u + v lambda = 0 mod r}, whose non-zero vectors are longer than 2^126
+            // (reduced basis (lambda, -1), (1, lambda + 1), lambda = x^2 - 1 > 2^127).  With one half per lane b = 0
+            // and a < 2^129 < r: never.  With both halves on one lane the prefixes stay below 2^(4 (33 - q)) + 8 in
+            // window q, so windows q >= 2 are safe and only the last two take the complete addition.
 #pragma unroll 1
             for (int q = 32; q >= 0; q--) {
                 if (q != 32 && !lad_inf) {
 #pragma unroll 1
                     for (int rep = 0; rep < 4; rep++) g1j28_dbl_t<true>(lad, lad);   // multiplier inlined: no argument marshalling
                 }
-                const int d = dg[q];
-                if (d != 0) {
-                    const uint32_t *ent = tab + ((d < 0 ? -d : d) - 1) * 28;
+#pragma unroll 1
+                for (int h = 0; h < NH; h++) {
+                    const int d = dg[h][q];
+                    if (d == 0) continue;
+                    const uint32_t *ent = tab + h * 224 + ((d < 0 ? -d : d) - 1) * 28;
                     F28 qx, qy;
 #pragma unroll
                     for (int k = 0; k < 14; k++) { qx.l[k] = ent[k]; qy.l[k] = ent[14 + k]; }
@@ -583,8 +627,13 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
                         if (d < 0) { F28_NEG(lad.y, qy, 3, 1); f28_carry(lad.y); }
                         f28_set_one(lad.z);
                         lad_inf = false;
+                    } else if (LPT == 2 || q >= 2) {
+                        g1j28_madd_ladder(lad, lad, qx, qy, d < 0);   // never an exceptional case (above)
                     } else {
-                        g1j28_madd_ladder(lad, lad, qx, qy, d < 0);   // never an exceptional case: see its comment
+                        G1J28 o;
+                        o.x = qx; o.y = qy;
+                        f28_set_one(o.z);
+                        g1j28_acc_add(lad, lad_inf, o, d < 0);
                     }
                 }
             }
@@ -631,6 +680,18 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
             out[(size_t)i * 36 + 24 + k] = acc.z.v[k];
         }
     }
+}
+extern "C" __global__ void __launch_bounds__(512, 2)
+k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
+         const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
+    extern __shared__ uint32_t red[];
+    msm_body<2>(plan, ma, n, per_block, scalars, pts, tabws, red);
+}
+extern "C" __global__ void __launch_bounds__(512, 2)
+k_g1_msm_merged(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
+                const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
+    extern __shared__ uint32_t red[];
+    msm_body<1>(plan, ma, n, per_block, scalars, pts, tabws, red);
 }
 
 // ============================================================================ K5: pairing check
@@ -695,7 +756,7 @@ H2V_DN bool final_exp_is_one(const Fp12 &f) {
 }
 
 extern "C" __global__ void __launch_bounds__(64)
-k_pairing_check(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid,
+k_pairing_check(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
                 const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac /* folded el (recursion) or NULL */,
                 uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -703,7 +764,7 @@ k_pairing_check(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, c
     const uint32_t slots = H2V_SLOTS(plan);
     uint32_t st = status[i];
     for (uint32_t j = 0; j < slots; j++)
-        if (!valid[(size_t)i * slots + j]) st |= H2V_ST_BAD_POINT;
+        if (!valid[(size_t)i * slots + j] || (valid_sub && !valid_sub[(size_t)i * slots + j])) st |= H2V_ST_BAD_POINT;
     if (st == 0) {
         G1A el, er;
         G1J ej;

@@ -319,7 +319,7 @@ H2V_DI F28 coop_inv(const Coop &c, const F28 &f, bool &ok) {
 // live across the engine call (the first version kept them in VGPRs and spent 65 % of its wave-cycles waiting on
 // the spills around every call).
 extern "C" __global__ void __launch_bounds__(64, 2)
-k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid,
+k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
                const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac /* folded el (recursion) or NULL */,
                uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
     const int lane = threadIdx.x, grp = lane >> 5;
@@ -351,7 +351,7 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
     if (is_leader) {
         st = status[ii];
         for (uint32_t j = 0; j < slots; j++)
-            if (!valid[(size_t)ii * slots + j]) st |= H2V_ST_BAD_POINT;
+            if (!valid[(size_t)ii * slots + j] || (valid_sub && !valid_sub[(size_t)ii * slots + j])) st |= H2V_ST_BAD_POINT;
         G1A el, er;
         G1J ej;
         const uint32_t *pp = pts + ((size_t)ii * slots + plan.pi_point) * 24;

@@ -389,10 +389,13 @@ def test_circuit_without_public_inputs(be):
     assert 0 < sum(got) < 20
 
 
-@pytest.mark.parametrize("env", [{"H2V_PIPES": "3"}, {"H2V_PAIRING": "legacy"}, {"H2V_DEBUG_SYNC": "1"}])
+@pytest.mark.parametrize("env", [{"H2V_PIPES": "3"}, {"H2V_PAIRING": "legacy"}, {"H2V_DEBUG_SYNC": "1"},
+                                 {"H2V_MSM_LPT": "1"}, {"H2V_MSM_LPT": "2", "H2V_MSM_BS": "256"}, {"H2V_SPLIT_DEC": "0"}])
 def test_alternate_pipeline_modes(be, env, tmp_path):
-    """The experiment knobs of the pipeline (chunked sub-batches on several streams, the one-lane pairing kernel, the
-    serialised debug path) are read once per process, so each runs in a child process; same verdicts."""
+    """The knobs of the pipeline (chunked sub-batches on several streams, the one-lane pairing kernel, the serialised
+    debug path, the MSM launch shape - one or two lanes per term, block size - that the cost model would otherwise
+    pick from the batch size, the unsplit decompression kernel) are read once per process, so each runs in a child
+    process; same verdicts."""
     import os
     import subprocess
     import sys
@@ -409,3 +412,17 @@ def test_alternate_pipeline_modes(be, env, tmp_path):
         "print('modes ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", script], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "modes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("lpt", ["1", "2"])
+def test_g1_msm_forced_shape(be, lpt):
+    """test_g1_msm (edge scalars, equal / opposite / infinity bases, T = 1 .. 64) again with the MSM shape forced: the
+    probe's small batches would otherwise always take two lanes per term."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_g1_msm and not forced"], env={**os.environ, "H2V_MSM_LPT": lpt}, cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
