@@ -42,8 +42,8 @@ WORKLOADS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="simple_mul", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="proofs per GPU (default: the workload's BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
