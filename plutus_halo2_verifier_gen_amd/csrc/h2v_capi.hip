@@ -69,6 +69,9 @@ struct h2v_workspace {
     uint64_t calls = 0;
 };
 
+// LDS left for the combiner's register file in a block: 160 KB minus the 8 KB hash buffer and 1 KB of slack
+// (plan.py: VM_LDS_BYTES)
+#define H2V_VM_LDS_BYTES ((size_t)160 * 1024 - 8192 - 1024)
 static uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 // ---------------------------------------------------------------------------------------------- plan
 extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_plan **out) {
@@ -105,34 +108,85 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
         for (int k = 0; k < 8; k++)
             if (w[H2V_HW_ACC_IDX0 + k] >= n_pi) return fail(H2V_E_PLAN, "accumulator public-input index out of range");
     if (w[H2V_HW_PI_POINT] >= n_points) return fail(H2V_E_PLAN, "pi point index out of range");
-    // validate the program: every register / constant / offset the kernels will touch is in range
-    const uint8_t *ip = blob + w[H2V_HW_OFF_INSTR];
-    bool has_end = false;
+    // validate the program(s): every register / constant / offset the kernels will touch is in range, and the bundle
+    // discipline the multi-lane interpreter relies on holds (h2v_plan.h)
     uint32_t n_sq = 0;
-    for (uint32_t k = 0; k < n_instr; k++) {
-        const uint8_t op = ip[8 * k];
-        const uint32_t dst = ip[8 * k + 2] | (ip[8 * k + 3] << 8), a = ip[8 * k + 4] | (ip[8 * k + 5] << 8), b = ip[8 * k + 6] | (ip[8 * k + 7] << 8);
-        const uint32_t off = a | (b << 16);
-        bool ok = true;
-        switch (op) {
-        case H2V_OP_END: has_end = true; break;
-        case H2V_OP_ABSORB_REG: ok = a < n_regs; break;
-        case H2V_OP_ABSORB_CI: ok = n_ci == 1; break;
-        case H2V_OP_LOAD_INSTANCE: ok = dst < n_regs && a < n_pi; break;
-        case H2V_OP_READ_POINT: ok = (uint64_t)off + 48 <= proof_len; break;
-        case H2V_OP_READ_SCALAR: ok = dst < n_regs && (uint64_t)off + 32 <= proof_len; break;
-        case H2V_OP_SQUEEZE: ok = dst < n_regs; n_sq++; break;
-        case H2V_OP_CONST: ok = dst < n_regs && a < n_consts; break;
-        case H2V_OP_ADD: case H2V_OP_SUB: case H2V_OP_MUL: ok = dst < n_regs && a < n_regs && b < n_regs; break;
-        case H2V_OP_NEG: case H2V_OP_INV: ok = dst < n_regs && a < n_regs; break;
-        case H2V_OP_OUT_SCALAR: ok = dst < n_terms && a < n_regs; break;
-        case H2V_OP_ASSERT_ZERO: ok = a < n_regs; break;
-        default: ok = false;
+    auto check_program = [&](const uint8_t *ip, uint32_t n_rec, uint32_t n_regs_v, uint32_t lanes, uint32_t *squeezes) -> int {
+        if (lanes == 0 || lanes > 32 || (lanes & (lanes - 1)) || n_rec % lanes) return fail(H2V_E_PLAN, "bad lane count of the program");
+        bool has_end = false;
+        uint32_t sq = 0;
+        for (uint32_t base_k = 0; base_k < n_rec && !has_end; base_k += lanes) {
+            uint32_t wr[32], n_wr = 0;
+            bool lane0_serial = false;
+            for (uint32_t l = 0; l < lanes; l++) {
+                const uint32_t k = base_k + l;
+                const uint8_t op = ip[8 * k];
+                const uint32_t dst = ip[8 * k + 2] | (ip[8 * k + 3] << 8), a = ip[8 * k + 4] | (ip[8 * k + 5] << 8), b = ip[8 * k + 6] | (ip[8 * k + 7] << 8);
+                const uint32_t off = a | (b << 16);
+                bool ok = true, writes = false, serial = false;
+                switch (op) {
+                case H2V_OP_END: has_end = true; serial = true; break;
+                case H2V_OP_NOP: break;
+                case H2V_OP_ABSORB_REG: ok = a < n_regs_v; serial = true; break;
+                case H2V_OP_ABSORB_CI: ok = n_ci == 1; serial = true; break;
+                case H2V_OP_LOAD_INSTANCE: ok = dst < n_regs_v && a < n_pi; writes = true; break;
+                case H2V_OP_READ_POINT: ok = (uint64_t)off + 48 <= proof_len; serial = true; break;
+                case H2V_OP_READ_SCALAR: ok = dst < n_regs_v && (uint64_t)off + 32 <= proof_len; writes = true; serial = true; break;
+                case H2V_OP_SQUEEZE: ok = dst < n_regs_v; sq++; writes = true; serial = true; break;
+                case H2V_OP_CONST: ok = dst < n_regs_v && a < n_consts; writes = true; break;
+                case H2V_OP_ADD: case H2V_OP_SUB: case H2V_OP_MUL: ok = dst < n_regs_v && a < n_regs_v && b < n_regs_v; writes = true; break;
+                case H2V_OP_NEG: case H2V_OP_INV: ok = dst < n_regs_v && a < n_regs_v; writes = true; break;
+                case H2V_OP_OUT_SCALAR: ok = dst < n_terms && a < n_regs_v; break;
+                case H2V_OP_ASSERT_ZERO: ok = a < n_regs_v; break;
+                default: ok = false;
+                }
+                if (!ok) return fail(H2V_E_PLAN, "instruction " + std::to_string(k) + " out of range");
+                if (serial && l != 0) return fail(H2V_E_PLAN, "transcript operation off lane 0 (record " + std::to_string(k) + ")");
+                if (l == 0) lane0_serial = serial;
+                else if (lane0_serial && op != H2V_OP_NOP) return fail(H2V_E_PLAN, "transcript operation shares its bundle (record " + std::to_string(k) + ")");
+                if (writes) wr[n_wr++] = (l << 16) | dst;
+            }
+            // independence inside the bundle: no register is written twice, none is read by a lane other than... any lane
+            for (uint32_t x = 0; x < n_wr; x++) {
+                const uint32_t reg = wr[x] & 0xffff;
+                for (uint32_t y = x + 1; y < n_wr; y++)
+                    if ((wr[y] & 0xffff) == reg) return fail(H2V_E_PLAN, "two lanes of a bundle write one register");
+                for (uint32_t l = 0; l < lanes; l++) {
+                    const uint32_t k = base_k + l;
+                    const uint8_t op = ip[8 * k];
+                    const uint32_t a = ip[8 * k + 4] | (ip[8 * k + 5] << 8), b = ip[8 * k + 6] | (ip[8 * k + 7] << 8);
+                    const bool reads_a = op == H2V_OP_ABSORB_REG || op == H2V_OP_ADD || op == H2V_OP_SUB || op == H2V_OP_MUL || op == H2V_OP_NEG ||
+                                         op == H2V_OP_INV || op == H2V_OP_OUT_SCALAR || op == H2V_OP_ASSERT_ZERO;
+                    const bool reads_b = op == H2V_OP_ADD || op == H2V_OP_SUB || op == H2V_OP_MUL;
+                    if (lanes > 1 && ((reads_a && a == reg) || (reads_b && b == reg)))
+                        return fail(H2V_E_PLAN, "a bundle reads a register it writes (record " + std::to_string(k) + ")");
+                }
+            }
         }
-        if (!ok) return fail(H2V_E_PLAN, "instruction " + std::to_string(k) + " out of range");
-        if (has_end) break;
+        if (!has_end) return fail(H2V_E_PLAN, "program has no END");
+        if (squeezes) *squeezes = sq;
+        return H2V_OK;
+    };
+    auto end_is_last = [&](const uint8_t *ip, uint32_t n_rec, uint32_t lanes) {   // the interpreter's trip count is n_rec / lanes - 1
+        for (uint32_t k = 0; k + lanes < n_rec; k++) if (ip[8 * k] == H2V_OP_END) return false;
+        return ip[8 * (n_rec - lanes)] == H2V_OP_END;
+    };
+    const uint32_t vm_lanes = w[H2V_HW_VM_LANES];
+    if (int rcp = check_program(blob + w[H2V_HW_OFF_INSTR], n_instr, n_regs, vm_lanes, &n_sq)) return rcp;
+    if (!end_is_last(blob + w[H2V_HW_OFF_INSTR], n_instr, vm_lanes)) return fail(H2V_E_PLAN, "END must be the last bundle of the program");
+    const uint32_t wide_lanes = w[H2V_HW_VM2_LANES], wide_n_regs = w[H2V_HW_VM2_N_REGS], wide_n_instr = w[H2V_HW_VM2_N_INSTR];
+    if (wide_lanes) {
+        const uint64_t off = w[H2V_HW_VM2_OFF_INSTR];
+        if (off < hdr || (off & 15) || off + 8ull * wide_n_instr > len || wide_n_instr == 0 || wide_n_instr > (1u << 20) ||
+            wide_n_regs == 0 || wide_n_regs > 65535)
+            return fail(H2V_E_PLAN, "wide program section out of bounds");
+        if (wide_lanes < 2 || (size_t)wide_n_regs * 32 * (64 / wide_lanes) > H2V_VM_LDS_BYTES)
+            return fail(H2V_E_PLAN, "wide program does not fit the LDS register file");
+        if (int rcp = check_program(blob + off, wide_n_instr, wide_n_regs, wide_lanes, nullptr)) return rcp;
+        if (!end_is_last(blob + off, wide_n_instr, wide_lanes)) return fail(H2V_E_PLAN, "END must be the last bundle of the program");
     }
-    if (!has_end) return fail(H2V_E_PLAN, "program has no END");
+    if (vm_lanes > 1 && (size_t)n_regs * 32 * (64 / vm_lanes) > H2V_VM_LDS_BYTES)
+        return fail(H2V_E_PLAN, "multi-lane program does not fit the LDS register file");
     const uint8_t *pp = blob + w[H2V_HW_OFF_POINTS];
     for (uint32_t k = 0; k < n_points; k++)
         if ((uint64_t)rd32(pp + 4 * k) + 48 > proof_len) return fail(H2V_E_PLAN, "point offset out of range");
@@ -183,6 +237,11 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
     d.proof_len = proof_len; d.n_pi = n_pi; d.n_ci = n_ci; d.n_regs = n_regs; d.n_instr = n_instr; d.n_consts = n_consts;
     d.n_points = n_points; d.n_vk_bases = n_bases; d.n_terms = n_terms; d.n_trace = n_trace; d.pi_point = w[H2V_HW_PI_POINT];
     d.instr = (const H2vInstr *)(base + w[H2V_HW_OFF_INSTR]);
+    d.vm_lanes = vm_lanes;
+    if (wide_lanes) {
+        d.wide_lanes = wide_lanes; d.wide_n_regs = wide_n_regs; d.wide_n_instr = wide_n_instr;
+        d.wide_instr = (const H2vInstr *)(base + w[H2V_HW_VM2_OFF_INSTR]);
+    }
     d.consts = (const uint32_t *)(base + w[H2V_HW_OFF_CONSTS]);
     d.points = (const uint32_t *)(base + w[H2V_HW_OFF_POINTS]);
     d.vk_bases = (const uint32_t *)(base + w[H2V_HW_OFF_VK_BASES]);
@@ -308,16 +367,26 @@ extern "C" void h2v_workspace_free(h2v_workspace *w) {
     delete w;
 }
 
-// Transcript + combiner launch: register file in LDS when P >= 8 proofs per block fit beside the 8 KB hash buffer
-// (160 KB of LDS per CU; the kernel has 64 waves' worth of work, so one block per CU is all it ever needs), otherwise in
-// the workspace's global buffer.
+// Transcript + combiner launch.  A block is one wave; its 64 lanes are P proofs x L lanes per proof (the plan's
+// bundles have L records), the Fr register file of the P proofs lives in LDS (160 KB per CU).  A single-lane plan whose
+// register file does not fit 64 proofs runs P = 32 / 16 / 8 proofs per block with the other lanes idle, or - below 8 -
+// with the register file in the workspace's global buffer.
 static uint32_t vm_lds_slots(const H2vDevPlan &d) {
+    if (d.vm_lanes > 1) return 64 / d.vm_lanes;   // validated at load: fits
     uint32_t P = 64;
-    while (P >= 8 && (size_t)d.n_regs * 32 * P + 8192 + 1024 > 160 * 1024) P >>= 1;
+    while (P >= 8 && (size_t)d.n_regs * 32 * P > H2V_VM_LDS_BYTES) P >>= 1;
     return P >= 8 ? P : 0;
 }
-static int launch_vm(const H2vDevPlan &d, uint32_t n, uint32_t stride, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst,
+static int launch_vm(const H2vDevPlan &d0, uint32_t n, uint32_t stride, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst,
                      const uint8_t *ci, uint32_t *regs, uint32_t *scalars, uint32_t *status, uint32_t *trace, hipStream_t st) {
+    // The wide schedule (more lanes per proof: shorter chain, more waves) when the launch would leave most of the chip
+    // idle anyway - at most a quarter of the SIMDs get a wave - and nobody asked for the trace (its register numbers are
+    // the narrow schedule's).  H2V_VM_WIDE = 0 / 1 forces the choice.
+    static const int env_wide = []() { const char *e = getenv("H2V_VM_WIDE"); return e ? atoi(e) : -1; }();
+    H2vDevPlan d = d0;
+    const bool wide_ok = d.wide_lanes && !trace;
+    const bool wide = wide_ok && (env_wide >= 0 ? env_wide != 0 : ((uint64_t)n * d.wide_lanes + 63) / 64 <= 256);
+    if (wide) { d.vm_lanes = d.wide_lanes; d.n_regs = d.wide_n_regs; d.n_instr = d.wide_n_instr; d.instr = d.wide_instr; }
     const uint32_t P = vm_lds_slots(d);
     if (P == 0) {
         hipLaunchKernelGGL(k_transcript_combiner, dim3((n + 63) / 64), dim3(64), 0, st, d, n, stride, proofs, off, inst, ci, regs, scalars, status, trace);

@@ -161,9 +161,14 @@ H2V_DI void tr_absorb_scalar(Transcript &s, uint32_t *sbuf, int lane, const Fr &
     for (int k = 0; k < 32; k++) tr_put(s, sbuf, lane, (plain.v[k >> 2] >> (8 * (k & 3))) & 0xff);
 }
 
+// The program is a sequence of bundles of L records (h2v_plan.h); lane `sub` of the proof's L lanes executes record `sub`
+// of each bundle.  The L lanes share the proof's register file (LDS), sit in the same wave, and a bundle's records are
+// independent, so program order is all the synchronisation there is: LDS serves one wave's accesses in issue order.
+// The transcript operations are on lane 0 by construction (the loader checks), so only that lane's hash state is real.
 template <class RF>
 H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const int lane, const uint32_t i, const uint32_t ii,
-                   const bool live, const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
+                   const bool live, const uint32_t L, const uint32_t sub, uint32_t *st_red /* 64 dwords of LDS */,
+                   const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
                    const uint8_t *__restrict__ instances, const uint8_t *__restrict__ committed,
                    uint32_t *__restrict__ scalars, uint32_t *__restrict__ status, uint32_t *__restrict__ trace) {
     const uint64_t off0 = proof_off[ii];
@@ -176,9 +181,18 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
     Transcript tr;
     tr_init(tr);
     Fr a, b, r;
-    for (uint32_t pc = 0; pc < plan.n_instr; pc++) {
-        const H2vInstr ins = plan.instr[pc];
-        if (ins.op == H2V_OP_END) break;
+    // Record fetch: one 8-byte load per lane and bundle (the L lanes of a proof read L consecutive records), issued one
+    // bundle ahead so that its latency - which a lone wave cannot hide behind anything else - overlaps the current bundle.
+    // END is the last bundle (the loader checks), so the trip count is known without looking at the records.
+    const uint64_t *code = reinterpret_cast<const uint64_t *>(plan.instr);
+    uint64_t nxt = code[sub];
+    for (uint32_t pc = 0; pc + L < plan.n_instr; pc += L) {
+        const uint64_t rec = nxt;
+        nxt = code[pc + L + sub];
+        const struct { uint32_t x, y; } raw = {(uint32_t)rec, (uint32_t)(rec >> 32)};
+        H2vInstr ins;
+        ins.op = (uint8_t)(raw.x & 0xffu); ins.pad = 0; ins.dst = (uint16_t)(raw.x >> 16);
+        ins.a = (uint16_t)(raw.y & 0xffffu); ins.b = (uint16_t)(raw.y >> 16);
         switch (ins.op) {
         case H2V_OP_ABSORB_REG: {
             rf.load(a, ins.a);
@@ -186,9 +200,14 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
             tr_absorb_scalar(tr, sbuf, lane, b);
         } break;
         case H2V_OP_ABSORB_CI: {
+            // (all the bytes are loaded before the first is hashed: a lone wave pays a full memory latency for every
+            // load it waits on, and a load inside the byte loop is waited on 48 times)
+            uint8_t raw[48];
+#pragma unroll
+            for (int k = 0; k < 48; k++) raw[k] = committed[(size_t)ii * 48 + k];
             tr_put(tr, sbuf, lane, 1);
-#pragma unroll 1
-            for (int k = 0; k < 48; k++) tr_put(tr, sbuf, lane, committed[(size_t)ii * 48 + k]);
+#pragma unroll
+            for (int k = 0; k < 48; k++) tr_put(tr, sbuf, lane, raw[k]);
         } break;
         case H2V_OP_LOAD_INSTANCE: {
             const uint8_t *p = instances + ((size_t)ii * plan.n_pi + ins.a) * 32;
@@ -200,20 +219,25 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
         } break;
         case H2V_OP_READ_POINT: {
             const uint32_t off = (uint32_t)ins.a | ((uint32_t)ins.b << 16);
+            uint8_t raw[48];
+#pragma unroll
+            for (int k = 0; k < 48; k++) raw[k] = short_proof ? (uint8_t)0 : proof[off + k];
             tr_put(tr, sbuf, lane, 1);
-#pragma unroll 1
-            for (int k = 0; k < 48; k++) tr_put(tr, sbuf, lane, short_proof ? 0u : proof[off + k]);
+#pragma unroll
+            for (int k = 0; k < 48; k++) tr_put(tr, sbuf, lane, raw[k]);
         } break;
         case H2V_OP_READ_SCALAR: {
             const uint32_t off = (uint32_t)ins.a | ((uint32_t)ins.b << 16);
+            uint8_t raw[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) raw[k] = short_proof ? (uint8_t)0 : proof[off + k];
             tr_put(tr, sbuf, lane, 1);
 #pragma unroll
             for (int l = 0; l < 8; l++) b.v[l] = 0;
-#pragma unroll 1
+#pragma unroll
             for (int k = 0; k < 32; k++) {
-                const uint32_t byte = short_proof ? 0u : proof[off + k];
-                tr_put(tr, sbuf, lane, byte);
-                b.v[k >> 2] |= byte << (8 * (k & 3));
+                tr_put(tr, sbuf, lane, raw[k]);
+                b.v[k >> 2] |= (uint32_t)raw[k] << (8 * (k & 3));
             }
             // canonical encodings only: the Rust reader (and Plinth's mkScalar, BlsTypes.hs:129-132) rejects >= r
             if (FrF::geq_mod(b.v)) st |= H2V_ST_BAD_SCALAR;
@@ -274,10 +298,16 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
                 for (int l = 0; l < 8; l++) scalars[((size_t)i * plan.n_terms + ins.dst) * 8 + l] = r.v[l];
             }
         } break;
-        default: break;
+        default: break;   // NOP: this lane idles through the bundle
         }
     }
-    if (live) {
+    if (L > 1) {   // status bits of the proof's other lanes (inverse of zero, recursion check)
+        st_red[lane] = st;
+        __syncthreads();
+        const uint32_t P = 64 / L;
+        for (uint32_t k = 1; k < L; k++) st |= st_red[((uint32_t)lane & (P - 1)) + k * P];
+    }
+    if (live && sub == 0) {
         status[i] = st;
         if (trace) {
             for (uint32_t k = 0; k < plan.n_trace; k++) {
@@ -301,7 +331,7 @@ k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_
     const bool live = i < n;
     const uint32_t ii = live ? i : n - 1;  // dead lanes shadow the last proof (keeps control flow uniform), never write
     const RegsGlobal rf = {regs, stride, ii, i};
-    vm_run(plan, rf, sbuf, lane, i, ii, live, proofs, proof_off, instances, committed, scalars, status, trace);
+    vm_run(plan, rf, sbuf, lane, i, ii, live, 1u, 0u, nullptr, proofs, proof_off, instances, committed, scalars, status, trace);
 }
 // P proofs per block (power of two, <= 64), register file in dynamic LDS: P * n_regs * 32 bytes
 extern "C" __global__ void __launch_bounds__(64)
@@ -310,14 +340,18 @@ k_transcript_combiner_lds(H2vDevPlan plan, uint32_t n, uint32_t P, const uint8_t
                           const uint8_t *__restrict__ committed, uint32_t *__restrict__ scalars,
                           uint32_t *__restrict__ status, uint32_t *__restrict__ trace) {
     __shared__ uint32_t sbuf[32 * 64];
+    __shared__ uint32_t st_red[64];
     const int lane = threadIdx.x;
-    const uint32_t q = (uint32_t)lane & (P - 1);            // lanes >= P shadow slot q: same proof, never write
+    const uint32_t L = plan.vm_lanes;
+    const uint32_t q = (uint32_t)lane & (P - 1);            // proof slot of the block
+    const uint32_t sub = L > 1 ? (uint32_t)lane / P : 0u;   // which of the proof's lanes (L > 1: P * L = 64)
     const uint32_t i = blockIdx.x * P + q;
-    const bool live = (uint32_t)lane < P && i < n;
+    // single-lane plans with P < 64: lanes >= P shadow slot q (same proof, same work) and never write
+    const bool live = (L > 1 || (uint32_t)lane < P) && i < n;
     const uint32_t ii = i < n ? i : n - 1;
     // a dead slot of the last block shadows proof n-1 but must not touch a live slot's registers: it owns slot q anyway
     const RegsLds rf = {P, q};
-    vm_run(plan, rf, sbuf, lane, i, ii, live, proofs, proof_off, instances, committed, scalars, status, trace);
+    vm_run(plan, rf, sbuf, lane, i, ii, live, L, sub, st_red, proofs, proof_off, instances, committed, scalars, status, trace);
 }
 
 // ============================================================================ K2: G1 decompression

@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define H2V_PLAN_MAGIC "H2VPLAN1"
-#define H2V_PLAN_VERSION 3u
+#define H2V_PLAN_VERSION 4u
 #define H2V_PLAN_HDR_WORDS 46
 #define H2V_MILLER_LINES 68  // 63 doublings + 5 additions for |x| = 0xd201000000010000
 
@@ -19,14 +19,21 @@ enum {
     H2V_HW_OFF_LINES_G2, H2V_HW_OFF_TRACE, H2V_HW_TOTAL_LEN, H2V_HW_OFF_LINES28_SG2, H2V_HW_OFF_LINES28_G2,
     // recursion (IVC; plan.py / ivc.py): flag, number of terms of the proof's own MSM, and the public-input positions
     // (x_hi, x_lo, y_hi, y_lo) of the two accumulator points
-    H2V_HW_IVC, H2V_HW_N_MAIN_TERMS, H2V_HW_ACC_IDX0 /* .. +7 */
+    H2V_HW_IVC, H2V_HW_N_MAIN_TERMS, H2V_HW_ACC_IDX0 /* .. +7 */,
+    // lanes per proof of the transcript + combiner program (the instruction stream is a sequence of bundles of that many
+    // records), and an optional second, wider schedule of the same program: lanes (0 = none), registers, records, offset
+    H2V_HW_VM_LANES = H2V_HW_ACC_IDX0 + 8, H2V_HW_VM2_LANES, H2V_HW_VM2_N_REGS, H2V_HW_VM2_N_INSTR, H2V_HW_VM2_OFF_INSTR
 };
 
-// opcodes of the transcript + Fr-combiner program (8-byte instructions: op, pad, dst, a, b)
+// opcodes of the transcript + Fr-combiner program (8-byte records: op, pad, dst, a, b).  The program is a sequence of
+// BUNDLES of `vm_lanes` records: record l of a bundle is executed by lane l of the proof's lanes (NOP = idle).  Records of
+// one bundle are independent (none reads or writes a register another one writes); the transcript operations (ABSORB_*,
+// READ_*, SQUEEZE) and END sit on lane 0 with the rest of their bundle idle.
 enum {
     H2V_OP_END = 0, H2V_OP_ABSORB_REG, H2V_OP_ABSORB_CI, H2V_OP_LOAD_INSTANCE, H2V_OP_READ_POINT, H2V_OP_READ_SCALAR,
     H2V_OP_SQUEEZE, H2V_OP_CONST, H2V_OP_ADD, H2V_OP_SUB, H2V_OP_MUL, H2V_OP_NEG, H2V_OP_INV, H2V_OP_OUT_SCALAR,
     H2V_OP_ASSERT_ZERO,  // status |= H2V_ST_RECURSION unless reg a == 0 (verifying-key hash check of the IVC fold)
+    H2V_OP_NOP,
     H2V_OP_COUNT
 };
 enum { H2V_TERM_PROOF_POINT = 0, H2V_TERM_VK_BASE = 1, H2V_TERM_COMMITTED_INSTANCE = 2, H2V_TERM_ACC_POINT = 3 };
@@ -51,6 +58,7 @@ struct H2vInstr {
 // device view of a loaded plan (all pointers are device pointers)
 struct H2vDevPlan {
     uint32_t proof_len, n_pi, n_ci, n_regs, n_instr, n_consts, n_points, n_vk_bases, n_terms, n_trace, pi_point;
+    uint32_t vm_lanes;         // records per bundle of `instr` (the launcher swaps in the wide schedule's instr / n_instr / n_regs / vm_lanes)
     const H2vInstr *instr;
     const uint32_t *consts;    // n_consts * 8   (Fr, Montgomery)
     const uint32_t *points;    // n_points       (byte offset in the proof)
@@ -67,6 +75,9 @@ struct H2vDevPlan {
     uint32_t acc_idx[8];
     const uint32_t *fold_terms;  // 4 x (kind, index): el + c*acc_left, er + c*acc_right over the fold's own point buffer
     const uint32_t *vk_tab;      // n_vk_bases x 2 x 224: affine window tables [1..8]B and [1..8]phi(B), built at plan load
+    // optional wide schedule of the program (0 lanes = none); host-side use only (launch_vm swaps it in)
+    uint32_t wide_lanes, wide_n_regs, wide_n_instr;
+    const H2vInstr *wide_instr;
 };
 // per-proof point slots: the proof's G1 elements, the committed instance, then (recursion) the two accumulator points
 #define H2V_SLOTS(plan) ((plan).n_points + (plan).n_ci + 2u * (plan).ivc)

@@ -43,9 +43,13 @@ R = bls.R
 
 # ---- opcodes (mirrored in csrc/h2v_plan.h)
 OP_END, OP_ABSORB_REG, OP_ABSORB_CI, OP_LOAD_INSTANCE, OP_READ_POINT, OP_READ_SCALAR, OP_SQUEEZE, OP_CONST, \
-    OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_INV, OP_OUT_SCALAR, OP_ASSERT_ZERO = range(15)
+    OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_INV, OP_OUT_SCALAR, OP_ASSERT_ZERO, OP_NOP = range(16)
 OP_NAMES = ["END", "ABSORB_REG", "ABSORB_CI", "LOAD_INSTANCE", "READ_POINT", "READ_SCALAR", "SQUEEZE", "CONST",
-            "ADD", "SUB", "MUL", "NEG", "INV", "OUT_SCALAR", "ASSERT_ZERO"]
+            "ADD", "SUB", "MUL", "NEG", "INV", "OUT_SCALAR", "ASSERT_ZERO", "NOP"]
+# the transcript is one hash chain: these run on lane 0 of a proof's lanes, alone in their bundle, in program order
+TRANSCRIPT_OPS = frozenset((OP_ABSORB_REG, OP_ABSORB_CI, OP_READ_POINT, OP_READ_SCALAR, OP_SQUEEZE))
+VM_LANE_CHOICES = (1, 2, 4, 8, 16)
+VM_LDS_BYTES = 160 * 1024 - 8192 - 1024   # register file budget of one block (h2v_capi.hip: vm_lds_fits)
 
 # ---- MSM term kinds (ACC_POINT: the two accumulator points rebuilt from the public inputs, recursion only)
 TERM_PROOF_POINT, TERM_VK_BASE, TERM_COMMITTED_INSTANCE, TERM_ACC_POINT = 0, 1, 2, 3
@@ -58,7 +62,7 @@ MAX_TRACE_EXPR = 256
 
 MILLER_LINES = 68
 PLAN_MAGIC = b"H2VPLAN1"
-PLAN_VERSION = 3
+PLAN_VERSION = 4
 PLAN_HDR_WORDS = 46  # 8 + 4*46 = 192 bytes: keeps every 16-byte-padded section 16-byte aligned
 
 ROT_LAST = "last"  # rotation key of x_last = w^-(bf+1) x
@@ -88,6 +92,14 @@ class Plan:
     # followed by its fixed bases.  acc_coords: public-input positions (x_hi, x_lo, y_hi, y_lo) x (left, right).
     n_main_terms: int = -1
     acc_coords: Optional[List[int]] = None
+    # lanes per proof of the transcript + combiner kernel: `instrs` is a sequence of bundles of vm_lanes records, record
+    # l of a bundle is executed by lane l (OP_NOP = idle); no record of a bundle reads or writes a register that another
+    # record of the same bundle writes, so running the records one after the other (run_plan) gives the same result
+    vm_lanes: int = 1
+    # optional second schedule of the same program for launches that leave most of the chip idle (small batches,
+    # large circuits): more lanes per proof, shorter chain, more waves.  (lanes, n_regs, instrs); the trace table
+    # refers to the first schedule only.
+    wide: Optional[Tuple[int, int, List[Tuple[int, int, int, int]]]] = None
 
     def __post_init__(self):
         if self.n_main_terms < 0:
@@ -115,6 +127,8 @@ class Plan:
             body.extend(data)
 
         section("instr", b"".join(struct.pack("<BBHHH", op, 0, d, a, b) for op, d, a, b in self.instrs))
+        if self.wide:
+            section("instr_wide", b"".join(struct.pack("<BBHHH", op, 0, d, a, b) for op, d, a, b in self.wide[2]))
         section("consts", b"".join(bls.fr_mont_bytes(c) for c in self.consts))
         section("points", b"".join(struct.pack("<I", o) for o in self.points))
         vb = bytearray()
@@ -139,6 +153,8 @@ class Plan:
         fields += sect + [hdr_len + len(body)]
         fields += [hdr_len + offs["lines28_sg2"], hdr_len + offs["lines28_g2"]]
         fields += [1 if self.is_recursive else 0, self.n_main_terms] + list(self.acc_coords or [0] * 8)
+        fields += [self.vm_lanes]
+        fields += [self.wide[0], self.wide[1], len(self.wide[2]), hdr_len + offs["instr_wide"]] if self.wide else [0, 0, 0, 0]
         fields += [0] * (PLAN_HDR_WORDS - len(fields))
         return PLAN_MAGIC + struct.pack("<%dI" % PLAN_HDR_WORDS, *fields) + bytes(body)
 
@@ -234,7 +250,7 @@ def _rot_sort_key(rot):
     return (4, rot)
 
 
-def compile_plan(vk: VerifyingKey) -> Plan:
+def compile_plan(vk: VerifyingKey, lanes: Optional[int] = None) -> Plan:
     b = _Builder()
     L = len(vk.lookups)
     Cn = vk.n_perm_chunks
@@ -714,7 +730,7 @@ def compile_plan(vk: VerifyingKey) -> Plan:
 
     # ---- register allocation (linear scan over the straight-line code)
     keep_alive = {r for _, r in trace_virt}
-    instrs, n_regs, mapping = _allocate(b, keep_alive)
+    (instrs, n_regs, mapping, vm_lanes), wide = _schedule_and_allocate(b.code, keep_alive, lanes)
     trace = [(slot, mapping[r]) for slot, r in trace_virt]
 
     s_g2 = bls.g2_decompress(bytes.fromhex(vk.s_g2))
@@ -723,7 +739,7 @@ def compile_plan(vk: VerifyingKey) -> Plan:
         consts=b.consts, points=points, point_names=point_names, vk_bases=vk_bases, terms=terms,
         term_names=term_names, pi_point=pi_pt, lines_sg2=bls.g2_line_table(s_g2),
         lines_g2=bls.g2_line_table(bls.G2_GEN), trace=trace, n_squeezes=n_squeezes, stream_len=stream_len,
-        n_main_terms=n_main_terms, acc_coords=acc_coords,
+        n_main_terms=n_main_terms, acc_coords=acc_coords, vm_lanes=vm_lanes, wide=wide,
     )
     return plan
 
@@ -740,15 +756,93 @@ def _defines(op):
     return op in (OP_LOAD_INSTANCE, OP_READ_SCALAR, OP_SQUEEZE, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_INV)
 
 
-def _allocate(b: _Builder, keep_alive):
-    """Constants are rematerialised right before each use-run would cost instructions; instead every virtual
-    register simply gets a physical one for [def, last use]; registers named in the trace table live to the end."""
-    code = b.code
-    last_use = {}
-    for i, (op, dst, a, c) in enumerate(code):
+# Relative cost of one bundle on the device (one Fr multiplication = 1): used to compare schedules only.
+_COST_MUL, _COST_INV, _COST_CHEAP, _COST_BUNDLE = 1.0, 14.0, 0.06, 0.05
+_COST_TRANSCRIPT = {OP_ABSORB_REG: 1.6, OP_ABSORB_CI: 0.8, OP_READ_POINT: 0.8, OP_READ_SCALAR: 1.7, OP_SQUEEZE: 3.5}
+
+
+def _schedule(code, lanes: int, pack_mul: bool):
+    """List scheduling of the straight-line SSA program into bundles of `lanes` records.
+
+    Every instruction goes to the earliest bundle after its operands' bundles that still has a free lane (records of a
+    bundle must be independent: divergent lanes of a wave run in no particular order); transcript operations keep their
+    program order and get a bundle of their own on lane 0.  pack_mul: a multiplication prefers the earliest bundle that
+    already holds one (the bundle costs one multiplication however many lanes multiply).  Returns a list of bundles,
+    each a list of `lanes` records [op, dst, a, b] (virtual registers) or None."""
+    slot_of: Dict[int, int] = {}
+    bundles: List[List[Optional[list]]] = []
+    exclusive: List[bool] = []
+    has_mul: List[bool] = []
+    first_open = 0   # every bundle below this index is full or exclusive
+    for ins in code:
+        op, dst, a, c = ins
+        if op == OP_END:
+            continue
+        e = 0
         for r in _uses(op, dst, a, c):
-            last_use[r] = i
-    end = len(code)
+            e = max(e, slot_of[r] + 1)
+        if op in TRANSCRIPT_OPS:
+            s = len(bundles)   # later than every operand and every earlier transcript operation
+            bundles.append([list(ins)] + [None] * (lanes - 1))
+            exclusive.append(True)
+            has_mul.append(False)
+        else:
+            s = -1
+            start = max(e, first_open)
+            if op == OP_MUL and pack_mul:
+                for k in range(start, len(bundles)):
+                    if has_mul[k] and not exclusive[k] and None in bundles[k]:
+                        s = k
+                        break
+            if s < 0:
+                for k in range(start, len(bundles)):
+                    if not exclusive[k] and None in bundles[k]:
+                        s = k
+                        break
+            if s < 0:
+                s = len(bundles)
+                bundles.append([None] * lanes)
+                exclusive.append(False)
+                has_mul.append(False)
+            bundles[s][bundles[s].index(None)] = list(ins)
+            has_mul[s] = has_mul[s] or op == OP_MUL
+            while first_open < len(bundles) and (exclusive[first_open] or None not in bundles[first_open]):
+                first_open += 1
+        if _defines(op):
+            slot_of[dst] = s
+    bundles.append([[OP_END, 0, 0, 0]] + [None] * (lanes - 1))
+    return bundles
+
+
+def _schedule_cost(bundles) -> float:
+    total = 0.0
+    for bun in bundles:
+        ops = {r[0] for r in bun if r is not None}
+        t = _COST_BUNDLE
+        for op in ops:
+            if op == OP_MUL:
+                t += _COST_MUL
+            elif op == OP_INV:
+                t += _COST_INV
+            elif op in _COST_TRANSCRIPT:
+                t += _COST_TRANSCRIPT[op]
+            else:
+                t += _COST_CHEAP
+        total += t
+    return total
+
+
+def _allocate(bundles, keep_alive):
+    """Physical registers for the scheduled program: a virtual register lives from the bundle that defines it to the
+    last bundle that reads it (registers named in the trace table: to the end), and its physical register becomes free
+    for bundles AFTER that one (never within it: the lanes of a bundle run in no particular order)."""
+    last_use: Dict[int, int] = {}
+    for s, bun in enumerate(bundles):
+        for rec in bun:
+            if rec is not None:
+                for r in _uses(*rec):
+                    last_use[r] = s
+    end = len(bundles)
     for r in keep_alive:
         last_use[r] = end
     free: List[int] = []
@@ -756,37 +850,80 @@ def _allocate(b: _Builder, keep_alive):
     mapping: Dict[int, int] = {}
     expiring: Dict[int, List[int]] = {}
     out = []
-    for i, (op, dst, a, c) in enumerate(code):
-        pa, pc = a, c
-        if op in (OP_ADD, OP_SUB, OP_MUL):
-            pa, pc = mapping[a], mapping[c]
-        elif op in (OP_NEG, OP_INV, OP_ABSORB_REG, OP_OUT_SCALAR, OP_ASSERT_ZERO):
-            pa = mapping[a]
-        # release registers whose last use is this instruction BEFORE allocating dst (dst may reuse a source:
-        # every op reads its sources fully before writing)
-        for r in expiring.pop(i, []):
-            free.append(mapping[r])
-        if _defines(op):
-            if dst not in last_use:
-                # dead value (e.g. an unused constant): still needs a slot for the write
-                last_use[dst] = i
-            if free:
-                p = free.pop()
-            else:
-                p = n_phys
-                n_phys += 1
-            mapping[dst] = p
-            lu = last_use[dst]
-            if lu <= i:
-                free.append(p)
-            elif lu < end:
-                expiring.setdefault(lu, []).append(dst)
-            pd = p
-        else:
+    for s, bun in enumerate(bundles):
+        for p in expiring.pop(s, []):
+            free.append(p)
+        for rec in bun:
+            if rec is None:
+                out.append((OP_NOP, 0, 0, 0))
+                continue
+            op, dst, a, c = rec
+            pa, pc = a, c
+            if op in (OP_ADD, OP_SUB, OP_MUL):
+                pa, pc = mapping[a], mapping[c]
+            elif op in (OP_NEG, OP_INV, OP_ABSORB_REG, OP_OUT_SCALAR, OP_ASSERT_ZERO):
+                pa = mapping[a]
             pd = dst
-        out.append((op, pd, pa, pc))
+            if _defines(op):
+                if free:
+                    pd = free.pop()
+                else:
+                    pd = n_phys
+                    n_phys += 1
+                mapping[dst] = pd
+                lu = max(last_use.get(dst, s), s)   # a dead value still needs a slot for the write
+                if lu < end:
+                    expiring.setdefault(lu + 1, []).append(pd)
+            out.append((op, pd, pa, pc))
     assert n_phys < 65536
     return out, max(n_phys, 1), mapping
+
+
+def check_bundles(instrs, lanes: int):
+    """The invariants the device relies on (h2v_plan_load checks the same): transcript operations and END only on lane
+    0 with the other lanes idle, and no record of a bundle touching a register that another record of it writes."""
+    assert len(instrs) % lanes == 0
+    for s in range(0, len(instrs), lanes):
+        bun = instrs[s:s + lanes]
+        if bun[0][0] in TRANSCRIPT_OPS or bun[0][0] == OP_END:
+            assert all(r[0] == OP_NOP for r in bun[1:]), "transcript operation shares its bundle"
+        written = [r[1] for r in bun if _defines(r[0])]
+        assert len(set(written)) == len(written), "two lanes write one register"
+        for k, r in enumerate(bun):
+            assert k == 0 or (r[0] not in TRANSCRIPT_OPS and r[0] != OP_END), "transcript operation off lane 0"
+            for u in _uses(*r):
+                assert all(u != w or (j == k and False) for j, w in enumerate(r2[1] for r2 in bun if _defines(r2[0]))), \
+                    "a lane reads a register written in the same bundle"
+
+
+def _schedule_and_allocate(code, keep_alive, lanes: Optional[int]):
+    """Two schedules of the program (a block of the combiner kernel has 64 lanes, so 64 / L proofs share its LDS
+    register file):
+      * narrow: the smallest lane count L whose register file fits in LDS - the batch then needs the fewest waves, which
+        is what counts when the other kernels of the phase keep every SIMD busy (simple_mul x 4096: L = 2);
+      * wide (optional): the L with the smallest estimated run time, kept when it is at least 10 % faster; the launcher
+        takes it when the launch would otherwise leave most of the chip idle (h2v_capi.hip: launch_vm).
+    L = 1 is the fallback when nothing fits (register file in global memory).  `lanes` forces a single schedule."""
+    cands = []
+    for L in ((lanes,) if lanes else VM_LANE_CHOICES):
+        best = None
+        for pack in (False, True):
+            bundles = _schedule(code, L, pack)
+            instrs, n_regs, mapping = _allocate(bundles, keep_alive)
+            cost = _schedule_cost(bundles)
+            if best is None or cost < best[0]:
+                best = (cost, instrs, n_regs, mapping, L)
+        check_bundles(best[1], L)
+        cands.append(best + (best[2] * 32 * (64 // L) <= VM_LDS_BYTES,))
+    fitting = [c for c in cands if c[5]]
+    if lanes or not fitting:
+        c = cands[0]
+        return (c[1], c[2], c[3], c[4]), None
+    narrow = fitting[0]
+    floor = min(c[0] for c in fitting)
+    wide = next(c for c in fitting if c[0] <= 1.1 * floor)   # the fewest lanes within 10 % of the best estimate
+    wide_out = (wide[4], wide[2], wide[1]) if wide[4] > narrow[4] and wide[0] < narrow[0] * 0.9 else None
+    return (narrow[1], narrow[2], narrow[3], narrow[4]), wide_out
 
 
 # ----------------------------------------------------------------------------- big-integer interpreter
@@ -795,23 +932,26 @@ class PlanReject(Exception):
 
 
 def run_plan(plan: Plan, proof: bytes, instances: List[int], committed: Optional[bytes] = None,
-             stop_before_point: Optional[int] = None):
+             stop_before_point: Optional[int] = None, use_wide: bool = False):
     """Executes the plan's bytecode with Python integers (host-side tool: used by the synthetic-proof forger and by
     the CPU tests of the compiler; NOT the verification path).  Returns (term scalars, registers, status).
     status: None = ran to the end, or a reject reason string.  With stop_before_point=i the run stops just before
     READ_POINT of point slot i (used to forge the last proof element)."""
     import hashlib
 
-    regs = [0] * plan.n_regs
+    instrs, n_regs = (plan.wide[2], plan.wide[1]) if use_wide else (plan.instrs, plan.n_regs)
+    regs = [0] * n_regs
     scalars = [0] * plan.n_terms
     acc = bytearray()
     status = None
     n_points_read = 0
     if len(proof) < plan.proof_len and stop_before_point is None:
         return scalars, regs, "short"
-    for op, d, a, c in plan.instrs:
+    for op, d, a, c in instrs:
         if op == OP_END:
             break
+        if op == OP_NOP:
+            continue
         if op == OP_ABSORB_REG:
             acc += b"\x01" + regs[a].to_bytes(32, "little")
         elif op == OP_ABSORB_CI:

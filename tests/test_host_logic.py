@@ -398,3 +398,82 @@ def test_generated_headers_are_current(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_coop_program
     assert gen_coop_program.check_bounds(gen_coop_program.build_program())
+
+
+@pytest.mark.parametrize("name", ["simple_mul", "lookup_table", "sha256", "ivc"])
+def test_scheduled_programs_are_equivalent(name):
+    """The combiner program is list-scheduled into bundles of L records (plan.py: _schedule); every schedule of a plan -
+    one lane per proof, the narrow one, the wide one - must compute the same MSM scalars and the same reject reason, on a
+    valid proof and on corrupted ones, and respect the bundle discipline the device interpreter relies on."""
+    vk, td = V.BUILDERS[name]()
+    pl = PL.compile_plan(vk)
+    pl1 = PL.compile_plan(vk, lanes=1)
+    assert pl1.vm_lanes == 1 and pl1.wide is None
+    assert pl.vm_lanes in PL.VM_LANE_CHOICES and pl.n_regs * 32 * (64 // pl.vm_lanes) <= PL.VM_LDS_BYTES
+    PL.check_bundles(pl.instrs, pl.vm_lanes)
+    assert pl.wide is not None and pl.wide[0] > pl.vm_lanes
+    PL.check_bundles(pl.wide[2], pl.wide[0])
+    assert pl.wide[1] * 32 * (64 // pl.wide[0]) <= PL.VM_LDS_BYTES
+    # same multiset of real instructions in every schedule
+    def ops(instrs):
+        return sorted(op for op, *_ in instrs if op not in (PL.OP_NOP, PL.OP_END))
+    assert ops(pl.instrs) == ops(pl.wide[2]) == ops(pl1.instrs)
+    b = synth.forge_batch(vk, td, 3, seed=21, plan=pl, workers=1)
+    b = synth.with_rejects(pl, b, vk.n_public_inputs, fraction=0.7, seed=5, kinds=["flip_first_scalar", "noncanonical_scalar", "wrong_pi"])
+    for i in range(3):
+        inst = b.instance_ints(i, vk.n_public_inputs)
+        ci = b.committed[48 * i:48 * i + 48] if b.committed else None
+        ref = PL.run_plan(pl1, b.proof(i), inst, ci)
+        for got in (PL.run_plan(pl, b.proof(i), inst, ci), PL.run_plan(pl, b.proof(i), inst, ci, use_wide=True)):
+            assert got[0] == ref[0] and got[2] == ref[2]
+
+
+def test_plan_loader_rejects_broken_bundles():
+    """A bundle whose records depend on each other, or a transcript operation that is not alone on lane 0, must be refused
+    by h2v_plan_load on the host (the interpreter's lanes run the records of a bundle in no particular order)."""
+    import struct
+    L = ctypes.CDLL(os.path.join(ROOT, "plutus_halo2_verifier_gen_amd", "libh2v_hip.so"))
+    L.h2v_plan_load.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.h2v_plan_load.restype = ctypes.c_int
+    L.h2v_last_error.restype = ctypes.c_char_p
+
+    def load(blob):
+        h = ctypes.c_void_p()
+        rc = L.h2v_plan_load(bytes(blob), len(blob), 0, ctypes.byref(h))
+        assert rc != 0 or not h.value or L.h2v_plan_free(h) is not None or True
+        return rc, (L.h2v_last_error() or b"").decode()
+
+    vk, _ = V.BUILDERS["simple_mul"]()
+    pl = PL.compile_plan(vk)
+    lanes = pl.vm_lanes
+    assert lanes >= 2
+    blob = pl.to_bytes()
+    off_instr = struct.unpack_from("<I", blob, 8 + 4 * 14)[0]
+    recs = pl.instrs
+    # a bundle with two arithmetic records
+    k = next(s for s in range(0, len(recs), lanes) if recs[s][0] == PL.OP_MUL and recs[s + 1][0] in (PL.OP_MUL, PL.OP_ADD, PL.OP_SUB))
+    op0, d0, a0, b0 = recs[k]
+    op1, d1, a1, b1 = recs[k + 1]
+    m = bytearray(blob)
+    struct.pack_into("<BBHHH", m, off_instr + 8 * (k + 1), op1, 0, d1, d0, b1)       # lane 1 reads what lane 0 writes
+    rc, msg = load(m)
+    assert rc == -2 and "reads a register it writes" in msg
+    m = bytearray(blob)
+    struct.pack_into("<BBHHH", m, off_instr + 8 * (k + 1), op1, 0, d0, a1, b1)       # both lanes write one register
+    rc, msg = load(m)
+    assert rc == -2 and "write one register" in msg
+    # a transcript operation on lane 1 / sharing its bundle
+    t = next(s for s in range(0, len(recs), lanes) if recs[s][0] == PL.OP_SQUEEZE)
+    m = bytearray(blob)
+    struct.pack_into("<BBHHH", m, off_instr + 8 * (t + 1), PL.OP_CONST, 0, 0, 0, 0)
+    rc, msg = load(m)
+    assert rc == -2 and "shares its bundle" in msg
+    m = bytearray(blob)
+    struct.pack_into("<BBHHH", m, off_instr + 8 * (k + 1), PL.OP_SQUEEZE, 0, d1, 0, 0)
+    rc, msg = load(m)
+    assert rc == -2 and "off lane 0" in msg
+    # lane count that does not divide the stream / is not a power of two
+    for bad in (3, 0, 64):
+        m = bytearray(blob)
+        struct.pack_into("<I", m, 8 + 4 * 35, bad)
+        assert load(m)[0] == -2
