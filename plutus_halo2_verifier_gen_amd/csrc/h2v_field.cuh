@@ -307,7 +307,37 @@ H2V_DI bool fp_eq(const Fp &a, const Fp &b) { return FpF::eq(a, b); }
 H2V_DI void fp_set_one(Fp &r) { FpF::set_one(r); }
 H2V_DI void fp_set_zero(Fp &r) { FpF::set_zero(r); }
 
-H2V_DN void fr_mul(Fr &r, const Fr &a, const Fr &b) { FrF::mul(r, a, b); }
+// Fr product out of line with operands and result in VGPRs (the by-reference form cost two scratch round trips per
+// call, which a lone wave of the combiner kernel cannot hide: 5.2k cycles per multiplying bundle instead of ~2.5k)
+struct FrRegs { u32x4 a, b; };
+H2V_DN FrRegs fr_mul_raw(u32x4 a0, u32x4 a1, u32x4 b0, u32x4 b1) {
+    Fr x, y, z;
+    x.v[0] = a0.x; x.v[1] = a0.y; x.v[2] = a0.z; x.v[3] = a0.w; x.v[4] = a1.x; x.v[5] = a1.y; x.v[6] = a1.z; x.v[7] = a1.w;
+    y.v[0] = b0.x; y.v[1] = b0.y; y.v[2] = b0.z; y.v[3] = b0.w; y.v[4] = b1.x; y.v[5] = b1.y; y.v[6] = b1.z; y.v[7] = b1.w;
+    FrF::mul(z, x, y);
+    FrRegs r;
+    r.a = u32x4{z.v[0], z.v[1], z.v[2], z.v[3]};
+    r.b = u32x4{z.v[4], z.v[5], z.v[6], z.v[7]};
+    return r;
+}
+H2V_DI void fr_mul(Fr &r, const Fr &a, const Fr &b) {
+    const FrRegs z = fr_mul_raw(u32x4{a.v[0], a.v[1], a.v[2], a.v[3]}, u32x4{a.v[4], a.v[5], a.v[6], a.v[7]},
+                                u32x4{b.v[0], b.v[1], b.v[2], b.v[3]}, u32x4{b.v[4], b.v[5], b.v[6], b.v[7]});
+    r.v[0] = z.a.x; r.v[1] = z.a.y; r.v[2] = z.a.z; r.v[3] = z.a.w; r.v[4] = z.b.x; r.v[5] = z.b.y; r.v[6] = z.b.z; r.v[7] = z.b.w;
+}
+// conversions through the same out-of-line multiplier (the Field<> forms inline a whole product each)
+H2V_DI void fr_to_mont(Fr &r, const Fr &plain) {
+    Fr k;
+#pragma unroll
+    for (int i = 0; i < 8; i++) k.v[i] = FR_R2[i];
+    fr_mul(r, plain, k);
+}
+H2V_DI void fr_from_mont(Fr &r, const Fr &a) {
+    Fr one;
+#pragma unroll
+    for (int i = 0; i < 8; i++) one.v[i] = i == 0 ? 1u : 0u;
+    fr_mul(r, a, one);
+}
 H2V_DI void fr_add(Fr &r, const Fr &a, const Fr &b) { FrF::add(r, a, b); }
 H2V_DI void fr_sub(Fr &r, const Fr &a, const Fr &b) { FrF::sub(r, a, b); }
 

@@ -88,7 +88,15 @@ H2V_DI void tr_put(Transcript &s, uint32_t *sbuf, int lane, uint32_t byte) {
         B2Msg blk;
         tr_load_block(blk, sbuf, lane, 128);
         s.t += 128;
-        b2_compress(s.h, blk, s.t, false);
+        // through a copy: handing s.h itself to the out-of-line function would pin the whole struct - fill level and
+        // byte counter included - in private memory, and every tr_put would then wait for a scratch round trip
+        // (measured: 560 cycles per absorbed byte on a lone wave)
+        uint64_t hh[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) hh[i] = s.h[i];
+        b2_compress(hh, blk, s.t, false);
+#pragma unroll
+        for (int i = 0; i < 8; i++) s.h[i] = hh[i];
         s.buflen = 0;
     }
     reinterpret_cast<uint8_t *>(&sbuf[(s.buflen >> 2) * 64 + lane])[s.buflen & 3] = (uint8_t)byte;
@@ -157,8 +165,8 @@ H2V_DI void fr_const(Fr &v, const uint32_t *c) {
 // absorb 0x01 || 32 little-endian bytes of a canonical (non-Montgomery) scalar
 H2V_DI void tr_absorb_scalar(Transcript &s, uint32_t *sbuf, int lane, const Fr &plain) {
     tr_put(s, sbuf, lane, 1);
-#pragma unroll 1
-    for (int k = 0; k < 32; k++) tr_put(s, sbuf, lane, (plain.v[k >> 2] >> (8 * (k & 3))) & 0xff);
+#pragma unroll
+    for (int k = 0; k < 32; k++) tr_put(s, sbuf, lane, (plain.v[k >> 2] >> (8 * (k & 3))) & 0xff);   // static limb indices
 }
 
 // The program is a sequence of bundles of L records (h2v_plan.h); lane `sub` of the proof's L lanes executes record `sub`
@@ -196,7 +204,7 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
         switch (ins.op) {
         case H2V_OP_ABSORB_REG: {
             rf.load(a, ins.a);
-            FrF::from_mont(b, a);
+            fr_from_mont(b, a);
             tr_absorb_scalar(tr, sbuf, lane, b);
         } break;
         case H2V_OP_ABSORB_CI: {
@@ -214,34 +222,40 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
 #pragma unroll
             for (int l = 0; l < 8; l++)
                 b.v[l] = (uint32_t)p[4 * l] | ((uint32_t)p[4 * l + 1] << 8) | ((uint32_t)p[4 * l + 2] << 16) | ((uint32_t)p[4 * l + 3] << 24);
-            FrF::to_mont(r, b);  // public inputs are field elements handed over by the caller: reduced mod r
+            fr_to_mont(r, b);  // public inputs are field elements handed over by the caller: reduced mod r
             if (live) rf.store(ins.dst, r);
         } break;
         case H2V_OP_READ_POINT: {
             const uint32_t off = (uint32_t)ins.a | ((uint32_t)ins.b << 16);
+            // unconditional loads from one base (a short proof reads a table of the plan instead and is zeroed): a
+            // load under a branch per byte is waited for before the next one issues - 560 cycles per byte on a lone wave
+            const uint8_t *src = short_proof ? reinterpret_cast<const uint8_t *>(plan.lines_sg2) : proof + off;
             uint8_t raw[48];
 #pragma unroll
-            for (int k = 0; k < 48; k++) raw[k] = short_proof ? (uint8_t)0 : proof[off + k];
+            for (int k = 0; k < 48; k++) raw[k] = src[k];
+#pragma unroll
+            for (int k = 0; k < 48; k++) raw[k] = short_proof ? (uint8_t)0 : raw[k];
             tr_put(tr, sbuf, lane, 1);
 #pragma unroll
             for (int k = 0; k < 48; k++) tr_put(tr, sbuf, lane, raw[k]);
         } break;
         case H2V_OP_READ_SCALAR: {
             const uint32_t off = (uint32_t)ins.a | ((uint32_t)ins.b << 16);
+            const uint8_t *src = short_proof ? reinterpret_cast<const uint8_t *>(plan.lines_sg2) : proof + off;
             uint8_t raw[32];
 #pragma unroll
-            for (int k = 0; k < 32; k++) raw[k] = short_proof ? (uint8_t)0 : proof[off + k];
+            for (int k = 0; k < 32; k++) raw[k] = src[k];
+#pragma unroll
+            for (int k = 0; k < 32; k++) raw[k] = short_proof ? (uint8_t)0 : raw[k];
+#pragma unroll
+            for (int l = 0; l < 8; l++)
+                b.v[l] = (uint32_t)raw[4 * l] | ((uint32_t)raw[4 * l + 1] << 8) | ((uint32_t)raw[4 * l + 2] << 16) | ((uint32_t)raw[4 * l + 3] << 24);
             tr_put(tr, sbuf, lane, 1);
 #pragma unroll
-            for (int l = 0; l < 8; l++) b.v[l] = 0;
-#pragma unroll
-            for (int k = 0; k < 32; k++) {
-                tr_put(tr, sbuf, lane, raw[k]);
-                b.v[k >> 2] |= (uint32_t)raw[k] << (8 * (k & 3));
-            }
+            for (int k = 0; k < 32; k++) tr_put(tr, sbuf, lane, raw[k]);
             // canonical encodings only: the Rust reader (and Plinth's mkScalar, BlsTypes.hs:129-132) rejects >= r
             if (FrF::geq_mod(b.v)) st |= H2V_ST_BAD_SCALAR;
-            FrF::to_mont(r, b);
+            fr_to_mont(r, b);
             if (live) rf.store(ins.dst, r);
         } break;
         case H2V_OP_SQUEEZE: {
@@ -257,7 +271,7 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
                 lo.v[2 * l] = (uint32_t)h[l]; lo.v[2 * l + 1] = (uint32_t)(h[l] >> 32);
                 hi.v[2 * l] = (uint32_t)h2[l]; hi.v[2 * l + 1] = (uint32_t)(h2[l] >> 32);
             }
-            FrF::to_mont(a, lo);
+            fr_to_mont(a, lo);
             fr_const(k, FR_R3);
             fr_mul(b, hi, k);  // hi * 2^768 / 2^256 = (hi * 2^256) * R
             fr_add(r, a, b);
@@ -283,7 +297,11 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
         case H2V_OP_INV: {
             rf.load(a, ins.a);
             // recip_eea of zero divides by zero in the reference (bls_utils.ak:151-154) => reject
-            if (!fr_inv(r, a)) st |= H2V_ST_INVERSE_OF_ZERO;
+            {
+                Fr ia = a, ir;   // copies: fr_inv takes references, and a / r must not be pinned in private memory
+                if (!fr_inv(ir, ia)) st |= H2V_ST_INVERSE_OF_ZERO;
+                r = ir;
+            }
             if (live) rf.store(ins.dst, r);
         } break;
         case H2V_OP_ASSERT_ZERO: {
@@ -292,7 +310,7 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
         } break;
         case H2V_OP_OUT_SCALAR: {
             rf.load(a, ins.a);
-            FrF::from_mont(r, a);
+            fr_from_mont(r, a);
             if (live) {
 #pragma unroll
                 for (int l = 0; l < 8; l++) scalars[((size_t)i * plan.n_terms + ins.dst) * 8 + l] = r.v[l];
@@ -312,7 +330,7 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
         if (trace) {
             for (uint32_t k = 0; k < plan.n_trace; k++) {
                 rf.load(a, plan.trace[2 * k + 1]);
-                FrF::from_mont(r, a);
+                fr_from_mont(r, a);
 #pragma unroll
                 for (int l = 0; l < 8; l++) trace[((size_t)i * plan.n_trace + k) * 8 + l] = r.v[l];
             }
