@@ -30,9 +30,14 @@ __device__ static constexpr uint8_t B2_SIGMA[12][16] = {
 
 H2V_DI uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
 
-struct B2Msg { uint64_t m[16]; };
-
-H2V_DN void b2_compress(uint64_t (&h)[8], const B2Msg &blk, uint64_t t, bool last) {
+// One compression.  The 128-byte message block is read from LDS (dword d of the calling lane at msg[d * 64]) and the
+// twelve rounds are a real loop whose message schedule is looked up per round (a scalar load of the sigma row, sixteen
+// 64-bit LDS reads): 2.5 KB of code instead of the 24 KB of the unrolled form.  On the combiner's lone waves the
+// unrolled form ran at the speed of instruction fetch - every instruction executed once per call, 32k cycles per
+// compression - while this one stays in the instruction cache.
+typedef __attribute__((address_space(3))) uint32_t h2v_lds_u32;
+H2V_DN void b2_compress_lds(uint64_t (&h)[8], const uint32_t *msg_generic, uint64_t t, bool last) {
+    const h2v_lds_u32 *msg = (const h2v_lds_u32 *)msg_generic;
     uint64_t v[16];
 #pragma unroll
     for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = B2_IV[i]; }
@@ -41,16 +46,22 @@ H2V_DN void b2_compress(uint64_t (&h)[8], const B2Msg &blk, uint64_t t, bool las
 #define B2G(a, b, c, d, x, y)                                                                             \
     v[a] = v[a] + v[b] + (x); v[d] = rotr64(v[d] ^ v[a], 32); v[c] = v[c] + v[d]; v[b] = rotr64(v[b] ^ v[c], 24); \
     v[a] = v[a] + v[b] + (y); v[d] = rotr64(v[d] ^ v[a], 16); v[c] = v[c] + v[d]; v[b] = rotr64(v[b] ^ v[c], 63);
-#pragma unroll
+#pragma unroll 1
     for (int r = 0; r < 12; r++) {
-        B2G(0, 4, 8, 12, blk.m[B2_SIGMA[r][0]], blk.m[B2_SIGMA[r][1]])
-        B2G(1, 5, 9, 13, blk.m[B2_SIGMA[r][2]], blk.m[B2_SIGMA[r][3]])
-        B2G(2, 6, 10, 14, blk.m[B2_SIGMA[r][4]], blk.m[B2_SIGMA[r][5]])
-        B2G(3, 7, 11, 15, blk.m[B2_SIGMA[r][6]], blk.m[B2_SIGMA[r][7]])
-        B2G(0, 5, 10, 15, blk.m[B2_SIGMA[r][8]], blk.m[B2_SIGMA[r][9]])
-        B2G(1, 6, 11, 12, blk.m[B2_SIGMA[r][10]], blk.m[B2_SIGMA[r][11]])
-        B2G(2, 7, 8, 13, blk.m[B2_SIGMA[r][12]], blk.m[B2_SIGMA[r][13]])
-        B2G(3, 4, 9, 14, blk.m[B2_SIGMA[r][14]], blk.m[B2_SIGMA[r][15]])
+        uint64_t w[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t sg = B2_SIGMA[r][i];
+            w[i] = (uint64_t)msg[(2 * sg) * 64] | ((uint64_t)msg[(2 * sg + 1) * 64] << 32);
+        }
+        B2G(0, 4, 8, 12, w[0], w[1])
+        B2G(1, 5, 9, 13, w[2], w[3])
+        B2G(2, 6, 10, 14, w[4], w[5])
+        B2G(3, 7, 11, 15, w[6], w[7])
+        B2G(0, 5, 10, 15, w[8], w[9])
+        B2G(1, 6, 11, 12, w[10], w[11])
+        B2G(2, 7, 8, 13, w[12], w[13])
+        B2G(3, 4, 9, 14, w[14], w[15])
     }
 #undef B2G
 #pragma unroll
@@ -66,16 +77,6 @@ struct Transcript {
     uint32_t buflen;  // bytes waiting in the LDS block
 };
 
-H2V_DI void tr_load_block(B2Msg &blk, const uint32_t *sbuf, int lane, uint32_t valid_bytes) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        uint32_t lo = sbuf[(2 * k) * 64 + lane], hi = sbuf[(2 * k + 1) * 64 + lane];
-        uint32_t b0 = 8 * k, b1 = 8 * k + 4;
-        if (valid_bytes < b0 + 4) lo = valid_bytes <= b0 ? 0u : (lo & ((1u << (8 * (valid_bytes - b0))) - 1u));
-        if (valid_bytes < b1 + 4) hi = valid_bytes <= b1 ? 0u : (hi & ((1u << (8 * (valid_bytes - b1))) - 1u));
-        blk.m[k] = (uint64_t)lo | ((uint64_t)hi << 32);
-    }
-}
 H2V_DI void tr_init(Transcript &s) {
 #pragma unroll
     for (int i = 0; i < 8; i++) s.h[i] = B2_IV[i];
@@ -85,16 +86,13 @@ H2V_DI void tr_init(Transcript &s) {
 }
 H2V_DI void tr_put(Transcript &s, uint32_t *sbuf, int lane, uint32_t byte) {
     if (s.buflen == 128) {  // full and more input follows: not the last block
-        B2Msg blk;
-        tr_load_block(blk, sbuf, lane, 128);
         s.t += 128;
         // through a copy: handing s.h itself to the out-of-line function would pin the whole struct - fill level and
         // byte counter included - in private memory, and every tr_put would then wait for a scratch round trip
-        // (measured: 560 cycles per absorbed byte on a lone wave)
         uint64_t hh[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) hh[i] = s.h[i];
-        b2_compress(hh, blk, s.t, false);
+        b2_compress_lds(hh, sbuf + lane, s.t, false);
 #pragma unroll
         for (int i = 0; i < 8; i++) s.h[i] = hh[i];
         s.buflen = 0;
@@ -102,26 +100,34 @@ H2V_DI void tr_put(Transcript &s, uint32_t *sbuf, int lane, uint32_t byte) {
     reinterpret_cast<uint8_t *>(&sbuf[(s.buflen >> 2) * 64 + lane])[s.buflen & 3] = (uint8_t)byte;
     s.buflen++;
 }
-// digest of everything absorbed so far, leaving the running state untouched (State::finalize on a clone)
-H2V_DI void tr_digest(const Transcript &s, const uint32_t *sbuf, int lane, uint64_t (&out)[4]) {
+// digest of everything absorbed so far, leaving the running state untouched (State::finalize on a clone).  The unused
+// tail of the block buffer is zeroed in place (the padding of the last block); the pending bytes stay where they are.
+H2V_DI void tr_digest(const Transcript &s, uint32_t *sbuf, int lane, uint64_t (&out)[4]) {
     uint64_t h[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) h[i] = s.h[i];
-    B2Msg blk;
-    tr_load_block(blk, sbuf, lane, s.buflen);
-    b2_compress(h, blk, (uint64_t)s.t + s.buflen, true);
+    const uint32_t bl = s.buflen;
+    if (bl & 3) sbuf[(bl >> 2) * 64 + lane] &= (1u << (8 * (bl & 3))) - 1u;
+#pragma unroll 1
+    for (uint32_t d = (bl + 3) >> 2; d < 32; d++) sbuf[d * 64 + lane] = 0;
+    b2_compress_lds(h, sbuf + lane, (uint64_t)s.t + bl, true);
 #pragma unroll
     for (int i = 0; i < 4; i++) out[i] = h[i];
 }
-H2V_DI void b2_hash32(const uint64_t (&in)[4], uint64_t (&out)[4]) {
+// blake2b-256 of a 32-byte message; borrows the lane's block buffer (saved and restored around the call)
+H2V_DI void b2_hash32(const uint64_t (&in)[4], uint64_t (&out)[4], uint32_t *sbuf, int lane) {
     uint64_t h[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) h[i] = B2_IV[i];
     h[0] ^= 0x01010000ull ^ 32ull;
-    B2Msg blk;
+    uint32_t saved[32];
 #pragma unroll
-    for (int k = 0; k < 16; k++) blk.m[k] = k < 4 ? in[k] : 0ull;
-    b2_compress(h, blk, 32, true);
+    for (int d = 0; d < 32; d++) saved[d] = sbuf[d * 64 + lane];
+#pragma unroll
+    for (int d = 0; d < 32; d++) sbuf[d * 64 + lane] = d < 8 ? (uint32_t)(in[d >> 1] >> (32 * (d & 1))) : 0u;
+    b2_compress_lds(h, sbuf + lane, 32, true);
+#pragma unroll
+    for (int d = 0; d < 32; d++) sbuf[d * 64 + lane] = saved[d];
 #pragma unroll
     for (int i = 0; i < 4; i++) out[i] = h[i];
 }
@@ -264,7 +270,7 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
             tr_put(tr, sbuf, lane, 0);
             uint64_t h[4], h2[4];
             tr_digest(tr, sbuf, lane, h);
-            b2_hash32(h, h2);
+            b2_hash32(h, h2, sbuf, lane);
             Fr lo, hi, k;
 #pragma unroll
             for (int l = 0; l < 4; l++) {
