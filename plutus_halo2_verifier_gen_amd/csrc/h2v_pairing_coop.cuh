@@ -30,7 +30,7 @@
 #define COOP_GROUP_SLOTS 64                  // slots reserved per group (COOP_N_GROUP_SLOTS used)
 #define COOP_GROUP_DW (COOP_GROUP_SLOTS * COOP_SLOT_DW)
 #define COOP_GROUPS_PER_WAVE 2
-#define COOP_TAB_DW ((16 * 2 * COOP_N_MUL_TERMS + 2 * 16 * 2 * COOP_N_LINE_TERMS + 16 * 2 * COOP_N_CSQR_TERMS) / 4)  // operand tables, copied at start
+#define COOP_TAB_DW ((16 * 2 * COOP_N_MUL_TERMS + 2 * 16 * 2 * COOP_N_LINE_TERMS + 16 * 2 * COOP_N_CSQR_TERMS + 16 * 2 * COOP_N_SQR_TERMS) / 4)  // operand tables, copied at start
 #define COOP_LDS_DW (COOP_GROUPS_PER_WAVE * COOP_GROUP_DW + COOP_N_SHARED_SLOTS * COOP_SLOT_DW + COOP_TAB_DW)
 
 // File-scope LDS so that every device function addresses it as LDS (ds_read/ds_write), not through flat pointers.
@@ -41,6 +41,7 @@ __shared__ __attribute__((aligned(16))) uint32_t coop_lds[COOP_LDS_DW];
 #define COOP_TAB_LINE1_B (16 * 2 * COOP_N_MUL_TERMS)
 #define COOP_TAB_LINE2_B (COOP_TAB_LINE1_B + 16 * 2 * COOP_N_LINE_TERMS)
 #define COOP_TAB_CSQR_B (COOP_TAB_LINE2_B + 16 * 2 * COOP_N_LINE_TERMS)
+#define COOP_TAB_SQR_B (COOP_TAB_CSQR_B + 16 * 2 * COOP_N_CSQR_TERMS)
 
 struct Coop {
     int grp_off;  // dword offset of this group's slots in coop_lds
@@ -212,6 +213,39 @@ H2V_DI F28 coop_csqr(const Coop &c, const F28 &a) {
     __syncthreads();
     return r;
 }
+// a^2 for a general a (the Miller loop's f^2): 8 terms per coefficient instead of the 12 of coop_mul(a, a)
+// (tools/gen_coop_tables.py: sqr_table).  Operands: A = a (6), NA = 7p - a_im (7) from the half-0 lanes; from the
+// half-1 lanes D = 2a (12), XD = xi D = (d0 - d1 + 13p, d0 + d1) (25) and, for k = 3..5, XA = xi a = (a0 - a1 + 7p,
+// a0 + a1) (13).  A half-sum is below (4 * 7 * 25 / 2520 + 1) p = 1.28 p, so the result is below 3p like a product's.
+H2V_DI F28 coop_sqr(const Coop &c, const F28 &a) {
+    coop_stage_a(c, a);
+    const F28 pa = coop_shfl_xor1(a);          // the other part of the same Fp2 coefficient
+    if (c.g < 12 && c.h == 1) {
+        F28 d2, pd2, t, xd;
+        f28_mul_small<2>(d2, a);               // (12, 2)
+        f28_carry(d2);
+        coop_store28(coop_slot(c, COOP_SLOT_D + c.g), d2);
+        f28_mul_small<2>(pd2, pa);
+        f28_carry(pd2);
+        F28_NEG(t, pd2, 13, 2);                // 13p - d1
+        if (c.g & 1) t = pd2;                  // imaginary part: (xi d)_1 = d0 + d1 ; real part: (xi d)_0 = d0 - d1
+        f28_add(xd, d2, t);
+        f28_carry(xd);
+        coop_store28(coop_slot(c, COOP_SLOT_XD + c.g), xd);
+        if (c.g >= 6) {
+            F28 xa;
+            F28_NEG(t, pa, 7, 1);
+            if (c.g & 1) t = pa;
+            f28_add(xa, a, t);
+            f28_carry(xa);
+            coop_store28(coop_slot(c, COOP_SLOT_XA + (c.g - 6)), xa);
+        }
+    }
+    __syncthreads();
+    const F28 r = coop_engine<COOP_N_SQR_TERMS, false>(c, COOP_TAB_SQR_B + c.g * 2 * COOP_N_SQR_TERMS);
+    __syncthreads();
+    return r;
+}
 H2V_DI F28 coop_conj(const Coop &c, const F28 &a) {  // w -> -w: odd powers change sign.  a: v <= 5
     F28 r = a;
     if (c.g < 12 && ((c.g >> 1) & 1)) {
@@ -344,6 +378,9 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
         for (int q = lane; q < n0; q += 64) coop_lds[COOP_TAB_OFF + q] = t0[q];
         for (int q = lane; q < n1; q += 64) { coop_lds[COOP_TAB_OFF + n0 + q] = t1[q]; coop_lds[COOP_TAB_OFF + n0 + n1 + q] = t2[q]; }
         for (int q = lane; q < n3; q += 64) coop_lds[COOP_TAB_OFF + n0 + 2 * n1 + q] = t3[q];
+        const uint32_t *t4 = reinterpret_cast<const uint32_t *>(&COOP_TAB_SQR[0][0]);
+        constexpr int n4 = 16 * 2 * COOP_N_SQR_TERMS / 4;
+        for (int q = lane; q < n4; q += 64) coop_lds[COOP_TAB_OFF + n0 + 2 * n1 + n3 + q] = t4[q];
     }
     // ---- leader: status, the two G1 arguments (el ; -er normalised to affine)
     uint32_t st = 0;
@@ -401,6 +438,10 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
         case COOP_OP_CSQR: {
             const F28 x = vars[a];
             vars[d] = coop_csqr(c, x);
+        } break;
+        case COOP_OP_SQR: {
+            const F28 x = vars[a];
+            vars[d] = coop_sqr(c, x);
         } break;
         case COOP_OP_LINE: {
             // d = loop, a = line index.  Invariants (see coop_tables.h / gen_coop_tables.py): before LINE1(n) the

@@ -16,8 +16,8 @@ sys.path.insert(0, ROOT)
 from plutus_halo2_verifier_gen_amd import bls12_381 as bls  # noqa: E402
 
 # opcodes (4 bytes per instruction: op, dst, a, b)
-OP_END, OP_MUL, OP_LINE, OP_CONJ, OP_FROB, OP_INV, OP_MOV, OP_SETONE, OP_DUMP, OP_WARMUP, OP_CSQR = range(11)
-OP_NAMES = ["END", "MUL", "LINE", "CONJ", "FROB", "INV", "MOV", "SETONE", "DUMP", "WARMUP", "CSQR"]
+OP_END, OP_MUL, OP_LINE, OP_CONJ, OP_FROB, OP_INV, OP_MOV, OP_SETONE, OP_DUMP, OP_WARMUP, OP_CSQR, OP_SQR = range(12)
+OP_NAMES = ["END", "MUL", "LINE", "CONJ", "FROB", "INV", "MOV", "SETONE", "DUMP", "WARMUP", "CSQR", "SQR"]
 # variables
 F, A, T, U, T0, T1, T2, T3, X = range(9)
 N_VARS = 9
@@ -30,7 +30,7 @@ def build_program():
     e(OP_WARMUP)
     line = 0
     for bit in bls.miller_bits():
-        e(OP_MUL, F, F, F)
+        e(OP_SQR, F, F)           # general squaring: 8 terms per coefficient instead of MUL's 12
         for _ in range(2 if bit else 1):
             e(OP_LINE, 1, line)
             e(OP_LINE, 2, line)
@@ -82,7 +82,7 @@ def check_bounds(prog):
         elif op == OP_MUL:
             assert v[a] <= 6 and v[b] <= 6
             v[d] = 3
-        elif op == OP_CSQR:
+        elif op == OP_CSQR or op == OP_SQR:
             assert v[a] <= 6
             v[d] = 3
         elif op == OP_LINE:
@@ -120,7 +120,7 @@ def simulate(prog, p1, q1, p2, q2):
             pass
         elif op == OP_MUL:
             v[d] = bls.f12_mul(v[a], v[b])
-        elif op == OP_CSQR:
+        elif op == OP_CSQR or op == OP_SQR:
             v[d] = bls.f12_sqr(v[a])
         elif op == OP_LINE:
             loop, idx = d, a
@@ -184,7 +184,8 @@ def emit():
     n_mul = sum(1 for p in prog if p[0] == OP_MUL)
     n_line = sum(1 for p in prog if p[0] == OP_LINE)
     n_csqr = sum(1 for p in prog if p[0] == OP_CSQR)
-    o.append("// %d instructions: %d MUL, %d CSQR, %d LINE" % (len(prog), n_mul, n_csqr, n_line))
+    n_sqr = sum(1 for p in prog if p[0] == OP_SQR)
+    o.append("// %d instructions: %d MUL, %d SQR, %d CSQR, %d LINE" % (len(prog), n_mul, n_sqr, n_csqr, n_line))
     path = os.path.join(ROOT, "plutus_halo2_verifier_gen_amd", "csrc", "coop_program.h")
     with open(path, "w") as f:
         f.write("\n".join(o) + "\n")

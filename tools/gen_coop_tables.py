@@ -30,7 +30,8 @@ SLOT_T1 = 42      # 4 : loop-1 line products  b0, b1, (xi b)0, (xi b)1   with b 
 SLOT_T2 = 46      # 4 : same for loop 2
 SLOT_PX1, SLOT_PY1, SLOT_PX2, SLOT_PY2 = 50, 51, 52, 53
 SLOT_ZERO = 54
-N_GROUP_SLOTS = 56
+SLOT_XA = 56      # 6 : (xi * a)_{k,part} for k = 3, 4, 5 (the wrapped squares of SQR) at XA + 2 (k - 3) + part
+N_GROUP_SLOTS = 62
 SH = 64           # shared slots: per line 8 constants  [nl0, nl1, nxl0, nxl1, c0, c1, xc0, xc1]
 SLOT_LN1 = SH + 0
 SLOT_LN2 = SH + 8
@@ -43,6 +44,9 @@ LN_NL0, LN_NL1, LN_NXL0, LN_NXL1, LN_C0, LN_C1, LN_XC0, LN_XC1 = range(8)
 N_MUL_TERMS = 12
 N_LINE_TERMS = 6
 N_CSQR_TERMS = 6
+N_SQR_TERMS = 8
+# general squaring (the Miller loop's f^2) stages D = 2a in the B area and XD = xi * D in the XB area
+SLOT_XD = SLOT_XB
 # cyclotomic squaring reuses the B area for the doubled operand D = 2*g (12 slots); products with -2*g_k1 are taken
 # as (-g_k1) * (2*g): no separate negated-doubled operand is staged (ND kept as a name for the simulation only)
 SLOT_D = SLOT_B
@@ -115,6 +119,62 @@ def line_table(loop):
             terms.append((SLOT_ZERO, SLOT_ZERO))
         tab.append(terms)
     return tab
+
+
+def sqr_table():
+    """c = a^2 for a general Fp12 element, 8 terms per coefficient instead of MUL's 12: the products a_i a_j and
+    a_j a_i of c_k = sum_{i+j = k mod 6} a_i a_j (x xi when i + j >= 6) are taken once against the doubled operand
+    D = 2a (XD = xi D when wrapped); the two squares a_i^2 (i = k/2 unwrapped, i = k/2 + 3 wrapped, k even) are
+    a_i x a_i and a_i x (xi a_i) = a_i x XA_i, their imaginary part 2 a_i0 a_i1 again through D."""
+    A = lambda k, part: SLOT_A + 2 * k + part
+    NA = lambda k: SLOT_NA + k
+    D = lambda k, part: SLOT_D + 2 * k + part
+    XD = lambda k, part: SLOT_XD + 2 * k + part
+    XA = lambda k, part: SLOT_XA + 2 * (k - 3) + part
+    tab = []
+    for g in range(16):
+        terms = []
+        if g < 12:
+            k, part = g >> 1, g & 1
+            for i in range(6):
+                j = (k - i) % 6
+                if i > j:
+                    continue
+                wrapped = i + j >= 6
+                if i < j:
+                    Y = XD if wrapped else D
+                    if part == 0:
+                        terms += [(A(i, 0), Y(j, 0)), (NA(i), Y(j, 1))]
+                    else:
+                        terms += [(A(i, 0), Y(j, 1)), (A(i, 1), Y(j, 0))]
+                elif not wrapped:        # a_i^2
+                    if part == 0:
+                        terms += [(A(i, 0), A(i, 0)), (NA(i), A(i, 1))]
+                    else:
+                        terms += [(A(i, 0), D(i, 1))]
+                else:                    # xi a_i^2 = a_i x XA_i
+                    if part == 0:
+                        terms += [(A(i, 0), XA(i, 0)), (NA(i), XA(i, 1))]
+                    else:
+                        terms += [(A(i, 0), XA(i, 1)), (A(i, 1), XA(i, 0))]
+        assert len(terms) <= N_SQR_TERMS
+        while len(terms) < N_SQR_TERMS:
+            terms.append((SLOT_ZERO, SLOT_ZERO))
+        tab.append(terms)
+    return tab
+
+
+def stage_sqr(a):
+    s = {SLOT_ZERO: 0}
+    for k in range(6):
+        s[SLOT_A + 2 * k], s[SLOT_A + 2 * k + 1] = a[k]
+        s[SLOT_NA + k] = (-a[k][1]) % P
+        d = (2 * a[k][0] % P, 2 * a[k][1] % P)
+        s[SLOT_D + 2 * k], s[SLOT_D + 2 * k + 1] = d
+        s[SLOT_XD + 2 * k], s[SLOT_XD + 2 * k + 1] = bls.f2_mul(bls.XI, d)
+        if k >= 3:
+            s[SLOT_XA + 2 * (k - 3)], s[SLOT_XA + 2 * (k - 3) + 1] = bls.f2_mul(bls.XI, a[k])
+    return s
 
 
 def csqr_table():
@@ -244,6 +304,10 @@ def self_check():
             # spare lanes: products for the other loop's next line
             exp = [v * xo % P for v in line_consts(lam_o, (0, 0))[:4]]
             assert out[12:16] == exp
+    st = sqr_table()
+    for _ in range(10):
+        a = [rf2() for _ in range(6)]
+        assert to_flat(run(st, stage_sqr(a))) == bls.f12_sqr(a) == bls.f12_mul(a, a)
     # cyclotomic squaring on an element of the cyclotomic subgroup (easy part of a Miller value)
     f = bls.miller_loop(bls.g1_mul(bls.G1_GEN, 777), bls.g2_mul(bls.G2_GEN, 3))
     t = bls.f12_mul(bls.f12_conj(f), bls.f12_inv(f))
@@ -262,7 +326,8 @@ def emit():
          "#pragma once", "#include <stdint.h>"]
     for name in ("SLOT_A", "SLOT_NA", "SLOT_B", "SLOT_XB", "SLOT_T1", "SLOT_T2", "SLOT_PX1", "SLOT_PY1", "SLOT_PX2",
                  "SLOT_PY2", "SLOT_ZERO", "N_GROUP_SLOTS", "SLOT_LN1", "SLOT_LN2", "N_SHARED_SLOTS", "N_MUL_TERMS",
-                 "N_LINE_TERMS", "N_CSQR_TERMS", "SLOT_D", "SLOT_ND", "SLOT_C23P", "SLOT_C23N"):
+                 "N_LINE_TERMS", "N_CSQR_TERMS", "SLOT_D", "SLOT_ND", "SLOT_C23P", "SLOT_C23N", "SLOT_XA", "SLOT_XD",
+                 "N_SQR_TERMS"):
         o.append("#define COOP_%s %d" % (name, globals()[name]))
     o.append("#define COOP_SHARED_BASE %d" % SH)
 
@@ -276,6 +341,7 @@ def emit():
     arr("COOP_TAB_LINE1", line_table(1), N_LINE_TERMS)
     arr("COOP_TAB_LINE2", line_table(2), N_LINE_TERMS)
     arr("COOP_TAB_CSQR", csqr_table(), N_CSQR_TERMS)
+    arr("COOP_TAB_SQR", sqr_table(), N_SQR_TERMS)
     path = os.path.join(ROOT, "plutus_halo2_verifier_gen_amd", "csrc", "coop_tables.h")
     with open(path, "w") as f:
         f.write("\n".join(o) + "\n")
