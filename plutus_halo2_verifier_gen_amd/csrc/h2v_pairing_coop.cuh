@@ -76,9 +76,9 @@ H2V_DI void coop_load28(uint32_t (&l)[14], const uint32_t *p) {
 // notation:  every Fp12 variable has lam = 1 and v <= 6 (engine outputs 3, conj 6, frob 5, inverse 3; the
 // generated program is checked for this by tools/gen_coop_program.py).  Operand slots must hold carried limbs: a
 // MUL column sums 12 terms x 14 products, which fills the 64-bit accumulator at lam = 1.  Staged operands:
-//   A = a (6)   NA = 7p - a_im (7)   B = b (6)   XB = (b0 - b1 + 7p, b0 + b1) (13)   D = 2a (12)
+//   A = a (6)   NA = 7p - a_im (7)   B = b (6)   XB = (b0 - b1 + 7p, b0 + b1) (13)   D = 2a (12)   (squarings: see coop_csqr / coop_sqr)
 // Each of the two lanes sharing a coefficient reduces its half of the terms on its own: a half is below
-// (6 * 7 * 13 / 2520 + 1) p = 1.22 p for MUL and (3 * 3 * 7 * 13 / 2520 + 1) p = 1.33 p for the tripled cyclotomic
+// (6 * 7 * 13 / 2520 + 1) p = 1.22 p for MUL and (3 * 2 * 7 * 26 / 2520 + 1) p = 1.44 p for the tripled cyclotomic
 // squaring (p / R < 1/2520), so the engine's result (the sum of the two halves) is below 3p.
 
 // out = sum_t X[tab[2t]] * Y[tab[2t+1]]  (mod p), one Montgomery reduction.  NT <= 12 (accumulator headroom).
@@ -148,7 +148,7 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
         const auto sw = __builtin_amdgcn_permlane16_swap(r.l[i], r.l[i], false, false);
         r.l[i] = sw[0] + sw[1];
     }
-    f28_carry(r);   // value < 2 * 1.33 p, limbs back below 2^28
+    f28_carry(r);   // value < 2 * 1.44 p, limbs back below 2^28
     return f28_pack(r);
 }
 template <int NT, bool TRIPLE>
@@ -198,15 +198,30 @@ H2V_DI F28 coop_mul(const Coop &c, const F28 &a, const F28 &b) {
     return r;
 }
 // a^2 for a in the cyclotomic subgroup (Granger-Scott; formulas and table: tools/gen_coop_tables.py: csqr_table).
-// Operands: A = a, NA = -a_im (half 0 lanes), D = 2a (half 1 lanes; -2 a_im b is taken as (-a_im)(2b)), and the shared
-// constants +-2/3: the engine returns 3 (Q_k -/+ (2/3) a_k) = 3 Q_k -/+ 2 a_k already reduced.
+// Operands: A = a (6), NA = 7p - a_im (7) from the half-0 lanes; from the half-1 lanes D = 2a (12) and, per Fp2
+// coefficient, the sum S = a_re + a_im (12) and the difference M = a_re - a_im + 7p (13) (Re(x^2) = S M is one product
+// instead of two), plus 2 S, 2 M (26) of the last coefficient; and the shared constants +-2/3: the engine returns
+// 3 (Q_k -/+ (2/3) a_k) = 3 Q_k -/+ 2 a_k already reduced.  Four terms per coefficient, two per lane; a half-sum is
+// below (3 * 2 * 7 * 26 / 2520 + 1) p = 1.44 p.
 H2V_DI F28 coop_csqr(const Coop &c, const F28 &a) {
     coop_stage_a(c, a);
+    const F28 pa = coop_shfl_xor1(a);          // the other part of the same Fp2 coefficient
     if (c.g < 12 && c.h == 1) {
-        F28 d2;
+        F28 d2, sm, t;
         f28_mul_small<2>(d2, a);               // (12, 2)
         f28_carry(d2);
         coop_store28(coop_slot(c, COOP_SLOT_D + c.g), d2);
+        if (c.g & 1) { F28_NEG(t, a, 7, 1); }  // imaginary-part lane: M = re - im = pa + (7p - a)
+        else t = a;                            // real-part lane:      S = re + im = a + pa
+        f28_add(sm, pa, t);
+        f28_carry(sm);                         // S (12, 1) / M (13, 1)
+        coop_store28(coop_slot(c, COOP_SLOT_SM + c.g), sm);
+        if (c.g >= 10) {                       // 2 S_5 -> DS5, 2 M_5 -> DM5
+            F28 ds;
+            f28_mul_small<2>(ds, sm);
+            f28_carry(ds);
+            coop_store28(coop_slot(c, COOP_SLOT_DS5 + (c.g - 10)), ds);
+        }
     }
     __syncthreads();
     const F28 r = coop_engine<COOP_N_CSQR_TERMS, true>(c, COOP_TAB_CSQR_B + c.g * 2 * COOP_N_CSQR_TERMS);
@@ -435,31 +450,31 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
             const F28 x = vars[a], y = vars[b];
             vars[d] = coop_mul(c, x, y);
         } break;
-        case COOP_OP_CSQR: {
-            const F28 x = vars[a];
-            vars[d] = coop_csqr(c, x);
+        case COOP_OP_CSQR: {   // b squarings in a row: the value stays in registers between them
+            F28 x = vars[a];
+#pragma unroll 1
+            for (int rep = 0; rep < b; rep++) x = coop_csqr(c, x);
+            vars[d] = x;
         } break;
-        case COOP_OP_SQR: {
-            const F28 x = vars[a];
-            vars[d] = coop_sqr(c, x);
-        } break;
-        case COOP_OP_LINE: {
-            // d = loop, a = line index.  Invariants (see coop_tables.h / gen_coop_tables.py): before LINE1(n) the
+        case COOP_OP_MSTEP: {
+            // One Miller-loop step on F (kept in registers throughout): F = F^2, then d times (line of loop 1, line of
+            // loop 2) from line index a.  Invariants (see coop_tables.h / gen_coop_tables.py): before LINE1(n) the
             // shared slots hold LN1(n) and T1(n); LINE1's spare lanes produce T2(n) from LN2(n); LINE2's spare lanes
             // produce T1(n+1) from LN1(n+1).
-            const F28 f = vars[COOP_VAR_F];
-            F28 r;
-            if (d == 1) {
-                if (a > 0) coop_stage_line(c, COOP_SLOT_LN2, plan.lines28_g2, a, lane);
+            F28 f = vars[COOP_VAR_F];
+            f = coop_sqr(c, f);
+#pragma unroll 1
+            for (int ln = a; ln < a + d; ln++) {
+                if (ln > 0) coop_stage_line(c, COOP_SLOT_LN2, plan.lines28_g2, ln, lane);
                 __syncthreads();
-                r = coop_line<1>(c, f);
-                if (!skip1 && c.g < 12) vars[COOP_VAR_F] = r;
-            } else {
-                if (a + 1 < H2V_MILLER_LINES) coop_stage_line(c, COOP_SLOT_LN1, plan.lines28_sg2, a + 1, lane);
+                const F28 r1 = coop_line<1>(c, f);
+                if (!skip1 && c.g < 12) f = r1;
+                if (ln + 1 < H2V_MILLER_LINES) coop_stage_line(c, COOP_SLOT_LN1, plan.lines28_sg2, ln + 1, lane);
                 __syncthreads();
-                r = coop_line<2>(c, f);
-                if (!skip2 && c.g < 12) vars[COOP_VAR_F] = r;
+                const F28 r2 = coop_line<2>(c, f);
+                if (!skip2 && c.g < 12) f = r2;
             }
+            vars[COOP_VAR_F] = f;
         } break;
         case COOP_OP_WARMUP: {
             coop_stage_line(c, COOP_SLOT_LN1, plan.lines28_sg2, 0, lane);

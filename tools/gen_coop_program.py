@@ -16,8 +16,13 @@ sys.path.insert(0, ROOT)
 from plutus_halo2_verifier_gen_amd import bls12_381 as bls  # noqa: E402
 
 # opcodes (4 bytes per instruction: op, dst, a, b)
-OP_END, OP_MUL, OP_LINE, OP_CONJ, OP_FROB, OP_INV, OP_MOV, OP_SETONE, OP_DUMP, OP_WARMUP, OP_CSQR, OP_SQR = range(12)
-OP_NAMES = ["END", "MUL", "LINE", "CONJ", "FROB", "INV", "MOV", "SETONE", "DUMP", "WARMUP", "CSQR", "SQR"]
+OP_END, OP_MUL, OP_MSTEP, OP_CONJ, OP_FROB, OP_INV, OP_MOV, OP_SETONE, OP_DUMP, OP_WARMUP, OP_CSQR = range(11)
+OP_NAMES = ["END", "MUL", "MSTEP", "CONJ", "FROB", "INV", "MOV", "SETONE", "DUMP", "WARMUP", "CSQR"]
+# MSTEP n, line: one step of the Miller loop on F: F = F^2 (general squaring), then n in {1, 2} times { F *= line of
+# loop 1, F *= line of loop 2 } starting at line index `line` (doubling step; plus the addition step where the bit of
+# |x| is set).  F stays in registers for the whole step.
+# CSQR d, a, n: d = a^(2^n) by n cyclotomic squarings; the value stays in registers between them (a run of squarings
+# is one interpreter step: no round trip of the variable through private memory per squaring)
 # variables
 F, A, T, U, T0, T1, T2, T3, X = range(9)
 N_VARS = 9
@@ -30,11 +35,9 @@ def build_program():
     e(OP_WARMUP)
     line = 0
     for bit in bls.miller_bits():
-        e(OP_SQR, F, F)           # general squaring: 8 terms per coefficient instead of MUL's 12
-        for _ in range(2 if bit else 1):
-            e(OP_LINE, 1, line)
-            e(OP_LINE, 2, line)
-            line += 1
+        n = 2 if bit else 1
+        e(OP_MSTEP, n, line)
+        line += n
     assert line == 68
     # x < 0: the Miller value is m = conj(F).  Easy part m^(p^6-1) = conj(m) * m^-1 = F * conj(F^-1); written so that
     # every CONJ / INV operand is an engine output (the lazily reduced field bounds of h2v_pairing_coop.cuh).
@@ -48,11 +51,16 @@ def build_program():
     e(OP_MUL, T, A, T)        # ^(p^2+1)
 
     def exp_x(dst, src):      # dst = src^x, x = -|x|  (cyclotomic subgroup: inverse = conjugate)
-        e(OP_MOV, X, src)
-        for bit in bls.miller_bits():
-            e(OP_CSQR, X, X)      # Granger-Scott squaring: X is in the cyclotomic subgroup after the easy part
+        bits = bls.miller_bits()          # the bits of |x| below the leading one
+        cur, run = src, 0
+        for bit in bits:
+            run += 1                      # Granger-Scott squaring: X is in the cyclotomic subgroup after the easy part
             if bit:
+                e(OP_CSQR, X, cur, run)
                 e(OP_MUL, X, X, src)
+                cur, run = X, 0
+        if run:
+            e(OP_CSQR, X, cur, run)
         e(OP_CONJ, dst, X)
 
     exp_x(A, T); e(OP_CONJ, U, T); e(OP_MUL, T0, A, U)       # t^(x-1)
@@ -82,11 +90,11 @@ def check_bounds(prog):
         elif op == OP_MUL:
             assert v[a] <= 6 and v[b] <= 6
             v[d] = 3
-        elif op == OP_CSQR or op == OP_SQR:
-            assert v[a] <= 6
+        elif op == OP_CSQR:
+            assert v[a] <= 6 and b >= 1
             v[d] = 3
-        elif op == OP_LINE:
-            assert v[F] <= 6
+        elif op == OP_MSTEP:
+            assert v[F] <= 6 and d in (1, 2)
             v[F] = 3
         elif op == OP_CONJ:
             assert v[a] <= 5, "CONJ of a value that is not an engine / FROB result"
@@ -120,12 +128,17 @@ def simulate(prog, p1, q1, p2, q2):
             pass
         elif op == OP_MUL:
             v[d] = bls.f12_mul(v[a], v[b])
-        elif op == OP_CSQR or op == OP_SQR:
-            v[d] = bls.f12_sqr(v[a])
-        elif op == OP_LINE:
-            loop, idx = d, a
-            if pts[loop] is not None:
-                v[F] = bls.f12_mul(v[F], bls._line_eval(lines[loop][idx], pts[loop]))
+        elif op == OP_CSQR:
+            t = v[a]
+            for _ in range(b):
+                t = bls.f12_sqr(t)
+            v[d] = t
+        elif op == OP_MSTEP:
+            v[F] = bls.f12_sqr(v[F])
+            for idx in range(a, a + d):
+                for loop in (1, 2):
+                    if pts[loop] is not None:
+                        v[F] = bls.f12_mul(v[F], bls._line_eval(lines[loop][idx], pts[loop]))
         elif op == OP_CONJ:
             v[d] = bls.f12_conj(v[a])
         elif op == OP_FROB:
@@ -182,9 +195,9 @@ def emit():
         o.append("    " + ", ".join(row) + ",")
     o.append("};")
     n_mul = sum(1 for p in prog if p[0] == OP_MUL)
-    n_line = sum(1 for p in prog if p[0] == OP_LINE)
-    n_csqr = sum(1 for p in prog if p[0] == OP_CSQR)
-    n_sqr = sum(1 for p in prog if p[0] == OP_SQR)
+    n_line = sum(2 * p[1] for p in prog if p[0] == OP_MSTEP)
+    n_csqr = sum(p[3] for p in prog if p[0] == OP_CSQR)
+    n_sqr = sum(1 for p in prog if p[0] == OP_MSTEP)
     o.append("// %d instructions: %d MUL, %d SQR, %d CSQR, %d LINE" % (len(prog), n_mul, n_sqr, n_csqr, n_line))
     path = os.path.join(ROOT, "plutus_halo2_verifier_gen_amd", "csrc", "coop_program.h")
     with open(path, "w") as f:

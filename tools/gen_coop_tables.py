@@ -43,14 +43,17 @@ LN_NL0, LN_NL1, LN_NXL0, LN_NXL1, LN_C0, LN_C1, LN_XC0, LN_XC1 = range(8)
 
 N_MUL_TERMS = 12
 N_LINE_TERMS = 6
-N_CSQR_TERMS = 6
+N_CSQR_TERMS = 4
 N_SQR_TERMS = 8
 # general squaring (the Miller loop's f^2) stages D = 2a in the B area and XD = xi * D in the XB area
 SLOT_XD = SLOT_XB
-# cyclotomic squaring reuses the B area for the doubled operand D = 2*g (12 slots); products with -2*g_k1 are taken
-# as (-g_k1) * (2*g): no separate negated-doubled operand is staged (ND kept as a name for the simulation only)
+# cyclotomic squaring reuses the B area for the doubled operand D = 2*g (12 slots; products with -2*g_k1 are taken as
+# (-g_k1) * (2*g)), the XB area for the sums / differences S_k = g_k0 + g_k1, M_k = g_k0 - g_k1 (S_k at SM + 2k, M_k at
+# SM + 2k + 1) and two slots of the XA area for 2 S_5, 2 M_5
 SLOT_D = SLOT_B
-SLOT_ND = SLOT_XB
+SLOT_SM = SLOT_XB
+SLOT_DS5 = SLOT_XA
+SLOT_DM5 = SLOT_XA + 1
 
 
 def mul_table():
@@ -182,13 +185,19 @@ def csqr_table():
          h0 = 3(g0^2 + xi g3^2) - 2g0   h3 = 3(2 g0 g3) + 2g3
          h1 = 3 xi (2 g2 g5)    + 2g1   h4 = 3(g2^2 + xi g5^2) - 2g4
          h2 = 3(g1^2 + xi g4^2) - 2g2   h5 = 3(2 g1 g4) + 2g5
-    The engine computes Q'_k = Q_k -/+ (2/3) g_k (minus for even k; the 6th term of every lane, against the shared
+    With the staged sums and differences S_k = g_k0 + g_k1, M_k = g_k0 - g_k1 (Re(x^2) = S M: one product instead of
+    two) and D = 2g every Fp coefficient is at most THREE products (xi = 1 + u: xi z = (z0 - z1, z0 + z1)):
+         even, real:  S_a M_a + S_b M_b - g_b1 D_b0          imaginary:  g_a0 D_a1 + S_b M_b + g_b0 D_b1
+         odd,  real:  g_a0 D_b0 - g_a1 D_b1                  imaginary:  g_a0 D_b1 + g_a1 D_b0
+         xi-odd, real: g_a0 (2 M_b) - g_a1 (2 S_b)           imaginary:  g_a0 (2 S_b) + g_a1 (2 M_b)
+    The engine computes Q'_k = Q_k -/+ (2/3) g_k (minus for even k; the last term of every lane, against the shared
     constants +-2/3) with its column accumulators tripled before the Montgomery reduction, so h_k = 3 Q'_k leaves the
-    engine reduced and no additive post-processing is left to the lane."""
+    engine reduced and no additive post-processing is left to the lane: 4 terms per coefficient, 2 per lane."""
     A = lambda k, part: SLOT_A + 2 * k + part
     NA = lambda k: SLOT_NA + k
     D = lambda k, part: SLOT_D + 2 * k + part
-    ND = lambda k: SLOT_ND + k
+    S = lambda k: SLOT_SM + 2 * k
+    M = lambda k: SLOT_SM + 2 * k + 1
     kind = {0: ("even", 0, 3), 3: ("odd", 0, 3), 1: ("xi_odd", 2, 5), 4: ("even", 2, 5), 2: ("even", 1, 4), 5: ("odd", 1, 4)}
     tab = []
     for g in range(16):
@@ -198,19 +207,20 @@ def csqr_table():
             ty, a, b = kind[k]
             if ty == "even":    # a^2 + xi b^2
                 if part == 0:
-                    terms = [(A(a, 0), A(a, 0)), (NA(a), A(a, 1)), (A(b, 0), A(b, 0)), (NA(b), A(b, 1)), (NA(b), D(b, 0))]
+                    terms = [(S(a), M(a)), (S(b), M(b)), (NA(b), D(b, 0))]
                 else:
-                    terms = [(A(a, 0), D(a, 1)), (A(b, 0), A(b, 0)), (NA(b), A(b, 1)), (A(b, 0), D(b, 1))]
+                    terms = [(A(a, 0), D(a, 1)), (S(b), M(b)), (A(b, 0), D(b, 1))]
             elif ty == "odd":   # 2 a b
                 if part == 0:
                     terms = [(A(a, 0), D(b, 0)), (NA(a), D(b, 1))]
                 else:
                     terms = [(A(a, 0), D(b, 1)), (A(a, 1), D(b, 0))]
-            else:               # 2 xi a b
+            else:               # 2 xi a b, b = g5: the doubled sum / difference of g5 sit in DS5 / DM5
+                assert b == 5
                 if part == 0:
-                    terms = [(A(a, 0), D(b, 0)), (NA(a), D(b, 1)), (NA(b), D(a, 0)), (NA(a), D(b, 0))]
+                    terms = [(A(a, 0), SLOT_DM5), (NA(a), SLOT_DS5)]
                 else:
-                    terms = [(A(a, 0), D(b, 0)), (NA(a), D(b, 1)), (A(a, 0), D(b, 1)), (A(a, 1), D(b, 0))]
+                    terms = [(A(a, 0), SLOT_DS5), (A(a, 1), SLOT_DM5)]
         if g < 12:
             assert len(terms) <= N_CSQR_TERMS - 1
             terms.append((A(g >> 1, g & 1), SLOT_C23N if (g >> 1) % 2 == 0 else SLOT_C23P))
@@ -226,7 +236,8 @@ def stage_csqr(g):
         s[SLOT_A + 2 * k], s[SLOT_A + 2 * k + 1] = g[k]
         s[SLOT_NA + k] = (-g[k][1]) % P
         s[SLOT_D + 2 * k], s[SLOT_D + 2 * k + 1] = 2 * g[k][0] % P, 2 * g[k][1] % P
-        s[SLOT_ND + k] = (-2 * g[k][1]) % P
+        s[SLOT_SM + 2 * k], s[SLOT_SM + 2 * k + 1] = (g[k][0] + g[k][1]) % P, (g[k][0] - g[k][1]) % P
+    s[SLOT_DS5], s[SLOT_DM5] = 2 * (g[5][0] + g[5][1]) % P, 2 * (g[5][0] - g[5][1]) % P
     return s
 
 
@@ -326,7 +337,7 @@ def emit():
          "#pragma once", "#include <stdint.h>"]
     for name in ("SLOT_A", "SLOT_NA", "SLOT_B", "SLOT_XB", "SLOT_T1", "SLOT_T2", "SLOT_PX1", "SLOT_PY1", "SLOT_PX2",
                  "SLOT_PY2", "SLOT_ZERO", "N_GROUP_SLOTS", "SLOT_LN1", "SLOT_LN2", "N_SHARED_SLOTS", "N_MUL_TERMS",
-                 "N_LINE_TERMS", "N_CSQR_TERMS", "SLOT_D", "SLOT_ND", "SLOT_C23P", "SLOT_C23N", "SLOT_XA", "SLOT_XD",
+                 "N_LINE_TERMS", "N_CSQR_TERMS", "SLOT_D", "SLOT_SM", "SLOT_DS5", "SLOT_DM5", "SLOT_C23P", "SLOT_C23N", "SLOT_XA", "SLOT_XD",
                  "N_SQR_TERMS"):
         o.append("#define COOP_%s %d" % (name, globals()[name]))
     o.append("#define COOP_SHARED_BASE %d" % SH)
