@@ -135,11 +135,41 @@ H2V_DN void f28_pow_const(F28 &r, const F28 &a, const uint32_t (&e)[NW]) {
     bool started = false;
 #pragma unroll 1
     for (int i = NW * 32 - 1; i >= 0; i--) {
-        if (started) f28_sqr(acc, acc);
-        if ((e[i >> 5] >> (i & 31)) & 1) {
-            if (started) f28_mul(acc, acc, a);
+        if (started) f28_sqr_inl(acc, acc);     // inlined: the loop is 380 squarings + 190 products long, and the
+        if ((e[i >> 5] >> (i & 31)) & 1) {      // argument marshalling of a call is a fifth of its instructions
+            if (started) f28_mul_inl(acc, acc, a);
             else { acc = a; started = true; }
         }
     }
+    r = acc;
+}
+
+// r = a^((p+1)/4) along the generated sliding-window chain (bls_consts.h: FP_SQRT_CHAIN; odd powers a, a^3 .. a^15 kept in
+// registers and picked with a wave-uniform switch): 377 squarings + 78 + 8 products instead of 380 + 190.  a: (2, 1) or better.
+H2V_DN void f28_sqrt_chain(F28 &r, const F28 &a) {
+    F28 t0 = a, t1, t2, t3, t4, t5, t6, t7, a2;
+    f28_sqr(a2, a);
+    f28_mul(t1, t0, a2); f28_mul(t2, t1, a2); f28_mul(t3, t2, a2); f28_mul(t4, t3, a2);
+    f28_mul(t5, t4, a2); f28_mul(t6, t5, a2); f28_mul(t7, t6, a2);
+#define F28_PICK(dst, idx)                                                                   \
+    do {                                                                                     \
+        switch (idx) {                                                                       \
+        case 0: dst = t0; break; case 1: dst = t1; break; case 2: dst = t2; break; case 3: dst = t3; break; \
+        case 4: dst = t4; break; case 5: dst = t5; break; case 6: dst = t6; break; default: dst = t7; break; \
+        }                                                                                    \
+    } while (0)
+    F28 acc, op;
+    F28_PICK(acc, FP_SQRT_CHAIN[0][1]);
+#pragma unroll 1
+    for (int k = 1; k < FP_SQRT_CHAIN_LEN; k++) {
+        const int nsq = FP_SQRT_CHAIN[k][0], idx = FP_SQRT_CHAIN[k][1];
+#pragma unroll 1
+        for (int q = 0; q < nsq; q++) f28_sqr_inl(acc, acc);
+        if (idx != 255) {
+            F28_PICK(op, idx);
+            f28_mul_inl(acc, acc, op);
+        }
+    }
+#undef F28_PICK
     r = acc;
 }

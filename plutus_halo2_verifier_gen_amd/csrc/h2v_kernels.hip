@@ -494,7 +494,7 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
             {
                 F28 c28, y28;
                 f28_from_fp(c28, c);
-                f28_pow_const<12>(y28, c28, FP_SQRT_EXP);
+                f28_sqrt_chain(y28, c28);
                 f28_to_fp(y, y28);
             }
             fp_sqr(chk, y);
