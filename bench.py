@@ -204,7 +204,7 @@ def main():
         mads = {
             "g1_msm": B * T * msm_lpt * msm_lane + B * (msm_lpt * T - 1) * MAD_ADD + B * 3 * MAD_MUL,
             "pairing": B * 32 * (35 * (6 * 196 + 196) + 63 * (4 * 196 + 196) + 315 * (2 * 196 + 196) + 136 * (3 * 196 + 196)),   # coop program: MUL / SQR / CSQR / LINE
-            "g1_decompress": B * slots * (380 * MAD_SQR + 190 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD + tab_point),
+            "g1_decompress": B * slots * (377 * MAD_SQR + 86 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD + tab_point),
             "transcript_combiner": B * sum(128 for ins in pl.instrs if ins[0] == PL.OP_MUL),
         }
 

@@ -408,8 +408,7 @@ static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint
     //    dispatcher only spreads one wave per SIMD for 64- and 256-thread blocks (128 / 192 / 320 / 384 / 448 / 512
     //    put two waves of a block on the same SIMD: 2.5 ms where 64 / 256 take 1.5 ms at 1024 waves).
     // cost = chain x (1 if every wave can sit alone, else 1.7 x whole rounds of two waves per SIMD: the waves of a
-    // launch all take the same time, so a partly filled round costs a full one); ties go to one-wave blocks, then to
-    // fewer idle lanes.
+    // launch all take the same time, so a partly filled round costs a full one).
     static const int env_lpt = []() { const char *e = getenv("H2V_MSM_LPT"); return e ? atoi(e) : 0; }();
     static const uint32_t env_bs = []() { const char *e = getenv("H2V_MSM_BS"); return e ? (uint32_t)atoi(e) : 0u; }();
     static const double n_simd = []() {
@@ -430,7 +429,10 @@ static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint
             const double chain = cl == 2 ? 1250.0 : 1600.0;
             const double rounds = rho > 2.0 ? (double)(uint64_t)((rho + 1.999) / 2.0) : 1.0;
             double cost = chain * ((spreads && rho <= 1.0) ? 1.0 : 1.7 * rounds);
-            cost *= 1.0 + (cand == 64 ? 0.0 : 0.01) + 0.005 * (double)(cand - pb * lpp_c) / cand;
+            // ties: 256-thread blocks first (four waves, one per SIMD of a CU whatever the dispatcher's state: after a
+            // launch of 128-thread blocks, 1024 one-wave blocks of this kernel measured 2.47 ms instead of 1.86, 256-thread
+            // blocks 1.87), then one-wave blocks, then fewer idle lanes
+            cost *= 1.0 + (cand == 256 ? 0.0 : cand == 64 ? 0.004 : 0.01) + 0.005 * (double)(cand - pb * lpp_c) / cand;
             if (cost < best) { best = cost; lpt = cl; bs = cand; }
         }
     }
