@@ -192,6 +192,15 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
     if (short_proof) st |= H2V_ST_SHORT_PROOF;
     // a short proof is rejected up front; its lane replays a zero-length-safe window (no out-of-bounds reads)
     const uint8_t *proof = proofs + off0;
+    // Pull the proof into the cache hierarchy up front: the proof's L lanes touch one byte per 64-byte line, all loads in
+    // flight together.  Without it every READ_SCALAR / READ_POINT of the lone wave waits out an HBM miss of its own
+    // (~11 k cycles per scalar read, 70 of them in the sha256 shape).  The bytes feed a value that is only stored under a
+    // condition that never holds, so the loads stay.
+    uint32_t warm = 0;
+    if (!short_proof) {
+#pragma unroll 1
+        for (uint32_t o = 64 * sub; o < plan.proof_len; o += 64 * L) warm += proof[o];
+    }
     Transcript tr;
     tr_init(tr);
     Fr a, b, r;
@@ -332,6 +341,7 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
         for (uint32_t k = 1; k < L; k++) st |= st_red[((uint32_t)lane & (P - 1)) + k * P];
     }
     if (live && sub == 0) {
+        if (warm == 0xffffffffu) st |= 0x80000000u;   // never true (at most 2^24 / 64 bytes of 255 are summed): keeps `warm` live
         status[i] = st;
         if (trace) {
             for (uint32_t k = 0; k < plan.n_trace; k++) {
