@@ -166,7 +166,7 @@ def main():
         lds_slots = 64
         while lds_slots >= 8 and pl.n_regs * 32 * lds_slots + 8192 + 1024 > 160 * 1024:
             lds_slots >>= 1
-        kname = {"g1_msm": "k_g1_msm_merged" if msm_lpt == 1 else "k_g1_msm", "g1_decompress": "k_g1_decompress",
+        kname = {"g1_msm": "k_g1_msm_fixed" if msm_lpt == 3 else "k_g1_msm_merged" if msm_lpt == 1 else "k_g1_msm", "g1_decompress": "k_g1_decompress",
                  "transcript_combiner": "k_transcript_combiner_lds" if lds_slots >= 8 else "k_transcript_combiner",
                  "pairing": "k_pairing_coop" if os.environ.get("H2V_PAIRING") != "legacy" else "k_pairing_check"}
 
@@ -198,11 +198,16 @@ def main():
         # analytical multiply-add counts per launch (lane-level v_mad_u64_u32), see DESIGN.md section 6
         # per MSM lane: 32 windows of 4 doublings + one mixed addition per GLV half the lane carries (tables are built
         # ahead); the launcher reports whether a term ran on two lanes (one half each) or on one (both halves)
+        n_fix_terms = sum(1 for kind, _ in pl.terms if kind == PL.TERM_VK_BASE)
+        msm_fixed = msm_lpt == 3   # fixed-base mode: VK-base terms cost 65 mixed additions and no doubling
+        if msm_fixed:
+            msm_lpt = 1
         msm_halves = 2 // msm_lpt
         msm_lane = 128 * MAD_DBL + (32 * msm_halves - 1) * MAD_MADD
         tab_point = 4 * MAD_DBL + 3 * MAD_ADD + 48 * MAD_MUL + 14 * MAD_SQR    # window tables of one point: [1..8]P, normalised, and x beta
         mads = {
-            "g1_msm": B * T * msm_lpt * msm_lane + B * (msm_lpt * T - 1) * MAD_ADD + B * 3 * MAD_MUL,
+            "g1_msm": (B * (T - n_fix_terms) * msm_lane + B * n_fix_terms * 65 * MAD_MADD + B * (T - 1) * MAD_ADD + B * 3 * MAD_MUL) if msm_fixed
+                      else B * T * msm_lpt * msm_lane + B * (msm_lpt * T - 1) * MAD_ADD + B * 3 * MAD_MUL,
             "pairing": B * 32 * (35 * (6 * 196 + 196) + 63 * (4 * 196 + 196) + 315 * (2 * 196 + 196) + 136 * (3 * 196 + 196)),   # coop program: MUL / SQR / CSQR / LINE
             "g1_decompress": B * slots * (377 * MAD_SQR + 86 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD + tab_point),
             "transcript_combiner": B * sum(128 for ins in pl.instrs if ins[0] == PL.OP_MUL),

@@ -62,7 +62,8 @@ typedef struct {
  * the SUM of that kernel's launch durations over the chunks, total_ms the span from the first launch to the last end.
  * g1_decompress_ms is the longer of the decompression kernel's two concurrent launches (square roots + window tables
  * on one stream, subgroup tests on another).  msm_lanes_per_term is the shape the MSM launcher chose for the call:
- * 2 = one lane per GLV half, 1 = both halves on one lane (shared doublings). */
+ * 2 = one lane per GLV half, 1 = both halves on one lane (shared doublings), 3 = ladders for the per-proof terms beside a
+ * fixed-base launch for the VK bases. */
 typedef struct {
     float transcript_combiner_ms, g1_decompress_ms, g1_msm_ms, pairing_ms, total_ms;
     uint32_t launches;

@@ -38,6 +38,8 @@ struct h2v_plan {
     void *blob = nullptr;      // one device allocation holding every section
     void *fold_terms = nullptr;  // recursion: the 4-entry term table of the two fold MSMs
     void *vk_tab = nullptr;      // window tables of the VK bases (k_vk_tables at load)
+    void *fix_tab = nullptr;     // all-window tables of the VK bases (k_vk_fixed_tables at load; non-recursive plans)
+    uint32_t n_var = 0, n_fix = 0;  // per-proof terms [0, n_var), VK-base terms [n_var, n_var + n_fix) when the list is so ordered
     uint32_t n_squeezes = 0, stream_len = 0;
     std::vector<uint32_t> trace_slots;
 };
@@ -50,6 +52,7 @@ struct h2v_workspace {
     // recursion (IVC): acc_left / acc_right_final sums, the fold's points + scalars, and the folded el / er
     uint32_t *accl = nullptr, *accr = nullptr, *fold_pts = nullptr, *fold_scal = nullptr, *el2 = nullptr, *er2 = nullptr;
     uint32_t *pt_tab = nullptr;  // MSM window tables of every per-proof point, written by the decompression kernel
+    uint32_t *er_fix = nullptr;  // sum of the VK-base terms when the MSM is split into a ladder and a fixed-base launch
     uint8_t *valid = nullptr, *valid_sub = nullptr, *accept = nullptr;
     // staging for the host-buffer entry point
     uint8_t *in_proofs = nullptr, *in_inst = nullptr, *in_ci = nullptr;
@@ -59,7 +62,7 @@ struct h2v_workspace {
     // chunk's decompression / transcript kernels (few waves) overlap another chunk's MSM / pairing kernels.
     static constexpr int MAXP = 4;
     hipStream_t pmain[MAXP] = {}, pside[MAXP] = {}, psub[MAXP] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[MAXP] = {}, ev_sub[MAXP] = {}, ev_done[MAXP] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAXP] = {}, ev_sub[MAXP] = {}, ev_fix[MAXP] = {}, ev_done[MAXP] = {};
     // ring of per-call, per-chunk event sets: [0]/[1] around the transcript+combiner kernel, [2]/[3] around the
     // decompression kernel's square-root half (side stream), [4]/[5] around the MSM, [5]/[6] around the pairing kernel,
     // [7]/[8] around the decompression kernel's subgroup half (third stream)
@@ -271,6 +274,31 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
         }
     }
     d.vk_tab = (const uint32_t *)p->vk_tab;
+    // fixed-base launches of the MSM (non-recursive plans whose VK-base terms are the tail of the term list, as plan.py
+    // orders them): every window multiple of every VK base
+    if (!ivc && n_bases) {
+        uint32_t nv = 0;
+        while (nv < n_terms && rd32(patched.data() + w[H2V_HW_OFF_TERMS] + 8 * nv) != H2V_TERM_VK_BASE) nv++;
+        bool tail_ok = nv < n_terms;
+        for (uint32_t k = nv; k < n_terms; k++) tail_ok = tail_ok && rd32(patched.data() + w[H2V_HW_OFF_TERMS] + 8 * k) == H2V_TERM_VK_BASE;
+        if (tail_ok) {
+            const size_t fix_bytes = (size_t)n_bases * 65 * 224 * 4;
+            bool okf = hipMalloc(&p->fix_tab, fix_bytes + 16) == hipSuccess && hipMemset(p->fix_tab, 0, fix_bytes + 16) == hipSuccess;
+            if (okf) {
+                hipLaunchKernelGGL(k_vk_fixed_tables, dim3((n_bases * 65 + 63) / 64), dim3(64), 0, nullptr, d.vk_bases, n_bases, (uint32_t *)p->fix_tab);
+                okf = hipDeviceSynchronize() == hipSuccess;
+            }
+            if (!okf) {
+                if (p->fix_tab) (void)hipFree(p->fix_tab);
+                (void)hipFree(p->vk_tab);
+                (void)hipFree(p->blob); delete p;
+                return fail(H2V_E_DEVICE, "fixed-base table setup failed");
+            }
+            p->n_var = nv;
+            p->n_fix = n_terms - nv;
+        }
+    }
+    d.fix_tab = (const uint32_t *)p->fix_tab; d.n_var = p->n_var; d.n_fix = p->n_fix;
     p->n_squeezes = n_sq;
     p->stream_len = w[H2V_HW_STREAM_LEN];
     for (uint32_t k = 0; k < n_trace; k++) p->trace_slots.push_back(rd32(trp + 8 * k));
@@ -283,6 +311,7 @@ extern "C" void h2v_plan_free(h2v_plan *p) {
     if (p->blob) (void)hipFree(p->blob);
     if (p->fold_terms) (void)hipFree(p->fold_terms);
     if (p->vk_tab) (void)hipFree(p->vk_tab);
+    if (p->fix_tab) (void)hipFree(p->fix_tab);
     delete p;
 }
 extern "C" int h2v_plan_info(const h2v_plan *p, uint32_t *proof_len, uint32_t *n_pi, uint32_t *n_ci, uint32_t *n_terms) {
@@ -303,13 +332,14 @@ extern "C" int h2v_plan_trace_slots(const h2v_plan *p, uint32_t *slot_ids, uint3
 // ---------------------------------------------------------------------------------------------- workspace
 static void ws_release(h2v_workspace *w) {
     (void)hipSetDevice(w->device);
-    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off, w->msm_tab,
+    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->er_fix, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off, w->msm_tab,
                     w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2, w->pt_tab};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipStream_t q : w->pmain) if (q) (void)hipStreamDestroy(q);
     for (hipStream_t q : w->pside) if (q) (void)hipStreamDestroy(q);
     for (hipStream_t q : w->psub) if (q) (void)hipStreamDestroy(q);
     for (hipEvent_t e : w->ev_sub) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : w->ev_fix) if (e) (void)hipEventDestroy(e);
     if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
     for (hipEvent_t e : w->ev_join) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : w->ev_done) if (e) (void)hipEventDestroy(e);
@@ -331,6 +361,7 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     WSALLOC(pts, (size_t)max_batch * slots * 96)
     WSALLOC(valid, (size_t)max_batch * slots)
     WSALLOC(valid_sub, (size_t)max_batch * slots)
+    if (d.fix_tab) { WSALLOC(er_fix, (size_t)max_batch * 36 * 4) }
     WSALLOC(er, (size_t)max_batch * 144)
     WSALLOC(pt_tab, (size_t)max_batch * slots * 448 * 4)             // per (proof, slot): [1..8]P and [1..8]phi(P), affine, 2 x 14 x 28-bit limbs
     if (d.ivc) { WSALLOC(msm_tab, (size_t)max_batch * 4 * 2 * 8 * 112) }  // fold MSMs build their four tables on the spot
@@ -349,7 +380,7 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     bool ok = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < h2v_workspace::MAXP && ok; k++)
         ok = hipStreamCreateWithFlags(&w->pmain[k], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&w->pside[k], hipStreamNonBlocking) == hipSuccess &&
-             hipStreamCreateWithFlags(&w->psub[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&w->ev_sub[k], hipEventDisableTiming) == hipSuccess &&
+             hipStreamCreateWithFlags(&w->psub[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&w->ev_sub[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->ev_fix[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&w->ev_join[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->ev_done[k], hipEventDisableTiming) == hipSuccess;
     for (auto &call : w->ring) for (auto &set : call) for (hipEvent_t &e : set)
         if (ok) ok = hipEventCreate(&e) == hipSuccess;
@@ -399,57 +430,99 @@ static int launch_vm(const H2vDevPlan &d0, uint32_t n, uint32_t stride, const ui
 }
 
 // MSM launch geometry: 2 lanes per (proof, term); LDS 172 B per thread (42 limbs + the infinity flag).
-static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const uint32_t *scalars, const uint32_t *pts,
-                                 uint32_t *tabws, hipStream_t st) {
-    // Launch shape from a cost model fitted to MI355X measurements:
-    //  * lanes per term: 2 = one lane per GLV half, chain of ~1250 multiplications; 1 = both halves on one accumulator,
-    //    chain ~1600 but 36 % less work per proof and half the waves;
-    //  * a wave alone on its SIMD runs ~1.7x faster than two sharing one (2048 proofs: 1.50 ms, 4096: 2.6 ms), and the
-    //    dispatcher only spreads one wave per SIMD for 64- and 256-thread blocks (128 / 192 / 320 / 384 / 448 / 512
-    //    put two waves of a block on the same SIMD: 2.5 ms where 64 / 256 take 1.5 ms at 1024 waves).
-    // cost = chain x (1 if every wave can sit alone, else 1.7 x whole rounds of two waves per SIMD: the waves of a
-    // launch all take the same time, so a partly filled round costs a full one).
-    static const int env_lpt = []() { const char *e = getenv("H2V_MSM_LPT"); return e ? atoi(e) : 0; }();
-    static const uint32_t env_bs = []() { const char *e = getenv("H2V_MSM_BS"); return e ? (uint32_t)atoi(e) : 0u; }();
-    static const double n_simd = []() {
+// MSM launch shape from a cost model fitted to MI355X measurements:
+//  * lanes per term: 2 = one lane per GLV half, chain of ~1250 multiplications; 1 = both halves on one accumulator,
+//    chain ~1600 but 36 % less work per proof and half the waves;
+//  * a wave alone on its SIMD runs ~1.7x faster than two sharing one (2048 proofs: 1.50 ms, 4096: 2.6 ms), and the
+//    dispatcher only spreads one wave per SIMD for 64- and 256-thread blocks (128 / 192 / 320 / 384 / 448 / 512
+//    put two waves of a block on the same SIMD: 2.5 ms where 64 / 256 take 1.5 ms at 1024 waves).
+// cost = chain x (1 if every wave can sit alone, else 1.7 x whole rounds of two waves per SIMD: the waves of a
+// launch all take the same time, so a partly filled round costs a full one).
+static double msm_n_simd() {
+    static const double v = []() {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         return 4.0 * cus;
     }();
-    uint32_t lpt = 2, bs = 64;
-    double best = 1e300;
+    return v;
+}
+struct MsmShape { uint32_t lpt, bs; double cost, waves; };
+// lanes_per_proof lanes of chain length `chain` per proof; other_waves: waves of a launch running beside this one
+static void msm_try_shape(MsmShape &best, uint32_t lpt, uint32_t lpp, double chain, uint32_t n, double other_waves, uint32_t force_bs) {
+    for (uint32_t cand = 64; cand <= 512; cand += 64) {
+        if (cand < lpp || (force_bs && cand != force_bs)) continue;
+        const uint32_t pb = cand / lpp;
+        const double waves = (double)((n + pb - 1) / pb) * (cand / 64), rho = (waves + other_waves) / msm_n_simd();
+        const bool spreads = cand == 64 || cand == 256;
+        const double rounds = rho > 2.0 ? (double)(uint64_t)((rho + 1.999) / 2.0) : 1.0;
+        double cost = chain * ((spreads && rho <= 1.0) ? 1.0 : 1.7 * rounds);
+        // ties: 256-thread blocks first (four waves, one per SIMD of a CU whatever the dispatcher's state: after a
+        // launch of 128-thread blocks, 1024 one-wave blocks of this kernel measured 2.47 ms instead of 1.86, 256-thread
+        // blocks 1.87), then one-wave blocks, then fewer idle lanes
+        cost *= 1.0 + (cand == 256 ? 0.0 : cand == 64 ? 0.004 : 0.01) + 0.005 * (double)(cand - pb * lpp) / cand;
+        if (cost < best.cost) { best.cost = cost; best.lpt = lpt; best.bs = cand; best.waves = waves; }
+    }
+}
+static MsmShape msm_ladder_shape(uint32_t n_terms, uint32_t n, double other_waves) {
+    static const int env_lpt = []() { const char *e = getenv("H2V_MSM_LPT"); return e ? atoi(e) : 0; }();
+    static const uint32_t env_bs = []() { const char *e = getenv("H2V_MSM_BS"); return e ? (uint32_t)atoi(e) : 0u; }();
+    MsmShape best = {2, 512, 1e300, 0};
     for (uint32_t cl = 2; cl >= 1; cl--) {
         if (env_lpt && (uint32_t)env_lpt != cl) continue;
-        const uint32_t lpp_c = cl * ma.n_terms;
-        for (uint32_t cand = 64; cand <= 512; cand += 64) {
-            if (cand < lpp_c || (env_bs && cand != env_bs)) continue;
-            const uint32_t pb = cand / lpp_c;
-            const double waves = (double)((n + pb - 1) / pb) * (cand / 64), rho = waves / n_simd;
-            const bool spreads = cand == 64 || cand == 256;
-            const double chain = cl == 2 ? 1250.0 : 1600.0;
-            const double rounds = rho > 2.0 ? (double)(uint64_t)((rho + 1.999) / 2.0) : 1.0;
-            double cost = chain * ((spreads && rho <= 1.0) ? 1.0 : 1.7 * rounds);
-            // ties: 256-thread blocks first (four waves, one per SIMD of a CU whatever the dispatcher's state: after a
-            // launch of 128-thread blocks, 1024 one-wave blocks of this kernel measured 2.47 ms instead of 1.86, 256-thread
-            // blocks 1.87), then one-wave blocks, then fewer idle lanes
-            cost *= 1.0 + (cand == 256 ? 0.0 : cand == 64 ? 0.004 : 0.01) + 0.005 * (double)(cand - pb * lpp_c) / cand;
-            if (cost < best) { best = cost; lpt = cl; bs = cand; }
-        }
+        msm_try_shape(best, cl, cl * n_terms, cl == 2 ? 1250.0 : 1600.0, n, other_waves, env_bs);
     }
-    if (best == 1e300) { lpt = 2; bs = 512; }   // forced shape that does not fit: fall back to the widest block
-    const uint32_t lpp = lpt * ma.n_terms;
-    const uint32_t per_block = bs / lpp;
+    if (best.cost == 1e300) {   // forced shape that does not fit: fall back to the widest block
+        const uint32_t pb = 512 / (2 * n_terms) ? 512 / (2 * n_terms) : 1;
+        best.lpt = 2; best.bs = 512; best.waves = (double)((n + pb - 1) / pb) * 8;
+    }
+    return best;
+}
+static uint32_t launch_msm_ladders(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const MsmShape &sh, const uint32_t *scalars,
+                                   const uint32_t *pts, uint32_t *tabws, hipStream_t st) {
+    const uint32_t lpp = sh.lpt * ma.n_terms;
+    const uint32_t per_block = sh.bs / lpp;
     const uint32_t blocks = (n + per_block - 1) / per_block;
-    if (lpt == 1) hipLaunchKernelGGL(k_g1_msm_merged, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
-    else hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
-    return lpt;
+    if (sh.lpt == 1) hipLaunchKernelGGL(k_g1_msm_merged, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+    else hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+    return sh.lpt;
+}
+static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const uint32_t *scalars, const uint32_t *pts,
+                                 uint32_t *tabws, hipStream_t st) {
+    return launch_msm_ladders(d, ma, n, msm_ladder_shape(ma.n_terms, n, 0.0), scalars, pts, tabws, st);
+}
+// Fixed-base split of the plan's own MSM (non-recursive plans, tables present): the per-proof terms [0, n_var) as ladders
+// and, beside them on another stream, the VK-base terms as one lane per term that walks the all-window table of its base
+// (65 mixed additions, no doubling: 0.88 ms alone).  Measured (2048 proofs): T = 50 with 30 VK bases 3.37 -> 2.52 ms,
+// T = 34 with 9 VK bases 3.42 -> 2.68 ms; but where the single launch already has every SIMD to itself the split is
+// slower (simple_mul x 4096: 1.87 -> 2.50 ms, sha256 shape x 1024: 1.99 -> 2.56 ms) - waves of two concurrent launches
+// pair up on SIMDs even when there would be room for all of them alone.  So the rule is: split (one base per lane) only
+// when the single launch cannot have one wave per SIMD and most terms are VK bases.  H2V_MSM_FIX = k forces a split with k bases per lane, 0 forbids it.
+struct MsmSplit { bool on; MsmShape var, fix; uint32_t k; };
+static MsmSplit msm_split_shape(const H2vDevPlan &d, uint32_t n, const MsmShape &single) {
+    static const int env_fix = []() { const char *e = getenv("H2V_MSM_FIX"); return e ? atoi(e) : -1; }();
+    static const uint32_t env_bs = []() { const char *e = getenv("H2V_MSM_BS"); return e ? (uint32_t)atoi(e) : 0u; }();
+    MsmSplit out = {false, {}, {}, 0};
+    if (!d.fix_tab || !d.n_fix || !d.n_var || d.ivc || env_fix == 0) return out;
+    // (and only when the VK bases are the majority of the terms: with 9 of 34 the MSM gained 0.8 ms and the pairing kernel
+    // that followed the three launches lost as much of its own placement; with 6 of 16 at 8192 proofs the split was slower)
+    if (env_fix < 0 && (single.waves <= msm_n_simd() || d.n_fix < d.n_var)) return out;
+    const uint32_t k = env_fix > 0 ? (uint32_t)(env_fix > 4 ? 4 : env_fix) : 1u;
+    const uint32_t lanes = (d.n_fix + k - 1) / k;
+    MsmShape fx = {1, 512, 1e300, 0};
+    msm_try_shape(fx, 1, lanes, k * 800.0, n, 0.0, env_bs);
+    if (fx.cost == 1e300) return out;
+    out.on = true;
+    out.k = k;
+    out.fix = fx;
+    out.var = msm_ladder_shape(d.n_var, n, fx.waves);
+    return out;
 }
 // the proof's own MSM: terms [0, n_main_terms) of the plan's table, scalars from the combiner, points from decompression.
 // A recursive plan sums acc_left and acc_right + fixed bases in the same launch (three groups, three outputs).
 static uint32_t launch_msm(const H2vDevPlan &d, uint32_t n, const uint32_t *scalars, const uint32_t *pts, const uint32_t *pt_tab,
                        uint32_t *er, uint32_t *accl, uint32_t *accr, hipStream_t st) {
     H2vMsmArgs ma = {d.terms, 0, d.n_main_terms, d.n_terms, 0, H2V_SLOTS(d), {d.n_main_terms, d.n_main_terms, d.n_main_terms}, {er, nullptr, nullptr},
-                     pt_tab, d.vk_tab};
+                     pt_tab, d.vk_tab, nullptr, 0, 0};
     if (d.ivc) {
         ma.n_terms = d.n_terms;
         ma.grp_end[0] = d.n_main_terms; ma.grp_end[1] = d.n_main_terms + 1; ma.grp_end[2] = d.n_terms;
@@ -464,7 +537,7 @@ struct IvcBufs { uint32_t *accl, *accr, *fold_pts, *fold_scal, *el2, *er2; };
 static void launch_ivc_fold(const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint32_t *er,
                             const IvcBufs &b, uint32_t *tabws, hipStream_t st) {
     hipLaunchKernelGGL(k_ivc_challenge, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, er, b.accl, b.accr, b.fold_pts, b.fold_scal);
-    const H2vMsmArgs fold = {d.fold_terms, 0, 4, 4, 0, 4, {2, 4, 4}, {b.el2, b.er2, nullptr}, nullptr, nullptr};
+    const H2vMsmArgs fold = {d.fold_terms, 0, 4, 4, 0, 4, {2, 4, 4}, {b.el2, b.er2, nullptr}, nullptr, nullptr, nullptr, 0, 0};
     launch_msm_range(d, fold, n, b.fold_scal, b.fold_pts, tabws, st);
 }
 // Pairing kernel selection: the cooperative 16-lanes-per-proof kernel is the product path; the one-lane-per-proof
@@ -583,7 +656,27 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         const IvcBufs ib = {d.ivc ? w->accl + (size_t)lo * 36 : nullptr, d.ivc ? w->accr + (size_t)lo * 36 : nullptr,
                             d.ivc ? w->fold_pts + (size_t)lo * 96 : nullptr, d.ivc ? w->fold_scal + (size_t)lo * 32 : nullptr,
                             d.ivc ? w->el2 + (size_t)lo * 36 : nullptr, d.ivc ? w->er2 + (size_t)lo * 36 : nullptr};
-        w->ring_lpt[slot] = (uint8_t)launch_msm(d, m, scal_k, pts_k, pt_tab_k, er_k, ib.accl, ib.accr, pm);
+        const MsmShape single = msm_ladder_shape(d.ivc ? d.n_terms : d.n_main_terms, m, 0.0);
+        const MsmSplit split = w->er_fix ? msm_split_shape(d, m, single) : MsmSplit{false, {}, {}, 0};
+        if (split.on) {
+            // per-proof terms as ladders on the main stream; the VK-base terms beside them on the side stream (free since
+            // the square roots finished), which first waits for the combiner's scalars; a one-lane-per-proof kernel adds
+            // the two sums
+            uint32_t *erf_k = w->er_fix + (size_t)lo * 36;
+            H2vMsmArgs mv = {d.terms, 0, d.n_var, d.n_terms, 0, slots, {d.n_var, d.n_var, d.n_var}, {er_k, nullptr, nullptr}, pt_tab_k, d.vk_tab, nullptr, 0, 0};
+            H2vMsmArgs mf = {d.terms, d.n_var, d.n_fix, d.n_terms, d.n_var, slots, {d.n_fix, d.n_fix, d.n_fix}, {erf_k, nullptr, nullptr}, pt_tab_k, d.vk_tab,
+                             d.fix_tab, split.k, (d.n_fix + split.k - 1) / split.k};
+            HIPCHK(hipStreamWaitEvent(ps, ev[1], 0));
+            const uint32_t pbf = split.fix.bs / mf.n_fixl;
+            hipLaunchKernelGGL(k_g1_msm_fixed, dim3((m + pbf - 1) / pbf), dim3(split.fix.bs), (size_t)split.fix.bs * 172, ps, d, mf, m, pbf, scal_k, pts_k, (uint32_t *)nullptr);
+            HIPCHK(hipEventRecord(w->ev_fix[k], ps));
+            (void)launch_msm_ladders(d, mv, m, split.var, scal_k, pts_k, nullptr, pm);
+            HIPCHK(hipStreamWaitEvent(pm, w->ev_fix[k], 0));
+            hipLaunchKernelGGL(k_g1_sum_pairs, dim3((m + 63) / 64), dim3(64), 0, pm, m, er_k, erf_k);
+            w->ring_lpt[slot] = 3;
+        } else {
+            w->ring_lpt[slot] = (uint8_t)launch_msm(d, m, scal_k, pts_k, pt_tab_k, er_k, ib.accl, ib.accr, pm);
+        }
         const uint32_t *er_in = er_k, *el_in = nullptr;
         if (d.ivc) {   // (timed with the MSM: the challenge hash and one more pass of the same kernel)
             launch_ivc_fold(d, m, pts_k, er_k, ib, tab_k, pm);

@@ -569,6 +569,10 @@ struct H2vMsmArgs {
     // decompression kernel, VK bases at plan load.  NULL: every lane builds its own table into `tabws` (fold MSMs).
     const uint32_t *pt_tab;    // [proof][slot][2][224]
     const uint32_t *vk_tab;    // [base][2][224]
+    // fixed-base launches (k_g1_msm_fixed; one group, every term of the range a VK base): lane f of a proof's n_fixl
+    // lanes sums the fix_k terms f * fix_k ... of the range from the all-window tables fix_tab [base][65 windows][8][28]
+    const uint32_t *fix_tab;
+    uint32_t fix_k, n_fixl;
 };
 // A proof owns exactly LPT * n_terms consecutive lanes of a block (no power-of-two padding: 34 terms used to occupy
 // 128 lanes); the block holds as many whole proofs as fit, the rest of its lanes idle.
@@ -578,27 +582,88 @@ struct H2vMsmArgs {
 // additions per lane, 36 % less work per proof, half the waves).  Measured on MI355X one wave per SIMD of this code
 // already reaches 85 % of what two deliver (2048 proofs: 1.54 ms, 4096: 2.60 ms with LPT = 2), so whenever the batch
 // still fills the SIMDs with one lane per term the smaller total wins; the launcher picks (h2v_capi.hip).
-template <int LPT>
+// FIX (with LPT = 1): a fixed-base launch over a range of VK-base terms.  The VK bases are the same for every proof, so
+// ALL their window multiples [d] 16^w V (w = 0..64, d = 1..8) are precomputed at plan load and a VK term costs 65 mixed
+// additions and no doubling; a lane sums fix_k of them (one accumulator per base - additions inside one base's sum
+// cannot be exceptional, see below - merged with complete additions).  It runs beside the ladder launch of the
+// per-proof terms (separate waves: one wave mixing the two kinds would execute them one after the other) and leaves
+// fewer lanes per proof: for T >= 34 at 2048 proofs that brings the MSM back to one wave per SIMD.
+template <int LPT, bool FIX = false>
 H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, uint32_t per_block,
                      const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws,
                      uint32_t *red /* Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t] */) {
+    static_assert(!FIX || LPT == 1, "fixed-base mode runs merged ladders");
     constexpr int NH = 2 / LPT;   // GLV halves per lane
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
-    const uint32_t lanes_per_proof = LPT * ma.n_terms;
+    const uint32_t lanes_per_proof = FIX ? ma.n_fixl : LPT * ma.n_terms;
     const uint32_t seg = tid / lanes_per_proof;       // which of the block's proofs
     const uint32_t sub = tid - seg * lanes_per_proof; // position inside the proof's segment
-    const uint32_t term = LPT == 2 ? sub >> 1 : sub, half = LPT == 2 ? sub & 1 : 0;
+    const bool fix_lane = FIX;   // a fixed-base launch has no ladder lanes (a wave mixing the two kinds would run them one after the other)
+    const uint32_t term = FIX ? 0u : (LPT == 2 ? sub >> 1 : sub), half = LPT == 2 ? sub & 1 : 0;
     const uint32_t i = blockIdx.x * per_block + seg;
     const bool active = seg < per_block && i < n;
     // this lane's group: position and length of its reduction segment inside the proof's lanes
-    const uint32_t grp = term < ma.grp_end[0] ? 0u : (term < ma.grp_end[1] ? 1u : 2u);
+    const uint32_t grp = FIX ? 0u : (term < ma.grp_end[0] ? 0u : (term < ma.grp_end[1] ? 1u : 2u));
     const uint32_t g_lo = grp == 0 ? 0u : ma.grp_end[grp - 1];
-    const uint32_t gsub = sub - LPT * g_lo, glen = LPT * (ma.grp_end[grp] - g_lo);
+    const uint32_t gsub = FIX ? sub : sub - LPT * g_lo, glen = FIX ? lanes_per_proof : LPT * (ma.grp_end[grp] - g_lo);
     // this lane's partial sum, on the lazily reduced field with an explicit infinity flag (h2v_curve28.cuh); idle
     // lanes and skipped terms contribute the point at infinity
     G1J28 lad;
     bool lad_inf = true;
-    if (active) {
+    if (FIX && active && fix_lane) {
+        // The accumulator of one base is [a]V with a = the signed-digit prefix read so far (most significant window first),
+        // a multiple of 16^(w+1); adding [d 16^w]V is exceptional iff a -+ d 16^w = 0 mod r.  As integers |a -+ d 16^w| <
+        // 2^257, so that means a -+ d 16^w in {0, +-r, +-2r}: 0 is excluded by the digits' size unless a = d = 0, and
+        // r, 2r are not = -+d 16^w modulo 16^(w+1) except for w = 0, where a + d_0 would be the whole scalar = r or 2r,
+        // not a canonical one.  So the 65 additions of a base are unchecked; sums of different bases meet in complete ones.
+        const uint32_t f0 = sub * ma.fix_k;
+#pragma unroll 1
+        for (uint32_t j = 0; j < ma.fix_k; j++) {
+            if (f0 + j >= ma.n_terms) break;
+            const uint32_t ft = f0 + j;
+            const uint32_t idx = ma.terms[2 * (ma.term_base + ft) + 1];
+            const uint32_t *bp = plan.vk_bases + (size_t)idx * 24;
+            uint32_t any_b = 0, sc[8], any_s = 0;
+#pragma unroll
+            for (int k = 0; k < 24; k++) any_b |= bp[k];
+            const uint32_t *sp = scalars + ((size_t)i * ma.scal_stride + ma.scal_col_base + ft) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { sc[k] = sp[k]; any_s |= sc[k]; }
+            if (any_b == 0 || any_s == 0) continue;
+            int8_t dg[65];
+            uint32_t carry = 0;
+#pragma unroll 1
+            for (int q = 0; q < 64; q++) {
+                uint32_t d = ((sc[q >> 3] >> (4 * (q & 7))) & 15u) + carry;
+                carry = d > 8 ? 1u : 0u;
+                dg[q] = (int8_t)(carry ? (int)d - 16 : (int)d);
+            }
+            dg[64] = (int8_t)carry;
+            G1J28 acc;
+            bool acc_inf = true;
+            const uint32_t *tabb = ma.fix_tab + (size_t)idx * 65 * 224;
+#pragma unroll 1
+            for (int q = 64; q >= 0; q--) {
+                const int d = dg[q];
+                if (d == 0) continue;
+                const uint32_t *ent = tabb + q * 224 + ((d < 0 ? -d : d) - 1) * 28;
+                F28 qx, qy;
+#pragma unroll
+                for (int k = 0; k < 14; k++) { qx.l[k] = ent[k]; qy.l[k] = ent[14 + k]; }
+                if (acc_inf) {
+                    acc.x = qx;
+                    acc.y = qy;
+                    if (d < 0) { F28_NEG(acc.y, qy, 3, 1); f28_carry(acc.y); }
+                    f28_set_one(acc.z);
+                    acc_inf = false;
+                } else {
+                    g1j28_madd_ladder(acc, acc, qx, qy, d < 0);
+                }
+            }
+            if (!acc_inf) g1j28_acc_add(lad, lad_inf, acc, false);   // complete
+        }
+    }
+    if (active && !fix_lane) {
         // terms[] as uploaded by h2v_plan_load: kind is VK base (1) or per-proof slot (0); the committed instance has
         // been rewritten to slot n_points there.  Two-way integer selects only: a nested three-way pointer select was
         // miscompiled by ROCm 7.2 (the copy of i feeding the scalar address was left undefined on the third path).
@@ -760,6 +825,29 @@ k_g1_msm_merged(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /
                 const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];
     msm_body<1>(plan, ma, n, per_block, scalars, pts, tabws, red);
+}
+
+extern "C" __global__ void __launch_bounds__(512, 2)
+k_g1_msm_fixed(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
+               const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
+    extern __shared__ uint32_t red[];
+    msm_body<1, true>(plan, ma, n, per_block, scalars, pts, tabws, red);
+}
+
+// er += er_fix (complete Jacobian addition, one lane per proof): joins the two launches of a split MSM
+extern "C" __global__ void __launch_bounds__(64)
+k_g1_sum_pairs(uint32_t n, uint32_t *__restrict__ er, const uint32_t *__restrict__ er_fix) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1J a, b, r;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        a.x.v[k] = er[(size_t)i * 36 + k]; a.y.v[k] = er[(size_t)i * 36 + 12 + k]; a.z.v[k] = er[(size_t)i * 36 + 24 + k];
+        b.x.v[k] = er_fix[(size_t)i * 36 + k]; b.y.v[k] = er_fix[(size_t)i * 36 + 12 + k]; b.z.v[k] = er_fix[(size_t)i * 36 + 24 + k];
+    }
+    g1j_add(r, a, b);
+#pragma unroll
+    for (int k = 0; k < 12; k++) { er[(size_t)i * 36 + k] = r.x.v[k]; er[(size_t)i * 36 + 12 + k] = r.y.v[k]; er[(size_t)i * 36 + 24 + k] = r.z.v[k]; }
 }
 
 // ============================================================================ K5: pairing check
@@ -974,6 +1062,28 @@ k_vk_tables(const uint32_t *__restrict__ vk_bases, uint32_t n, uint32_t *__restr
     for (int k = 0; k < 12; k++) { base.x.v[k] = vk_bases[(size_t)b * 24 + k]; base.y.v[k] = vk_bases[(size_t)b * 24 + 12 + k]; }
     if (g1a_is_inf(base)) return;   // the MSM skips an infinite base before it looks at the table
     g1_build_window_tables_glv(vk_tab + (size_t)b * 448, base);
+}
+
+// all-window tables of the VK bases for the fixed-base MSM lanes: thread (b, w) writes [1..8] (16^w V_b), affine, at
+// fix_tab[(b * 65 + w) * 224 ...] (w = 64 serves the carry digit of the recoding)
+extern "C" __global__ void __launch_bounds__(64)
+k_vk_fixed_tables(const uint32_t *__restrict__ vk_bases, uint32_t n, uint32_t *__restrict__ fix_tab) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = t / 65, w = t - b * 65;
+    if (b >= n) return;
+    G1A base;
+#pragma unroll
+    for (int k = 0; k < 12; k++) { base.x.v[k] = vk_bases[(size_t)b * 24 + k]; base.y.v[k] = vk_bases[(size_t)b * 24 + 12 + k]; }
+    if (g1a_is_inf(base)) return;
+    G1J28 p;
+    g1j28_from_affine(p, base);
+#pragma unroll 1
+    for (uint32_t q = 0; q < 4 * w; q++) g1j28_dbl_ool(p, p);   // a point of prime order: never infinity
+    G1J pj;
+    g1j28_to_g1j(pj, p, false);
+    G1A aff;
+    g1j_to_affine(aff, pj);
+    g1_build_window_table(fix_tab + ((size_t)b * 65 + w) * 224, aff);
 }
 
 // ============================================================================ primitive probes (parity tests)

@@ -75,6 +75,10 @@ struct H2vDevPlan {
     uint32_t acc_idx[8];
     const uint32_t *fold_terms;  // 4 x (kind, index): el + c*acc_left, er + c*acc_right over the fold's own point buffer
     const uint32_t *vk_tab;      // n_vk_bases x 2 x 224: affine window tables [1..8]B and [1..8]phi(B), built at plan load
+    // fixed-base MSM launches (non-recursive plans whose VK-base terms are the tail of the term list): all-window tables of
+    // the VK bases [base][65][8][28]; terms [0, n_var) are per-proof points, [n_var, n_var + n_fix) VK bases
+    const uint32_t *fix_tab;
+    uint32_t n_var, n_fix;
     // optional wide schedule of the program (0 lanes = none); host-side use only (launch_vm swaps it in)
     uint32_t wide_lanes, wide_n_regs, wide_n_instr;
     const H2vInstr *wide_instr;

@@ -694,6 +694,13 @@ def compile_plan(vk: VerifyingKey, lanes: Optional[int] = None) -> Plan:
     add_term(TERM_VK_BASE, vk_base(("neg_g1", 0), bls.g1_neg(bls.G1_GEN)), v, "neg_g1_generator")
     add_term(TERM_PROOF_POINT, pi_pt, x3, "pi")
 
+    # per-proof terms first, VK-base terms last (a stable partition; the sum does not care): the backend can then run the
+    # two kinds as two contiguous ranges - merged ladders for the first, all-window fixed-base tables for the second
+    order = sorted(range(len(terms)), key=lambda t: terms[t][0] == TERM_VK_BASE)
+    terms[:] = [terms[t] for t in order]
+    term_scalar[:] = [term_scalar[t] for t in order]
+    term_names[:] = [term_names[t] for t in order]
+
     # ---- recursion: accumulator terms + verifying-key hash check (ivc.py; emitters/aiken.rs:648-757)
     n_main_terms = len(terms)
     acc_coords = None

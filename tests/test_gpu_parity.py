@@ -390,19 +390,20 @@ def test_circuit_without_public_inputs(be):
 
 
 @pytest.mark.parametrize("env", [{"H2V_PIPES": "3"}, {"H2V_PAIRING": "legacy"}, {"H2V_DEBUG_SYNC": "1"},
-                                 {"H2V_MSM_LPT": "1"}, {"H2V_MSM_LPT": "2", "H2V_MSM_BS": "256"}, {"H2V_SPLIT_DEC": "0"}])
+                                 {"H2V_MSM_LPT": "1"}, {"H2V_MSM_LPT": "2", "H2V_MSM_BS": "256"}, {"H2V_SPLIT_DEC": "0"},
+                                 {"H2V_MSM_FIX": "1"}, {"H2V_MSM_FIX": "3"}, {"H2V_VM_WIDE": "1"}, {"H2V_VM_WIDE": "0"}])
 def test_alternate_pipeline_modes(be, env, tmp_path):
     """The knobs of the pipeline (chunked sub-batches on several streams, the one-lane pairing kernel, the serialised
-    debug path, the MSM launch shape - one or two lanes per term, block size - that the cost model would otherwise
-    pick from the batch size, the unsplit decompression kernel) are read once per process, so each runs in a child
-    process; same verdicts."""
+    debug path, the MSM launch shape - one or two lanes per term, block size, fixed-base lanes for the VK bases - that the
+    cost model would otherwise pick from the batch size, the unsplit decompression kernel, the narrow / wide schedule of
+    the combiner) are read once per process, so each runs in a child process; same verdicts."""
     import os
     import subprocess
     import sys
     script = (
         "import sys; sys.path.insert(0, %r)\n"
         "from plutus_halo2_verifier_gen_amd import backend, plan as PL, synth, vk as V\n"
-        "for name in ('simple_mul', 'ivc'):\n"
+        "for name in ('simple_mul', 'ivc', 'lookup_table'):\n"
         "    vk, td = V.BUILDERS[name]()\n"
         "    pl = PL.compile_plan(vk)\n"
         "    b = synth.forge_batch(vk, td, 150, seed=4, plan=pl, workers=1)\n"
