@@ -101,32 +101,40 @@ H2V_DI int g1j28_add(G1J28 &r, const G1J28 &p, const G1J28 &q, const bool neg_q)
 // a = 16 * (a non-zero prefix of a scalar below 2^128), q = [d]P with 1 <= d <= 8, and P of prime order r > 2^254, so
 // a +- d is never 0 mod r - and nowhere else is this function used.
 // In: p with the stored-point bounds.  Out: X (10,1) Y (5,1) Z (2,1).
-H2V_DI void g1j28_madd_ladder(G1J28 &r, const G1J28 &p, const F28 &qx, const F28 &qy_in, const bool neg_q) {
+#define F28_MUL_(r, a, b) do { if (INL) f28_mul_inl(r, a, b); else f28_mul(r, a, b); } while (0)
+#define F28_SQR_(r, a) do { if (INL) f28_sqr_inl(r, a); else f28_sqr(r, a); } while (0)
+template <bool INL>
+H2V_DI void g1j28_madd_ladder_t(G1J28 &r, const G1J28 &p, const F28 &qx, const F28 &qy_in, const bool neg_q) {
     F28 X1 = p.x, Y1 = p.y, Z1 = p.z, a, b, c, t;
-    f28_sqr(a, Z1);                                  // Z1^2        lam 4, v 16          (2, 1)
-    f28_mul(b, qx, a);                               // U2                               (2, 1)
-    f28_mul(t, Z1, a);                               // Z1^3                             (2, 1)
+    F28_SQR_(a, Z1);                                  // Z1^2        lam 4, v 16          (2, 1)
+    F28_MUL_(b, qx, a);                               // U2                               (2, 1)
+    F28_MUL_(t, Z1, a);                               // Z1^3                             (2, 1)
     {
         F28 qy = qy_in, nq;
         F28_NEG(nq, qy, 3, 1);                       // -Y2                              (3, 3)
         if (neg_q) qy = nq;
-        f28_mul(c, qy, t);                           // S2          lam 3, v 6           (2, 1)
+        F28_MUL_(c, qy, t);                           // S2          lam 3, v 6           (2, 1)
     }
     F28_SUB(b, b, X1, 32, 1);                        // H = U2 - X1                      (34, 4)
     F28_SUB(c, c, Y1, 21, 1);                        // R = S2 - Y1                      (23, 4)
-    f28_mul(Z1, Z1, b);                              // Z3 = Z1 H   lam 8, v 136         (2, 1)
-    f28_sqr(a, b);                                   // HH          lam 16, v 1156       (2, 1)
-    f28_mul(b, b, a);                                // HHH         lam 4, v 68          (2, 1)
-    f28_mul(a, X1, a);                               // V = X1 HH   v 62                 (2, 1)
-    f28_sqr(X1, c);                                  // R^2         lam 16, v 529        (2, 1)
+    F28_MUL_(Z1, Z1, b);                              // Z3 = Z1 H   lam 8, v 136         (2, 1)
+    F28_SQR_(a, b);                                   // HH          lam 16, v 1156       (2, 1)
+    F28_MUL_(b, b, a);                                // HHH         lam 4, v 68          (2, 1)
+    F28_MUL_(a, X1, a);                               // V = X1 HH   v 62                 (2, 1)
+    F28_SQR_(X1, c);                                  // R^2         lam 16, v 529        (2, 1)
     F28_SUB(X1, X1, b, 3, 1);                        // R^2 - HHH                        (5, 4)
     f28_mul_small<2>(t, a);                          // 2V                               (4, 2)
     F28_SUB(X1, X1, t, 5, 2); f28_carry(X1);         // X3                               (10, 1)
     F28_SUB(t, a, X1, 11, 1);                        // V - X3                           (13, 4)
-    f28_mul(c, c, t);                                // R (V - X3)  lam 16, v 299        (2, 1)
-    f28_mul(t, Y1, b);                               // Y1 HHH      v 40                 (2, 1)
+    F28_MUL_(c, c, t);                                // R (V - X3)  lam 16, v 299        (2, 1)
+    F28_MUL_(t, Y1, b);                               // Y1 HHH      v 40                 (2, 1)
     F28_SUB(Y1, c, t, 3, 1); f28_carry(Y1);          // Y3                               (5, 1)
     r.x = X1; r.y = Y1; r.z = Z1;
+}
+#undef F28_MUL_
+#undef F28_SQR_
+H2V_DI void g1j28_madd_ladder(G1J28 &r, const G1J28 &p, const F28 &qx, const F28 &qy_in, const bool neg_q) {
+    g1j28_madd_ladder_t<false>(r, p, qx, qy_in, neg_q);
 }
 // Brings n <= 8 finite Jacobian points to affine with ONE inversion (Montgomery's trick); x and y come out carried
 // with v <= 2.  ax / ay may alias nothing in `pts`.

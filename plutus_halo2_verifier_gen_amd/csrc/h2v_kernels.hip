@@ -588,7 +588,7 @@ struct H2vMsmArgs {
 // cannot be exceptional, see below - merged with complete additions).  It runs beside the ladder launch of the
 // per-proof terms (separate waves: one wave mixing the two kinds would execute them one after the other) and leaves
 // fewer lanes per proof: for T >= 34 at 2048 proofs that brings the MSM back to one wave per SIMD.
-template <int LPT, bool FIX = false>
+template <int LPT, bool FIX = false, bool MADD_INL = false>
 H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, uint32_t per_block,
                      const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws,
                      uint32_t *red /* Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t] */) {
@@ -761,7 +761,7 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
                         f28_set_one(lad.z);
                         lad_inf = false;
                     } else if (LPT == 2 || q >= 2) {
-                        g1j28_madd_ladder(lad, lad, qx, qy, d < 0);   // never an exceptional case (above)
+                        g1j28_madd_ladder_t<MADD_INL>(lad, lad, qx, qy, d < 0);   // never an exceptional case (above)
                     } else {
                         G1J28 o;
                         o.x = qx; o.y = qy;
@@ -824,7 +824,7 @@ extern "C" __global__ void __launch_bounds__(512, 2)
 k_g1_msm_merged(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
                 const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];
-    msm_body<1>(plan, ma, n, per_block, scalars, pts, tabws, red);
+    msm_body<1, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red);
 }
 
 extern "C" __global__ void __launch_bounds__(512, 2)
