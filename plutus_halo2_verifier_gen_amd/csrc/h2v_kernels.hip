@@ -818,7 +818,7 @@ extern "C" __global__ void __launch_bounds__(512, 2)
 k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
          const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];
-    msm_body<2>(plan, ma, n, per_block, scalars, pts, tabws, red);
+    msm_body<2, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red);
 }
 extern "C" __global__ void __launch_bounds__(512, 2)
 k_g1_msm_merged(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
