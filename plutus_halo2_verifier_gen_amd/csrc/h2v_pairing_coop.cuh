@@ -53,7 +53,7 @@ H2V_DI uint32_t *coop_slot(const Coop &c, int s) {
     const int off = s < COOP_SHARED_BASE ? c.grp_off + s * COOP_SLOT_DW : COOP_SHR_OFF + (s - COOP_SHARED_BASE) * COOP_SLOT_DW;
     return coop_lds + off;
 }
-H2V_DI void coop_store28(uint32_t *p, const F28 &a) {   // a must be carried (limbs < 2^28)
+H2V_DI void coop_store28(uint32_t *p, const F28 &a) {   // limbs < 2^28 (carried), except where the headroom note below allows 2^29
     uint4 *q = reinterpret_cast<uint4 *>(p);
     q[0] = make_uint4(a.l[0], a.l[1], a.l[2], a.l[3]);
     q[1] = make_uint4(a.l[4], a.l[5], a.l[6], a.l[7]);
@@ -74,8 +74,10 @@ H2V_DI void coop_load28(uint32_t (&l)[14], const uint32_t *p) {
 
 // Values between engine calls are lazily reduced F28 elements (h2v_fp28.cuh).  Bounds, in that header's (v, lam)
 // notation:  every Fp12 variable has lam = 1 and v <= 6 (engine outputs 3, conj 6, frob 5, inverse 3; the
-// generated program is checked for this by tools/gen_coop_program.py).  Operand slots must hold carried limbs: a
-// MUL column sums 12 terms x 14 products, which fills the 64-bit accumulator at lam = 1.  Staged operands:
+// generated program is checked for this by tools/gen_coop_program.py).  Accumulator headroom: a lane's column sums
+// (terms per lane) x 14 products of (lam_x lam_y) 2^56, tripled for the cyclotomic squaring, plus 14 reduction products:
+// the weighted product count must stay below 2^8.  MUL: 6 x 14 = 84 with carried operands (lam = 1); the doubled operand
+// D = 2a of the squarings is stored UNCARRIED (lam = 2): SQR 4 x 14 x 2 = 112, CSQR 2 x 14 x 2 x 3 = 168.  Staged operands:
 //   A = a (6)   NA = 7p - a_im (7)   B = b (6)   XB = (b0 - b1 + 7p, b0 + b1) (13)   D = 2a (12)   (squarings: see coop_csqr / coop_sqr)
 // Each of the two lanes sharing a coefficient reduces its half of the terms on its own: a half is below
 // (6 * 7 * 13 / 2520 + 1) p = 1.22 p for MUL and (3 * 2 * 7 * 26 / 2520 + 1) p = 1.44 p for the tripled cyclotomic
@@ -208,8 +210,7 @@ H2V_DI F28 coop_csqr(const Coop &c, const F28 &a) {
     const F28 pa = coop_shfl_xor1(a);          // the other part of the same Fp2 coefficient
     if (c.g < 12 && c.h == 1) {
         F28 d2, sm, t;
-        f28_mul_small<2>(d2, a);               // (12, 2)
-        f28_carry(d2);
+        f28_mul_small<2>(d2, a);               // (12, 2): stored with limbs below 2^29 - see the headroom note at the engine
         coop_store28(coop_slot(c, COOP_SLOT_D + c.g), d2);
         if (c.g & 1) { F28_NEG(t, a, 7, 1); }  // imaginary-part lane: M = re - im = pa + (7p - a)
         else t = a;                            // real-part lane:      S = re + im = a + pa
@@ -237,12 +238,10 @@ H2V_DI F28 coop_sqr(const Coop &c, const F28 &a) {
     const F28 pa = coop_shfl_xor1(a);          // the other part of the same Fp2 coefficient
     if (c.g < 12 && c.h == 1) {
         F28 d2, pd2, t, xd;
-        f28_mul_small<2>(d2, a);               // (12, 2)
-        f28_carry(d2);
+        f28_mul_small<2>(d2, a);               // (12, 2): stored with limbs below 2^29
         coop_store28(coop_slot(c, COOP_SLOT_D + c.g), d2);
-        f28_mul_small<2>(pd2, pa);
-        f28_carry(pd2);
-        F28_NEG(t, pd2, 13, 2);                // 13p - d1
+        f28_mul_small<2>(pd2, pa);             // (12, 2)
+        F28_NEG(t, pd2, 13, 2);                // 13p - d1                                 (13, 4)
         if (c.g & 1) t = pd2;                  // imaginary part: (xi d)_1 = d0 + d1 ; real part: (xi d)_0 = d0 - d1
         f28_add(xd, d2, t);
         f28_carry(xd);
