@@ -53,6 +53,7 @@ struct h2v_workspace {
     uint32_t *accl = nullptr, *accr = nullptr, *fold_pts = nullptr, *fold_scal = nullptr, *el2 = nullptr, *er2 = nullptr;
     uint32_t *pt_tab = nullptr;  // MSM window tables of every per-proof point, written by the decompression kernel
     uint32_t *er_fix = nullptr;  // sum of the VK-base terms when the MSM is split into a ladder and a fixed-base launch
+    uint32_t *dec_ctr = nullptr; // work-queue counters of the decompression launch (one per pipeline chunk)
     uint8_t *valid = nullptr, *valid_sub = nullptr, *accept = nullptr;
     // staging for the host-buffer entry point
     uint8_t *in_proofs = nullptr, *in_inst = nullptr, *in_ci = nullptr;
@@ -332,7 +333,7 @@ extern "C" int h2v_plan_trace_slots(const h2v_plan *p, uint32_t *slot_ids, uint3
 // ---------------------------------------------------------------------------------------------- workspace
 static void ws_release(h2v_workspace *w) {
     (void)hipSetDevice(w->device);
-    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->er_fix, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off, w->msm_tab,
+    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->er_fix, w->dec_ctr, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off, w->msm_tab,
                     w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2, w->pt_tab};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipStream_t q : w->pmain) if (q) (void)hipStreamDestroy(q);
@@ -361,6 +362,7 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     WSALLOC(pts, (size_t)max_batch * slots * 96)
     WSALLOC(valid, (size_t)max_batch * slots)
     WSALLOC(valid_sub, (size_t)max_batch * slots)
+    WSALLOC(dec_ctr, 64)
     if (d.fix_tab) { WSALLOC(er_fix, (size_t)max_batch * 36 * 4) }
     WSALLOC(er, (size_t)max_batch * 144)
     WSALLOC(pt_tab, (size_t)max_batch * slots * 448 * 4)             // per (proof, slot): [1..8]P and [1..8]phi(P), affine, 2 x 14 x 28-bit limbs
@@ -622,28 +624,37 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
             HIPCHK(hipEventRecord(ev[1], pm));
             return 0;
         };
+        // Decompression: by default ONE launch whose waves (at most one per SIMD) take 64-point units from a queue - all
+        // subgroup tests, then all square roots (k_g1_decompress_queue); H2V_DEC_QUEUE = 0: the two halves as two
+        // launches of 64-thread blocks on two streams; H2V_SPLIT_DEC = 0: one launch of 128-thread blocks, a root wave and
+        // a subgroup wave per block.
+        static const bool dec_queue = []() { const char *e = getenv("H2V_DEC_QUEUE"); return e ? atoi(e) != 0 : true; }();
         auto sqrt_half = [&]() {
             HIPCHK(hipEventRecord(ev[2], ps));
-            if (split_dec) hipLaunchKernelGGL(k_g1_decompress, dim3(dec_grid), dim3(64), 0, ps, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, pt_tab_k, 1u, (uint8_t *)nullptr);
+            if (split_dec && dec_queue) {
+                uint32_t *ctr = w->dec_ctr + k;
+                HIPCHK(hipMemsetAsync(ctr, 0, 4, ps));
+                const uint32_t units = 2 * dec_grid, max_blocks = (uint32_t)(msm_n_simd() / 4.0);
+                uint32_t blocks = (units + 3) / 4;
+                if (blocks > max_blocks) blocks = max_blocks;
+                hipLaunchKernelGGL(k_g1_decompress_queue, dim3(blocks), dim3(256), 0, ps, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, pt_tab_k, vsub_k, ctr, dec_grid);
+            } else if (split_dec) hipLaunchKernelGGL(k_g1_decompress, dim3(dec_grid), dim3(64), 0, ps, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, pt_tab_k, 1u, (uint8_t *)nullptr);
             else hipLaunchKernelGGL(k_g1_decompress, dim3(dec_grid), dim3(128), 0, ps, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, pt_tab_k, 0u, (uint8_t *)nullptr);
             HIPCHK(hipEventRecord(ev[3], ps));
             HIPCHK(hipEventRecord(w->ev_join[k], ps));
             return 0;
         };
         auto sub_half = [&]() {
-            // the MSM needs coordinates and window tables only: the (longer) subgroup chain gets its own launch and is
-            // joined before the pairing kernel, which is where the verdict on the points is read
+            // the subgroup tests as a launch of their own (only without the queue)
             if (!split_dec) return 0;
             hipStream_t pb = w->psub[k];
             HIPCHK(hipStreamWaitEvent(pb, w->ev_fork, 0));
             HIPCHK(hipEventRecord(ev[7], pb));
-            hipLaunchKernelGGL(k_g1_decompress, dim3(dec_grid), dim3(64), 0, pb, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, (uint32_t *)nullptr, 2u, vsub_k);
+            if (!dec_queue) hipLaunchKernelGGL(k_g1_decompress, dim3(dec_grid), dim3(64), 0, pb, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, (uint32_t *)nullptr, 2u, vsub_k);
             HIPCHK(hipEventRecord(ev[8], pb));
             HIPCHK(hipEventRecord(w->ev_sub[k], pb));
             return 0;
         };
-        // launch order measured on MI355X (the dispatcher gives the first grid the emptier SIMDs): square roots first,
-        // so that the MSM's inputs are the part that finishes early
         const int rco = sqrt_half() || sub_half() || vm();
         if (rco) return rco;
         if (rcv) return rcv;

@@ -430,19 +430,17 @@ H2V_DN void acc_coordinate(Fp &r, const uint8_t *ins, uint32_t idx_hi, uint32_t 
     fp_add(r, r, part[1]);
     fp_add(r, r, one);
 }
-extern "C" __global__ void __launch_bounds__(128, 2)
-k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
-                const uint8_t *__restrict__ committed, const uint8_t *__restrict__ instances,
-                uint32_t *__restrict__ pts, uint8_t *__restrict__ valid, uint32_t *__restrict__ pt_tab /* or NULL */,
-                uint32_t mode, uint8_t *__restrict__ valid_sub) {
-    // mode 0: both roles in one 128-thread block (valid = on curve && in G1);  modes 1 / 2: one role per launch
-    // (64-thread blocks) so that the MSM, which needs coordinates and tables only, does not wait for the longer
-    // subgroup chain: 1 = square root + tables (valid = encoding / on curve), 2 = subgroup test (valid_sub)
-    __shared__ uint8_t sub_ok[H2V_DEC_PTS];
+// one group of 64 points (one wave): `role` 0 = square root (+ window tables), 1 = subgroup test
+H2V_DI void dec_group(const H2vDevPlan &plan, uint32_t n, const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
+                      const uint8_t *__restrict__ committed, const uint8_t *__restrict__ instances,
+                      uint32_t *__restrict__ pts, uint8_t *__restrict__ valid, uint32_t *__restrict__ pt_tab /* or NULL */,
+                      const uint32_t mode, uint8_t *__restrict__ valid_sub, const uint32_t group, const uint32_t role,
+                      const uint32_t lane, uint8_t *sub_ok) {
+    // mode 0: both roles in one 128-thread block (valid = on curve && in G1);  modes 1 / 2: one role per wave, so that
+    // the two chains can be scheduled apart: 1 = square root + tables (valid = encoding / on curve), 2 = subgroup test
+    // (valid_sub)
     const uint32_t slots = H2V_SLOTS(plan);
-    const uint32_t role = mode == 0 ? threadIdx.x >> 6 : mode - 1;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t gid = blockIdx.x * H2V_DEC_PTS + lane;
+    const uint32_t gid = group * H2V_DEC_PTS + lane;
     const bool live = gid < n * slots;
     const uint32_t gg = live ? gid : 0;
     const uint32_t i = gg / slots, j = gg - i * slots;
@@ -540,6 +538,36 @@ k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs,
 #pragma unroll
         for (int k = 0; k < 12; k++) { pts[(size_t)gid * 24 + k] = out.x.v[k]; pts[(size_t)gid * 24 + 12 + k] = out.y.v[k]; }
         valid[gid] = ok ? 1 : 0;
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(128, 2)
+k_g1_decompress(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
+                const uint8_t *__restrict__ committed, const uint8_t *__restrict__ instances,
+                uint32_t *__restrict__ pts, uint8_t *__restrict__ valid, uint32_t *__restrict__ pt_tab /* or NULL */,
+                uint32_t mode, uint8_t *__restrict__ valid_sub) {
+    __shared__ uint8_t sub_ok[H2V_DEC_PTS];
+    const uint32_t role = mode == 0 ? threadIdx.x >> 6 : mode - 1;
+    dec_group(plan, n, proofs, proof_off, committed, instances, pts, valid, pt_tab, mode, valid_sub, blockIdx.x, role, threadIdx.x & 63, sub_ok);
+}
+// The same work from a queue: the launch has at most one wave per SIMD (256-thread blocks: four waves, one per SIMD of
+// a CU) and every wave takes the next 64-point unit until none is left - the n_groups subgroup tests first (the longer
+// chain), then the n_groups square roots.  Separate launches left the pairing of waves on SIMDs to the dispatcher: some
+// subgroup waves shared a SIMD with a root wave for their whole life and finished at 1.45 ms while most SIMDs idled
+// from 1.06 ms on.  `counter` is zeroed by the host before the launch; a wave leaves when the counter passes the end.
+extern "C" __global__ void __launch_bounds__(256, 2)
+k_g1_decompress_queue(H2vDevPlan plan, uint32_t n, const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
+                      const uint8_t *__restrict__ committed, const uint8_t *__restrict__ instances,
+                      uint32_t *__restrict__ pts, uint8_t *__restrict__ valid, uint32_t *__restrict__ pt_tab,
+                      uint8_t *__restrict__ valid_sub, uint32_t *__restrict__ counter, uint32_t n_groups) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (;;) {
+        uint32_t u = 0;
+        if (lane == 0) u = atomicAdd(counter, 1u);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u >= 2 * n_groups) break;
+        if (u < n_groups) dec_group(plan, n, proofs, proof_off, committed, instances, pts, valid, pt_tab, 2u, valid_sub, u, 1u, lane, nullptr);
+        else dec_group(plan, n, proofs, proof_off, committed, instances, pts, valid, pt_tab, 1u, valid_sub, u - n_groups, 0u, lane, nullptr);
     }
 }
 
