@@ -166,7 +166,7 @@ def main():
         lds_slots = 64
         while lds_slots >= 8 and pl.n_regs * 32 * lds_slots + 8192 + 1024 > 160 * 1024:
             lds_slots >>= 1
-        kname = {"g1_msm": "k_g1_msm_fixed" if msm_lpt == 3 else "k_g1_msm_merged" if msm_lpt == 1 else "k_g1_msm", "g1_decompress": "k_g1_decompress",
+        kname = {"g1_msm": "k_g1_msm_fixed" if msm_lpt == 3 else "k_g1_msm_merged" if msm_lpt == 1 else "k_g1_msm", "g1_decompress": "k_g1_decompress" if (os.environ.get("H2V_DEC_QUEUE") == "0" or os.environ.get("H2V_SPLIT_DEC") == "0") else "k_g1_decompress_queue",
                  "transcript_combiner": "k_transcript_combiner_lds" if lds_slots >= 8 else "k_transcript_combiner",
                  "pairing": "k_pairing_coop" if os.environ.get("H2V_PAIRING") != "legacy" else "k_pairing_check"}
 
