@@ -22,7 +22,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # Integer-multiply issue ceiling measured on this chip with tools/ubench/imad.hip: v_mad_u64_u32 sustains one
 # wave-instruction per 5.4 cycles per SIMD at >= 2 waves/SIMD  ->  1024 SIMDs * 64 lanes * 2.4e9 / 5.4 lane-mads/s.
 IMAD_PEAK_TOPS = 1024 * 64 * 2.4e9 / 5.4 / 1e12
-# v_mad_u64_u32 per field operation (csrc/h2v_field.cuh): product-scanning multiply 392, square 301
+# v_mad_u64_u32 per field operation (csrc/h2v_field.hpp): product-scanning multiply 392, square 301
 MAD_MUL, MAD_SQR = 392, 301
 MAD_DBL = 2 * MAD_MUL + 5 * MAD_SQR          # dbl-2009-l
 MAD_MADD = 8 * MAD_MUL + 3 * MAD_SQR         # mixed addition

@@ -79,6 +79,9 @@ void h2v_plan_free(h2v_plan *plan);
 int h2v_plan_info(const h2v_plan *plan, uint32_t *proof_len, uint32_t *n_public_inputs, uint32_t *n_committed,
                   uint32_t *n_msm_terms);
 
+/* A workspace is sized from `plan` (MSM terms, point slots, register file, recursion / fixed-base buffers).  It may be
+ * reused with ANOTHER plan only if that plan needs no more of any of these; otherwise the verify calls return H2V_E_ARG
+ * (they never write past a buffer).  One workspace serves one call at a time. */
 int h2v_workspace_create(const h2v_plan *plan, uint64_t max_batch, h2v_workspace **out);
 void h2v_workspace_free(h2v_workspace *ws);
 /* Per-kernel device times of a past call that used `ws` (calls_back = 0: the most recent; up to 63 back), from HIP
@@ -117,13 +120,15 @@ int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_t *scalars,
 /* e(p1, s_g2 of plan) == e(p2, G2) for n pairs of compressed G1 points; out[i] = 1/0 */
 int h2v_probe_pairing(const h2v_plan *plan, uint32_t n, const uint8_t *p1_compressed, const uint8_t *p2_compressed,
                       uint8_t *out);
-/* same with an explicit kernel (impl 0: one lane per proof, 1: cooperative 16 lanes per proof, -1: default) and an
+/* same with an explicit kernel (impl 0: one lane per proof, 1: cooperative, 32 lanes per proof, -1: default) and an
  * optional dump (n * 24 * 48 bytes): the 12 Fp coefficients (flat order w^k, re/im; canonical LE) of f after the
  * Miller loop and, for the cooperative kernel, after the final exponentiation */
 int h2v_probe_pairing_ex(const h2v_plan *plan, uint32_t n, const uint8_t *p1_compressed, const uint8_t *p2_compressed,
                          uint8_t *out, int impl, uint8_t *dbg);
 
 const char *h2v_last_error(void);
+/* sha256 (hex) of the sources this binary was built from; "unknown" for a build outside __graft_entry__.build() */
+const char *h2v_build_id(void);
 int h2v_device_count(void);
 
 #ifdef __cplusplus

@@ -72,6 +72,10 @@ def lib():
         L.orc_verify.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.POINTER(Trace)]
         L.orc_verify_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_void_p, C.c_char_p, C.c_char_p,
                                        C.c_void_p, C.c_int]
+        L.orc_vk_commitment_map.restype = C.c_long
+        L.orc_vk_commitment_map.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_lookup_argument.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t, C.c_char_p,
+                                          C.c_size_t, C.c_char_p, C.c_void_p]
         L.orc_transcript_script.restype = C.c_long
         L.orc_transcript_script.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_void_p,
                                             C.c_size_t]
@@ -169,10 +173,37 @@ class OracleVK:
         return lib().orc_vk_proof_len(self._h)
 
     def verify(self, proof: bytes, instances, committed: bytes | None = None, trace: bool = False):
-        inst = b"".join(_fr(v) for v in instances)
+        # the 32 bytes as the caller would hand them over: a value in [r, 2^256) stays non-canonical (and is rejected)
+        inst = b"".join(int(v).to_bytes(32, "little") if 0 <= int(v) < (1 << 256) else _fr(v) for v in instances)
         tr = Trace() if trace else None
         ok = lib().orc_verify(self._h, proof, len(proof), inst, committed, C.byref(tr) if trace else None)
         return (bool(ok), tr) if trace else bool(ok)
+
+    CK_NAMES = ["instance", "advice", "fixed", "perm", "lookup", "perm_input", "perm_table", "common", "vanishing_g",
+                "vanishing_rand", "trash"]
+    EK_NAMES = ["instance", "advice", "fixed", "perm", "lookup", "lookup_next", "perm_input", "perm_input_inv",
+                "perm_table", "common", "vanishing_s", "random", "trash"]
+    ROT_NAMES = ["last", "prev", "cur", "next", "custom"]
+
+    def commitment_map(self):
+        """The commitment map build_sets derived (the structure orc_verify walks): a list of dicts
+        {commitment: (kind, idx), set: first-seen point-set index, sorted_set: its position after the cardinality
+        sort, pairs: [(rotation name, (eval kind, idx, sub))...]}."""
+        buf = (C.c_int32 * 65536)()
+        n = lib().orc_vk_commitment_map(self._h, buf, 65536)
+        assert n >= 0
+        out, w = [], 0
+        while w < n:
+            ck, cidx, st, srt, npts = buf[w:w + 5]
+            w += 5
+            pairs = []
+            for _ in range(npts):
+                rk, rn, ek, eidx, esub = buf[w:w + 5]
+                w += 5
+                rot = self.ROT_NAMES[rk] if rk < 4 else ("custom", rn)
+                pairs.append((rot, (self.EK_NAMES[ek], eidx, esub)))
+            out.append({"commitment": (self.CK_NAMES[ck], cidx), "set": st, "sorted_set": srt, "pairs": pairs})
+        return out
 
     def verify_batch(self, proofs: bytes, offsets, instances: bytes, committed: bytes | None, threads: int = 1):
         n = len(offsets) - 1
@@ -314,6 +345,16 @@ def g2_generator_compressed() -> bytes:
     out = C.create_string_buffer(96)
     lib().orc_g2_generator_compressed(out)
     return out.raw
+
+
+def lookup_argument(inputs, table, advice, fixed, theta, beta, gamma, l_0, l_last, active_rows, evals5):
+    """The lookup block orc_verify runs, on explicit values: returns the five identities."""
+    blob = b"".join(expr_blob(e) for e in list(inputs) + list(table))
+    scal = b"".join(_fr(v) for v in [theta, beta, gamma, l_0, l_last, active_rows] + list(evals5))
+    out = C.create_string_buffer(160)
+    ok = lib().orc_lookup_argument(blob, len(blob), len(inputs), len(table), b"".join(_fr(a) for a in advice), len(advice),
+                                   b"".join(_fr(f) for f in fixed), len(fixed), scal, out)
+    return [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(5)] if ok else None
 
 
 def eval_expr(e, advice, fixed):

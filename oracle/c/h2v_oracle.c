@@ -449,6 +449,43 @@ static void g1_scale_add(g1j *acc, const g1a *p, const fr *k) { /* acc += k*P */
     g1j_add(acc, acc, &t);
 }
 
+/* The five identities of one lookup argument (aiken.rs:264-330) from the already compressed input / table values and
+ * the argument's five evaluations ev = {product, product_next, permuted_input, permuted_input_inv, permuted_table}.
+ * orc_verify and the golden-vector entry point orc_lookup_identities both run THIS code. */
+static void lookup_identities(fr out[5], const fr *l_0, const fr *l_last, const fr *active_rows, const fr *beta,
+                              const fr *gamma, const fr *inp, const fr *tab, const fr ev[5]) {
+    const fr *prod = &ev[0], *prod_next = &ev[1], *pin = &ev[2], *pinv = &ev[3], *ptab = &ev[4];
+    fr one, t, u, left, right;
+    fr_one(&one);
+    fr_sub(&t, &one, prod); fr_mul(&out[0], l_0, &t);
+    fr_mul(&t, prod, prod); fr_sub(&t, &t, prod); fr_mul(&out[1], l_last, &t);
+    fr_add(&t, pin, beta); fr_mul(&left, prod_next, &t); fr_add(&t, ptab, gamma); fr_mul(&left, &left, &t);
+    fr_add(&t, inp, beta); fr_mul(&right, prod, &t); fr_add(&t, tab, gamma); fr_mul(&right, &right, &t);
+    fr_sub(&t, &left, &right); fr_mul(&out[2], &t, active_rows);
+    fr_sub(&t, pin, ptab); fr_mul(&out[3], l_0, &t);
+    fr_sub(&u, pin, pinv); fr_mul(&t, &t, &u); fr_mul(&out[4], &t, active_rows);
+}
+/* One lookup argument: theta-compression of its input / table expression lists (Horner, languages/aiken.rs:18-29)
+ * followed by the five identities.  Shared by orc_verify and orc_lookup_argument (golden vectors of gates_test.hbs). */
+static void lookup_argument(fr out[5], const enode *pool, const int *in_ids, uint32_t n_in, const int *tab_ids, uint32_t n_tab,
+                            const fr *advice_eval, const fr *fixed_eval, const fr *theta, const fr *beta, const fr *gamma,
+                            const fr *l_0, const fr *l_last, const fr *active_rows, const fr ev[5]) {
+    fr tab, inp, e;
+    fr_zero(&tab); fr_zero(&inp);
+    for (uint32_t j = 0; j < n_tab; j++) { eval_expr(pool, tab_ids[j], advice_eval, fixed_eval, &e); fr_mul(&tab, &tab, theta); fr_add(&tab, &tab, &e); }
+    for (uint32_t j = 0; j < n_in; j++) { eval_expr(pool, in_ids[j], advice_eval, fixed_eval, &e); fr_mul(&inp, &inp, theta); fr_add(&inp, &inp, &e); }
+    lookup_identities(out, l_0, l_last, active_rows, beta, gamma, &inp, &tab, ev);
+}
+/* One commitment's contribution to the q_eval set of its point set (compute_q_evals_and_final_comm,
+ * halo2_kzg.ak:46-89): q[j] += x1^pos * eval_j.  Shared by orc_verify and orc_multiopen_scalars. */
+static void q_eval_accumulate(fr *q, const fr *const *evs, int npts, const fr *x1p) {
+    for (int j = 0; j < npts; j++) {
+        fr t;
+        fr_mul(&t, evs[j], x1p);
+        fr_add(&q[j], &q[j], &t);
+    }
+}
+
 #define REJECT(code) do { status = (code); goto done; } while (0)
 
 int orc_verify(const orc_vk *vk, const uint8_t *proof, size_t proof_len, const uint8_t *instances,
@@ -491,8 +528,9 @@ int orc_verify(const orc_vk *vk, const uint8_t *proof, size_t proof_len, const u
         fr_from_u64(&cnt, vk->n_pi);
         tr_common_scalar(&tr, &cnt);
         for (i = 0; i < vk->n_pi; i++) {
-            /* public inputs are field elements handed over by the caller (State<Scalar>): reduce silently */
-            fr_from_le32(&pi[i], instances + 32 * i);
+            /* public inputs are field elements on the reference side (Rust F, Aiken State<Scalar>): a 32-byte value
+             * >= r has no counterpart there, so it is rejected like a non-canonical proof scalar */
+            if (!fr_from_le32(&pi[i], instances + 32 * i)) bad_scalar = 1;
             tr_common_scalar(&tr, &pi[i]);
         }
     }
@@ -625,18 +663,9 @@ int orc_verify(const orc_vk *vk, const uint8_t *proof, size_t proof_len, const u
     }
     /* lookups: aiken.rs:264-330; compression languages/aiken.rs:18-29 */
     for (i = 0; i < L; i++) {
-        fr tab = zero, inp = zero, e, t, u;
-        for (uint32_t j = 0; j < vk->lk_ntab[i]; j++) { eval_expr(vk->pool.n, vk->lk_tab[i][j], advice_eval, fixed_eval, &e); fr_mul(&tab, &tab, &theta); fr_add(&tab, &tab, &e); }
-        for (uint32_t j = 0; j < vk->lk_nin[i]; j++) { eval_expr(vk->pool.n, vk->lk_in[i][j], advice_eval, fixed_eval, &e); fr_mul(&inp, &inp, &theta); fr_add(&inp, &inp, &e); }
-        const fr *prod = &lk_eval[5 * i], *prod_next = &lk_eval[5 * i + 1], *pin = &lk_eval[5 * i + 2], *pinv = &lk_eval[5 * i + 3], *ptab = &lk_eval[5 * i + 4];
-        fr_sub(&t, &one, prod); fr_mul(&expr[n_expr++], &l_0, &t);
-        fr_mul(&t, prod, prod); fr_sub(&t, &t, prod); fr_mul(&expr[n_expr++], &l_last, &t);
-        fr left, right;
-        fr_add(&t, pin, &beta); fr_mul(&left, prod_next, &t); fr_add(&t, ptab, &gamma); fr_mul(&left, &left, &t);
-        fr_add(&t, &inp, &beta); fr_mul(&right, prod, &t); fr_add(&t, &tab, &gamma); fr_mul(&right, &right, &t);
-        fr_sub(&t, &left, &right); fr_mul(&expr[n_expr++], &t, &active_rows);
-        fr_sub(&t, pin, ptab); fr_mul(&expr[n_expr++], &l_0, &t);
-        fr_sub(&u, pin, pinv); fr_mul(&t, &t, &u); fr_mul(&expr[n_expr++], &t, &active_rows);
+        lookup_argument(&expr[n_expr], vk->pool.n, vk->lk_in[i], vk->lk_nin[i], vk->lk_tab[i], vk->lk_ntab[i], advice_eval, fixed_eval,
+                        &theta, &beta, &gamma, &l_0, &l_last, &active_rows, &lk_eval[5 * i]);
+        n_expr += 5;
     }
     /* trashcans: aiken.rs:444-461 */
     for (i = 0; i < vk->n_trash; i++) {
@@ -704,6 +733,7 @@ int orc_verify(const orc_vk *vk, const uint8_t *proof, size_t proof_len, const u
                 default: P = &trash_c[cd->cidx]; break;
                 }
                 g1_scale_add(&q_com, P, &x1p);
+                const fr *evs[MAX_SET_PTS];
                 for (int j = 0; j < cd->npts; j++) {
                     const fr *ev;
                     switch (cd->ek[j]) {
@@ -721,10 +751,9 @@ int orc_verify(const orc_vk *vk, const uint8_t *proof, size_t proof_len, const u
                     case EK_RANDOM: ev = &random_eval; break;
                     default: ev = &trash_eval[cd->eidx[j]]; break;
                     }
-                    fr t;
-                    fr_mul(&t, ev, &x1p);
-                    fr_add(&q_eval_sets[s][j], &q_eval_sets[s][j], &t);
+                    evs[j] = ev;
                 }
+                q_eval_accumulate(q_eval_sets[s], evs, cd->npts, &x1p);
                 fr_mul(&x1p, &x1p, &x1);
             }
             g1j t;
@@ -898,6 +927,7 @@ int orc_multiopen_scalars(size_t n_sets, const uint32_t *set_sizes, const uint8_
                           uint8_t v[32]) {
     fr fx1, fx2, fx3, fx4, fe, fv;
     fr_from_le32(&fx1, x1); fr_from_le32(&fx2, x2); fr_from_le32(&fx3, x3); fr_from_le32(&fx4, x4);
+    for (size_t s = 0; s < n_sets; s++) if (set_sizes[s] > MAX_SET_PTS) return 0;
     fr **pts = (fr **)calloc(n_sets, sizeof(fr *)), **qs = (fr **)calloc(n_sets, sizeof(fr *));
     int *sizes = (int *)calloc(n_sets, sizeof(int));
     fr *qe = (fr *)calloc(n_sets, sizeof(fr));
@@ -907,7 +937,10 @@ int orc_multiopen_scalars(size_t n_sets, const uint32_t *set_sizes, const uint8_
         for (int j = 0; j < sizes[s]; j++) { fr_from_le32(&pts[s][j], points); points += 32; }
         fr x1p; fr_one(&x1p);
         for (uint32_t c = 0; c < n_comms[s]; c++) {
-            for (int j = 0; j < sizes[s]; j++) { fr e, t; fr_from_le32(&e, evals); evals += 32; fr_mul(&t, &e, &x1p); fr_add(&qs[s][j], &qs[s][j], &t); }
+            fr e[MAX_SET_PTS];
+            const fr *evs[MAX_SET_PTS];
+            for (int j = 0; j < sizes[s]; j++) { fr_from_le32(&e[j], evals); evals += 32; evs[j] = &e[j]; }
+            q_eval_accumulate(qs[s], evs, sizes[s], &x1p);   /* the loop body orc_verify runs */
             fr_mul(&x1p, &x1p, &fx1);
         }
         fr_from_le32(&qe[s], q_evals + 32 * s);
@@ -920,6 +953,48 @@ int orc_multiopen_scalars(size_t n_sets, const uint32_t *set_sizes, const uint8_
     for (size_t s = 0; s < n_sets; s++) { free(pts[s]); free(qs[s]); }
     free(pts); free(qs); free(sizes); free(qe);
     return ok;
+}
+/* Golden-vector entry point of the lookup block orc_verify runs (lookup_argument above).
+ * exprs: n_in input expressions then n_tab table expressions, concatenated expression blobs;
+ * scal: theta, beta, gamma, l_0, l_last, active_rows, product, product_next, permuted_input, permuted_input_inv,
+ * permuted_table (11 x 32 bytes); out: the five identities (5 x 32 bytes). */
+int orc_lookup_argument(const uint8_t *exprs, size_t exprs_len, uint32_t n_in, uint32_t n_tab, const uint8_t *advice, size_t n_adv,
+                        const uint8_t *fixed, size_t n_fix, const uint8_t scal[11 * 32], uint8_t out[5 * 32]) {
+    if (n_in + n_tab > 64) return 0;
+    rd r = {exprs, exprs_len, 0, 0};
+    epool pool = {0, 0, 0};
+    int ids[64];
+    for (uint32_t j = 0; j < n_in + n_tab; j++) ids[j] = parse_expr(&r, &pool, 0);
+    if (r.err) { free(pool.n); return 0; }
+    for (int i = 0; i < pool.cnt; i++) {
+        if (pool.n[i].tag == EX_FIXED && (size_t)pool.n[i].idx >= n_fix) { free(pool.n); return 0; }
+        if (pool.n[i].tag == EX_ADVICE && (size_t)pool.n[i].idx >= n_adv) { free(pool.n); return 0; }
+    }
+    fr *a = (fr *)calloc(n_adv + 1, sizeof(fr)), *f = (fr *)calloc(n_fix + 1, sizeof(fr)), v[11], o[5];
+    for (size_t i = 0; i < n_adv; i++) fr_from_le32(&a[i], advice + 32 * i);
+    for (size_t i = 0; i < n_fix; i++) fr_from_le32(&f[i], fixed + 32 * i);
+    for (int i = 0; i < 11; i++) fr_from_le32(&v[i], scal + 32 * i);
+    lookup_argument(o, pool.n, ids, n_in, ids + n_in, n_tab, a, f, &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]);
+    for (int i = 0; i < 5; i++) fr_to_le32(out + 32 * i, &o[i]);
+    free(a); free(f); free(pool.n);
+    return 1;
+}
+/* The commitment map and point sets orc_verify walks (build_sets), for the golden commitmentMap of ProofData.hs:184-197.
+ * Per commitment, in order: ck, cidx, first-seen set index, position of that set after the cardinality sort, npts, then
+ * npts x (rotation kind, rotation n, ek, eidx, esub).  Returns the number of int32 written, or -1 if cap is too small. */
+long orc_vk_commitment_map(const orc_vk *vk, int32_t *out, size_t cap) {
+    size_t w = 0;
+    for (int c = 0; c < vk->n_comm; c++) {
+        const commitment_data *cd = &vk->cd[c];
+        if (w + 5 + 5 * (size_t)cd->npts > cap) return -1;
+        int sorted_pos = -1;
+        for (int s = 0; s < vk->n_sets; s++) if (vk->sort_order[s] == cd->set) sorted_pos = s;
+        out[w++] = cd->ck; out[w++] = cd->cidx; out[w++] = cd->set; out[w++] = sorted_pos; out[w++] = cd->npts;
+        for (int j = 0; j < cd->npts; j++) {
+            out[w++] = cd->pts[j].kind; out[w++] = cd->pts[j].n; out[w++] = cd->ek[j]; out[w++] = cd->eidx[j]; out[w++] = cd->esub[j];
+        }
+    }
+    return (long)w;
 }
 static int g1a_from_xy(g1a *p, const uint8_t xy[96]) {
     int z = 1;

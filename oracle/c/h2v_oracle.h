@@ -80,6 +80,12 @@ void orc_g2_generator_compressed(uint8_t out[96]);
 int orc_eval_expr(const uint8_t *blob, size_t len, const uint8_t *advice, size_t n_adv, const uint8_t *fixed,
                   size_t n_fix, uint8_t out[32]);
 
+/* the lookup block of orc_verify (theta-compression + five identities) on explicit inputs: gates_test.hbs vectors */
+int orc_lookup_argument(const uint8_t *exprs, size_t exprs_len, uint32_t n_in, uint32_t n_tab, const uint8_t *advice, size_t n_adv,
+                        const uint8_t *fixed, size_t n_fix, const uint8_t scal[11 * 32], uint8_t out[5 * 32]);
+/* commitment map + point sets as orc_verify walks them (ProofData.hs:184-197 commitmentMap) */
+long orc_vk_commitment_map(const orc_vk *vk, int32_t *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

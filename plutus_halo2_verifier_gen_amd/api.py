@@ -30,6 +30,7 @@ STATUS_TEXT = {
     backend.ST_SHORT_PROOF: "proof shorter than the verifier's read program",
     backend.ST_BAD_POINT: "invalid G1 encoding (malformed / off-curve / not in the subgroup)",
     backend.ST_PAIRING: "pairing check failed",
+    backend.ST_RECURSION: "recursion: the verifying-key hash in the public inputs is not this key's",
 }
 
 
@@ -140,7 +141,9 @@ _VERIFIERS = {}
 
 
 def verifier_for(vk: VerifyingKey, device: int = 0) -> Verifier:
-    key = (id(vk), device)
+    """One compiled plan per (verifying key CONTENT, device).  Keyed by the key's canonical JSON, not by id(vk): an
+    object id is reused after garbage collection and would hand a new key a stale plan."""
+    key = (vk.to_json(), device)
     if key not in _VERIFIERS:
         _VERIFIERS[key] = Verifier(vk, device)
     return _VERIFIERS[key]

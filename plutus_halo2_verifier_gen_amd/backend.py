@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libh2v_hip.so")
 
 H2V_OK = 0
-ST_BAD_SCALAR, ST_INVERSE_OF_ZERO, ST_SHORT_PROOF, ST_BAD_POINT, ST_PAIRING = 1, 2, 4, 8, 16
+ST_BAD_SCALAR, ST_INVERSE_OF_ZERO, ST_SHORT_PROOF, ST_BAD_POINT, ST_PAIRING, ST_RECURSION = 1, 2, 4, 8, 16, 32
 
 
 class H2VError(RuntimeError):
@@ -35,7 +35,7 @@ EXPORTS = [
     "h2v_workspace_timings",
     "h2v_verify_batch", "h2v_verify_batch_device", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
     "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_pairing", "h2v_probe_pairing_ex",
-    "h2v_last_error",
+    "h2v_last_error", "h2v_build_id",
     "h2v_device_count",
 ]
 
@@ -51,6 +51,7 @@ def lib():
                            "(there is no CPU fallback)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         L.h2v_last_error.restype = C.c_char_p
+        L.h2v_build_id.restype = C.c_char_p
         L.h2v_plan_load.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         L.h2v_plan_free.argtypes = [C.c_void_p]
         L.h2v_plan_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4
@@ -116,6 +117,14 @@ class DevicePlan:
     # ---- host-buffer batch verify
     def verify_batch(self, proofs: bytes, proof_off, instances: bytes, committed: Optional[bytes], ws=None) -> bytes:
         n = len(proof_off) - 1
+        if n < 0 or any(proof_off[i + 1] < proof_off[i] for i in range(n)) or (n >= 0 and proof_off[0] < 0):
+            raise H2VError("proof offsets must be non-decreasing")
+        if n > 0 and proof_off[-1] > len(proofs):
+            raise H2VError("proof_off[n] = %d exceeds the %d proof bytes handed over" % (proof_off[-1], len(proofs)))
+        if self.n_pi and len(instances or b"") < 32 * self.n_pi * n:
+            raise H2VError("instances: expected %d bytes" % (32 * self.n_pi * n))
+        if self.n_ci and len(committed or b"") < 48 * n:
+            raise H2VError("committed: expected %d bytes" % (48 * n))
         off = (C.c_uint64 * (n + 1))(*proof_off)
         pbuf = C.create_string_buffer(proofs, len(proofs)) if proofs else C.create_string_buffer(1)
         ibuf = C.create_string_buffer(instances, len(instances)) if instances else None

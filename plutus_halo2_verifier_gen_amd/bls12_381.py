@@ -555,7 +555,7 @@ GLV_MU = (1 << 383) // GLV_LAMBDA
 
 
 def glv_split(k: int):
-    """k = k2*lambda + k1 with 0 <= k1 < lambda, exactly as csrc/h2v_curve.cuh: glv_split computes it
+    """k = k2*lambda + k1 with 0 <= k1 < lambda, exactly as csrc/h2v_curve.hpp: glv_split computes it
     (Barrett estimate floor(k*mu / 2^383), at most two corrections)."""
     q = (k * GLV_MU) >> 383
     rem = k - q * GLV_LAMBDA

@@ -26,6 +26,14 @@ static int fail(int code, const std::string &msg) {
     } while (0)
 
 extern "C" const char *h2v_last_error(void) { return g_err.c_str(); }
+// content hash of csrc/ + include/h2v.h this binary was built from (__graft_entry__.build_hip compares it with the tree)
+#ifndef H2V_SRC_HASH_STR
+#define H2V_SRC_HASH_STR "unknown"
+#endif
+extern "C" const char *h2v_build_id(void) {
+    static const char id[] = "H2V_SRC_HASH=" H2V_SRC_HASH_STR;
+    return id + 13;
+}
 extern "C" int h2v_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -48,6 +56,9 @@ struct h2v_workspace {
     int device = 0;
     uint64_t cap = 0;       // max batch
     uint32_t stride = 0;    // register-file stride (cap rounded up to 64)
+    // what the buffers were sized for (the creating plan's shape): a plan fits iff each of its values is <= these
+    uint32_t sz_terms = 0, sz_slots = 0, sz_regs = 0 /* 0: register file in LDS */, sz_trace = 0;
+    bool sz_ivc = false, sz_fix = false;
     uint32_t *regs = nullptr, *scalars = nullptr, *pts = nullptr, *er = nullptr, *status = nullptr, *trace = nullptr, *msm_tab = nullptr;
     // recursion (IVC): acc_left / acc_right_final sums, the fold's points + scalars, and the folded el / er
     uint32_t *accl = nullptr, *accr = nullptr, *fold_pts = nullptr, *fold_scal = nullptr, *el2 = nullptr, *er2 = nullptr;
@@ -355,6 +366,8 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     w->cap = max_batch;
     w->stride = (uint32_t)((max_batch + 63) / 64 * 64);
     const uint64_t slots = H2V_SLOTS(d);
+    w->sz_terms = d.n_terms; w->sz_slots = (uint32_t)slots; w->sz_regs = vm_lds_slots(d) == 0 ? d.n_regs : 0;
+    w->sz_trace = with_trace ? d.n_trace : 0; w->sz_ivc = d.ivc != 0; w->sz_fix = d.fix_tab != nullptr;
 #define WSALLOC(field, bytes)                                                                  \
     if (hipMalloc((void **)&w->field, (bytes)) != hipSuccess) { ws_release(w); delete w; return fail(H2V_E_DEVICE, "hipMalloc(" #field ") failed"); }
     if (vm_lds_slots(d) == 0) { WSALLOC(regs, (size_t)d.n_regs * 8 * w->stride * 4) }  // else the register file lives in LDS
@@ -398,6 +411,20 @@ extern "C" void h2v_workspace_free(h2v_workspace *w) {
     if (!w) return;
     ws_release(w);
     delete w;
+}
+
+// A workspace is sized from the plan it was created for; another plan may use it iff every buffer is large enough for
+// it (terms, point slots, a global register file if it needs one, recursion buffers, the fixed-base sum).
+static int ws_fits(const h2v_workspace *w, const h2v_plan *p, uint64_t n, bool want_trace) {
+    const H2vDevPlan &d = p->d;
+    if (w->device != p->device) return fail(H2V_E_ARG, "workspace belongs to another device");
+    if (w->cap < n) return fail(H2V_E_ARG, "workspace too small for this batch");
+    if (d.n_terms > w->sz_terms || H2V_SLOTS(d) > w->sz_slots) return fail(H2V_E_ARG, "workspace was created for a smaller plan (MSM terms / point slots)");
+    if (vm_lds_slots(d) == 0 && d.n_regs > w->sz_regs) return fail(H2V_E_ARG, "workspace has no (or too small a) global register file for this plan");
+    if (d.ivc && !w->sz_ivc) return fail(H2V_E_ARG, "workspace was created for a non-recursive plan");
+    if (d.fix_tab && !w->sz_fix) return fail(H2V_E_ARG, "workspace lacks the fixed-base sum buffer of this plan");
+    if (want_trace && d.n_trace > w->sz_trace) return fail(H2V_E_ARG, "workspace has no trace buffer for this plan");
+    return H2V_OK;
 }
 
 // Transcript + combiner launch.  A block is one wave; its 64 lanes are P proofs x L lanes per proof (the plan's
@@ -723,7 +750,7 @@ extern "C" int h2v_verify_batch_device(const h2v_plan *p, const h2v_batch *b, ui
         if (rc) return rc;
         ws = tmp;
     }
-    if (ws->device != p->device || ws->cap < b->n) { if (tmp) h2v_workspace_free(tmp); return fail(H2V_E_ARG, "workspace too small / wrong device"); }
+    if (int rcf = ws_fits(ws, p, b->n, false)) { if (tmp) h2v_workspace_free(tmp); return rcf; }
     int rc = run_pipeline(p->d, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws,
                           (hipStream_t)stream, timings, false);
     if (tmp) {
@@ -813,7 +840,7 @@ extern "C" int h2v_verify_batch(const h2v_plan *p, const h2v_batch *b, uint8_t *
         if ((rc = ws_create_for(p->d, p->device, b->n, false, &tmp))) return rc;
         ws = tmp;
     }
-    if (ws->device != p->device || ws->cap < b->n) { if (tmp) h2v_workspace_free(tmp); return fail(H2V_E_ARG, "workspace too small / wrong device"); }
+    if ((rc = ws_fits(ws, p, b->n, false))) { if (tmp) h2v_workspace_free(tmp); return rc; }
     rc = stage_inputs(p, b, ws);
     if (rc == H2V_OK)
         rc = run_pipeline(p->d, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, nullptr, nullptr, false);

@@ -5,7 +5,7 @@
 // input and the accept/reject result must match the reference's exact group law (the Plutus builtins
 // bls12_381_G1_add / scalarMul used by aiken-verifier/aiken_halo2/lib/bls_utils.ak:77-86).
 #pragma once
-#include "h2v_field.cuh"
+#include "h2v_field.hpp"
 
 struct G1A { Fp x, y; };       // affine; (0,0) = infinity
 struct G1J { Fp x, y, z; };    // Jacobian

@@ -1,17 +1,17 @@
 // G1 group law (a = 0 short Weierstrass; the constant b never enters the formulas, so the same code serves
-// y^2 = x^3 + 4 and the isomorphic curves the subgroup test works on) over the lazily reduced field of h2v_fp28.cuh.
+// y^2 = x^3 + 4 and the isomorphic curves the subgroup test works on) over the lazily reduced field of h2v_fp28.hpp.
 //
 // The point at infinity is an explicit flag (`inf`) beside the coordinates: with lazily reduced coordinates "Z == 0"
-// is not a limb pattern.  Completeness is kept exactly as in h2v_curve.cuh (P+P, P+(-P), infinity operands): proof
+// is not a limb pattern.  Completeness is kept exactly as in h2v_curve.hpp (P+P, P+(-P), infinity operands): proof
 // bytes are adversarial and the verdict must match the reference's group law
 // (aiken-verifier/aiken_halo2/lib/bls_utils.ak:77-86, the Plutus builtins bls12_381_G1_add / scalarMul).
 //
-// Coordinate bounds (v, lam) of every stored point, see h2v_fp28.cuh for the notation:
+// Coordinate bounds (v, lam) of every stored point, see h2v_fp28.hpp for the notation:
 //     X (31, 1)   Y (20, 1)   Z (4, 2)           -- closed under g1j28_dbl and g1j28_add (derivations inline);
 //     table entries (never negated in place) have Y (19, 1)
 #pragma once
-#include "h2v_curve.cuh"
-#include "h2v_fp28.cuh"
+#include "h2v_curve.hpp"
+#include "h2v_fp28.hpp"
 
 struct G1J28 { F28 x, y, z; };
 
@@ -21,7 +21,7 @@ H2V_DI void g1j28_from_affine(G1J28 &r, const G1A &a) {
     f28_from_fp(r.y, a.y);
     f28_set_one(r.z);
 }
-// -> canonical Jacobian coordinates of h2v_curve.cuh
+// -> canonical Jacobian coordinates of h2v_curve.hpp
 H2V_DI void g1j28_to_g1j(G1J &r, const G1J28 &p, const bool inf) {
     if (inf) { g1j_set_inf(r); return; }
     F28 z = p.z;

@@ -356,8 +356,8 @@ H2V_DI void fp_from_mont(Fp &r, const Fp &a) {
 // ------------------------------------------------------------------ inversion
 // Any exact inverse is the same field element as the reference's recip (BlsTypes.hs:201-212 / recip_eea,
 // bls_utils.ak:98-117).
-#include "h2v_modinv.cuh"
-// Inversion: batched division steps (h2v_modinv.cuh).  The operand is a Montgomery residue aR; its integer
+#include "h2v_modinv.hpp"
+// Inversion: batched division steps (h2v_modinv.hpp).  The operand is a Montgomery residue aR; its integer
 // inverse is a^-1 R^-1, and one Montgomery product with R^3 returns a^-1 R.  Returns false when a == 0.
 H2V_DN bool fp_inv(Fp &r, const Fp &a) {
     if (fp_is_zero(a)) { fp_set_zero(r); return false; }

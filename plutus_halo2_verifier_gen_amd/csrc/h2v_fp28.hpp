@@ -6,7 +6,7 @@
 // carry chains plus a select (~60-85 issue slots).  Here additions are 14 independent v_add, subtractions add a
 // pre-spread multiple of p first, and a value is only brought back to normal form where the bounds below need it.
 //
-// Bounds (checked by hand per formula in h2v_curve28.cuh; the generator asserts the bias tables):
+// Bounds (checked by hand per formula in h2v_curve28.hpp; the generator asserts the bias tables):
 //   an element is described by (v, lam):  value < v*p  and every limb < lam * 2^28  (top limb: whatever v implies)
 //   * f28_mul / f28_sqr need lam_a * lam_b <= 17 (14 products + 14 reduction terms per 64-bit column) and
 //     v_a * v_b <= 2048 = R/p-ish (R = 2^392), and return (2, 1)
@@ -14,9 +14,9 @@
 //   * f28_sub<K, M>(a, b) = a + (K p spread so that every limb >= M 2^28) - b needs v_b <= K - 1, lam_b <= M and
 //     returns (v_a + K, lam_a + M + 2)
 //   * f28_carry: limbs back below 2^28 (value unchanged): (v, 1)
-// Montgomery constant and domain are those of h2v_field.cuh (R = 2^392), so conversion is a re-cut of the limbs.
+// Montgomery constant and domain are those of h2v_field.hpp (R = 2^392), so conversion is a re-cut of the limbs.
 #pragma once
-#include "h2v_field.cuh"
+#include "h2v_field.hpp"
 
 struct F28 { uint32_t l[14]; };
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -38,7 +38,7 @@ H2V_DI F28 f28_unpack(const u32x4 a, const u32x4 b, const u32x4 c, const u32x2 d
     x.l[12] = d.x; x.l[13] = d.y;
     return x;
 }
-// out-of-line multiplier, operands and result in VGPRs (see the ABI note in h2v_field.cuh)
+// out-of-line multiplier, operands and result in VGPRs (see the ABI note in h2v_field.hpp)
 H2V_DN F28Regs f28_mul_raw(u32x4 a0, u32x4 a1, u32x4 a2, u32x2 a3, u32x4 b0, u32x4 b1, u32x4 b2, u32x2 b3) {
     const F28 a = f28_unpack(a0, a1, a2, a3), b = f28_unpack(b0, b1, b2, b3);
     F28 t;

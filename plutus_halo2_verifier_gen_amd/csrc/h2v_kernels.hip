@@ -11,10 +11,10 @@
 // calls (aiken-verifier/aiken_halo2/lib/{transcript,lagrange,halo2_kzg,bls_utils}.ak); hash plug-in
 // /root/reference/src/plutus_gen/adjusted_types/mod.rs:30-72.
 #include <hip/hip_runtime.h>
-#include "h2v_curve28.cuh"
+#include "h2v_curve28.hpp"
 #include "h2v_plan.h"
-#include "h2v_tower.cuh"
-#include "h2v_pairing_coop.cuh"
+#include "h2v_tower.hpp"
+#include "h2v_pairing_coop.hpp"
 
 // ============================================================================ blake2b-256 (RFC 7693)
 __device__ static constexpr uint64_t B2_IV[8] = {
@@ -237,7 +237,10 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
 #pragma unroll
             for (int l = 0; l < 8; l++)
                 b.v[l] = (uint32_t)p[4 * l] | ((uint32_t)p[4 * l + 1] << 8) | ((uint32_t)p[4 * l + 2] << 16) | ((uint32_t)p[4 * l + 3] << 24);
-            fr_to_mont(r, b);  // public inputs are field elements handed over by the caller: reduced mod r
+            // public inputs are field elements on the reference side (Rust F / Aiken State<Scalar>): only the canonical
+            // encoding exists there, so v + r is rejected here rather than verifying as a second encoding of v
+            if (FrF::geq_mod(b.v)) st |= H2V_ST_BAD_SCALAR;
+            fr_to_mont(r, b);
             if (live) rf.store(ins.dst, r);
         } break;
         case H2V_OP_READ_POINT: {
@@ -634,7 +637,7 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
     const uint32_t grp = FIX ? 0u : (term < ma.grp_end[0] ? 0u : (term < ma.grp_end[1] ? 1u : 2u));
     const uint32_t g_lo = grp == 0 ? 0u : ma.grp_end[grp - 1];
     const uint32_t gsub = FIX ? sub : sub - LPT * g_lo, glen = FIX ? lanes_per_proof : LPT * (ma.grp_end[grp] - g_lo);
-    // this lane's partial sum, on the lazily reduced field with an explicit infinity flag (h2v_curve28.cuh); idle
+    // this lane's partial sum, on the lazily reduced field with an explicit infinity flag (h2v_curve28.hpp); idle
     // lanes and skipped terms contribute the point at infinity
     G1J28 lad;
     bool lad_inf = true;
@@ -758,7 +761,7 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
                 g1_build_window_tables_glv(mine, base);
                 tab = mine;
             }
-            // The ladder runs on the lazily reduced 28-bit field (h2v_fp28.cuh / h2v_curve28.cuh) and is only ever
+            // The ladder runs on the lazily reduced 28-bit field (h2v_fp28.hpp / h2v_curve28.hpp) and is only ever
             // touched by inlined code, so `lad` stays in VGPRs.
             //
             // Exceptional additions.  The accumulator is [a]P + [b]phi(P) = [a + b lambda]P with (a, b) the signed

@@ -10,7 +10,7 @@
 // x^-1 = +-d.  Model and cross-check: tests/test_host_logic.py::test_safegcd_model.
 #pragma once
 #include <stdint.h>
-// (included by h2v_field.cuh after its H2V_DI / H2V_DN definitions)
+// (included by h2v_field.hpp after its H2V_DI / H2V_DN definitions)
 
 #define H2V_M30 0x3fffffff
 

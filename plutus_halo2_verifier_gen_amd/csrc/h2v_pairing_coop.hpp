@@ -19,10 +19,10 @@
 #pragma once
 #include "coop_program.h"
 #include "coop_tables.h"
-#include "h2v_curve.cuh"
-#include "h2v_fp28.cuh"
+#include "h2v_curve.hpp"
+#include "h2v_fp28.hpp"
 #include "h2v_plan.h"
-#include "h2v_tower.cuh"
+#include "h2v_tower.hpp"
 
 #define COOP_SLOT_DW 20                      // dwords per operand slot: 14 limbs + pad; 20 keeps 16-byte alignment and
                                              // spreads 16 consecutive slots over 16 distinct bank groups (stride 16
@@ -72,7 +72,7 @@ H2V_DI void coop_load28(uint32_t (&l)[14], const uint32_t *p) {
     l[8] = c.x; l[9] = c.y; l[10] = c.z; l[11] = c.w; l[12] = d.x; l[13] = d.y;
 }
 
-// Values between engine calls are lazily reduced F28 elements (h2v_fp28.cuh).  Bounds, in that header's (v, lam)
+// Values between engine calls are lazily reduced F28 elements (h2v_fp28.hpp).  Bounds, in that header's (v, lam)
 // notation:  every Fp12 variable has lam = 1 and v <= 6 (engine outputs 3, conj 6, frob 5, inverse 3; the
 // generated program is checked for this by tools/gen_coop_program.py).  Accumulator headroom: a lane's column sums
 // (terms per lane) x 14 products of (lam_x lam_y) 2^56, tripled for the cyclotomic squaring, plus 14 reduction products:

@@ -4,7 +4,7 @@
 // Karatsuba at every level (Fp2: 3 Fp mul, Fp6: 6 Fp2 mul, Fp12: 3 Fp6 mul), complex squaring for Fp2 and
 // Fp12, and a dedicated sparse product for the Miller-loop line  c + b w^2 + a w^3  (a in Fp).
 #pragma once
-#include "h2v_field.cuh"
+#include "h2v_field.hpp"
 
 struct Fp2 { Fp c0, c1; };
 struct Fp6 { Fp2 c0, c1, c2; };

@@ -56,7 +56,9 @@ TERM_PROOF_POINT, TERM_VK_BASE, TERM_COMMITTED_INSTANCE, TERM_ACC_POINT = 0, 1, 
 
 # ---- trace slots (same order as the oracle's trace struct; expressions start at TRACE_EXPR0)
 TRACE_NAMES = ["theta", "beta", "gamma", "trash", "y", "x", "x1", "x2", "x3", "x4", "x_prev", "x_next", "x_last", "xn",
-               "l_last", "l_0", "active_rows", "h_eval", "vanishing_s", "f_eval", "v"]
+               "l_last", "l_0", "active_rows", "h_eval", "vanishing_s", "f_eval", "v",
+               # only in plans compiled with legacy_no_trash_squeeze (the golden-proof replay of the GPU tests)
+               "advice_eval_1", "advice_eval_2", "advice_eval_3"]
 TRACE_EXPR0 = 32
 MAX_TRACE_EXPR = 256
 
@@ -100,6 +102,10 @@ class Plan:
     # large circuits): more lanes per proof, shorter chain, more waves.  (lanes, n_regs, instrs); the trace table
     # refers to the first schedule only.
     wide: Optional[Tuple[int, int, List[Tuple[int, int, int, int]]]] = None
+    # host-side record of the commitment map the compiler derived (pcs/mod.rs:36-109), not part of the blob: per
+    # commitment, in order, {commitment: (kind, idx), set: first-seen point-set index, sorted_set: position after the
+    # cardinality sort (aiken.rs:580-587), pairs: [(rotation, eval key)...]} - what tests compare with ProofData.hs
+    commitment_map: Optional[list] = None
 
     def __post_init__(self):
         if self.n_main_terms < 0:
@@ -250,7 +256,11 @@ def _rot_sort_key(rot):
     return (4, rot)
 
 
-def compile_plan(vk: VerifyingKey, lanes: Optional[int] = None) -> Plan:
+def compile_plan(vk: VerifyingKey, lanes: Optional[int] = None, legacy_no_trash_squeeze: bool = False) -> Plan:
+    """legacy_no_trash_squeeze (TEST ONLY): the proof layout before the `trash` challenge was added
+    (extraction_steps/proof.rs:68) - the layout of the reference's only in-tree full proof, transcript.ak:241-382 -
+    so that the GPU transcript kernel can be replayed against every challenge of that vector.  Only for keys without
+    trashcan arguments; the first three advice evaluations are added to the trace set."""
     b = _Builder()
     L = len(vk.lookups)
     Cn = vk.n_perm_chunks
@@ -325,7 +335,11 @@ def compile_plan(vk: VerifyingKey, lanes: Optional[int] = None) -> Plan:
     gamma = squeeze()
     perm_pts = [read_point("permutations_committed_%s" % chr(ord("a") + i)) for i in range(Cn)]
     lk_prod = [read_point("lookup_commitment_%d" % (i + 1)) for i in range(L)]
-    trash = squeeze()
+    if legacy_no_trash_squeeze:
+        assert n_trash == 0, "the legacy layout has no trashcan arguments"
+        trash = b.const(0)
+    else:
+        trash = squeeze()
     trash_pts = [read_point("trashcan_commitment_%d" % (i + 1)) for i in range(n_trash)]
     vanish_rand_pt = read_point("vanishing_rand")
     y = squeeze()
@@ -731,6 +745,9 @@ def compile_plan(vk: VerifyingKey, lanes: Optional[int] = None) -> Plan:
     named = {"theta": theta, "beta": beta, "gamma": gamma, "trash": trash, "y": y, "x": x, "x1": x1, "x2": x2,
              "x3": x3, "x4": x4, "x_last": x_last, "xn": xn, "l_last": l_last, "l_0": l_0,
              "active_rows": active_rows, "h_eval": h_eval, "vanishing_s": vanishing_s, "f_eval": f_eval, "v": v}
+    if legacy_no_trash_squeeze:
+        for i, r in enumerate(advice_eval[:3]):
+            named["advice_eval_%d" % (i + 1)] = r
     trace_virt = [(TRACE_NAMES.index(n), r) for n, r in named.items()]
     for i, e in enumerate(expressions[:MAX_TRACE_EXPR]):
         trace_virt.append((TRACE_EXPR0 + i, e))
@@ -747,6 +764,8 @@ def compile_plan(vk: VerifyingKey, lanes: Optional[int] = None) -> Plan:
         term_names=term_names, pi_point=pi_pt, lines_sg2=bls.g2_line_table(s_g2),
         lines_g2=bls.g2_line_table(bls.G2_GEN), trace=trace, n_squeezes=n_squeezes, stream_len=stream_len,
         n_main_terms=n_main_terms, acc_coords=acc_coords, vm_lanes=vm_lanes, wide=wide,
+        commitment_map=[{"commitment": ck, "set": set_of[ck], "sorted_set": sort_order.index(set_of[ck]),
+                         "pairs": list(cmap[ck])} for ck in commitments],
     )
     return plan
 
@@ -964,6 +983,8 @@ def run_plan(plan: Plan, proof: bytes, instances: List[int], committed: Optional
         elif op == OP_ABSORB_CI:
             acc += b"\x01" + committed
         elif op == OP_LOAD_INSTANCE:
+            if not 0 <= instances[a] < R:   # only the canonical encoding of a public input exists on the reference side
+                status = status or "scalar"
             regs[d] = instances[a] % R
         elif op == OP_READ_POINT:
             if stop_before_point is not None and n_points_read == stop_before_point:

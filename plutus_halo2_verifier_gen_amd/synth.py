@@ -235,7 +235,8 @@ def forge_batch(vk: VerifyingKey, td: Trapdoor, n: int, seed: int = 1, workers: 
 
 # ----------------------------------------------------------------------------- negative cases
 CORRUPTIONS = ("flip_first_scalar", "flip_last_scalar", "bad_point_flag", "point_not_on_curve", "point_not_in_subgroup",
-               "noncanonical_scalar", "wrong_public_input", "wrong_pi", "truncated", "infinity_commitment",
+               "noncanonical_scalar", "noncanonical_instance", "wrong_public_input", "wrong_pi", "truncated",
+               "infinity_commitment",
                # recursion (IVC) only; None for plans without an accumulator
                "acc_limb", "acc_scalar", "acc_fixed_scalar", "acc_sign", "acc_vk_hash")
 
@@ -288,6 +289,15 @@ def corrupt(plan: Plan, proof: bytes, inst: bytes, kind: str, rng: random.Random
         if v + R >= 1 << 256:
             v = 5
         buf[o:o + 32] = (v + R).to_bytes(32, "little")
+    elif kind == "noncanonical_instance":
+        # the same public input as v + r: one field element, a second 32-byte encoding the reference cannot express
+        if len(inst) == 0:
+            return None
+        k = rng.randrange(len(inst) // 32)
+        v = int.from_bytes(inst[32 * k:32 * k + 32], "little")
+        if v + R >= 1 << 256:
+            return None
+        inst[32 * k:32 * k + 32] = (v + R).to_bytes(32, "little")
     elif kind == "wrong_public_input":
         if len(inst) == 0:
             return None

@@ -206,15 +206,32 @@ def test_end_to_end_vs_oracle(be, circuits, name):
 
 def test_golden_transcript_on_gpu(be, kats, circuits):
     """The reference's full simple_mul proof (transcript.ak:241-382) replayed by the GPU transcript kernel.  The golden
-    proof predates the `trash` squeeze (proof.rs:68), so only the challenges squeezed before it are comparable:
-    theta/beta/gamma depend on repr, inputs and the first two commitments alone."""
+    proof predates the `trash` squeeze (proof.rs:68): with the current layout only theta/beta/gamma are comparable
+    (first half of this test); a test-only plan with the legacy layout (compile_plan(legacy_no_trash_squeeze=True))
+    replays ALL of it - gamma, y, x, the three advice evaluations, x1..x4 and pi - on the GPU."""
+    from plutus_halo2_verifier_gen_amd import plan as PL, vk as V
     vk, td, pl, dp, ov = circuits["simple_mul"]
     k = kats["simple_mul_full"]
+    H = lambda h: int(h, 16)
     proof = bytes.fromhex(k["proof"])
     inst = b"".join((42).to_bytes(32, "little") for _ in range(3))
     tr = dp.trace(proof, inst, None)
-    assert tr["scalars"][TRACE_NAMES.index("gamma")] == int(k["gamma"], 16)
+    assert tr["scalars"][TRACE_NAMES.index("gamma")] == H(k["gamma"])
     assert tr["accept"] == 0   # (different VK / layout: must not verify)
+    # the whole vector through the legacy layout, with the vector's own transcript representation
+    assert vk.transcript_repr == H(k["transcript_repr"])   # vk.py's simple_mul key carries the vector's representation
+    pl2 = PL.compile_plan(vk, legacy_no_trash_squeeze=True)
+    assert pl2.proof_len == 1120
+    dp2 = be.DevicePlan(pl2.to_bytes(), 0)
+    tr2 = dp2.trace(proof, inst, None)
+    sc = {PL.TRACE_NAMES[s]: v for s, v in tr2["scalars"].items() if s < PL.TRACE_EXPR0}
+    for name in ("gamma", "y", "x", "advice_eval_1", "advice_eval_2", "advice_eval_3", "x1", "x2", "x3", "x4"):
+        assert sc[name] == H(k[name]), name
+    assert tr2["el"] == bls.g1_decompress(bytes.fromhex(k["pi"]))          # el = pi
+    assert not (tr2["status"] & (be.ST_BAD_SCALAR | be.ST_SHORT_PROOF | be.ST_BAD_POINT))   # every element parses
+    # the batch path (multi-lane schedule, LDS register file) reads the same proof: rejected by the pairing only
+    got = dp2.verify_batch(proof * 3, [0, 1120, 2240, 3360], inst * 3, None)
+    assert list(got) == [0, 0, 0]
 
 
 def test_api_errors(be, circuits):
@@ -231,6 +248,21 @@ def test_api_errors(be, circuits):
         be.DevicePlan(bytes(bad), 0)
     # empty batch is fine
     assert dp.verify_batch(b"", [0], b"", None) == b""
+    # a workspace is sized from the plan it was created for: a larger plan (more terms / point slots, recursion
+    # buffers) must get H2V_E_ARG, not device memory corruption; a smaller plan may reuse it
+    from plutus_halo2_verifier_gen_amd import synth
+    ws_small = be.Workspace(dp, 8)
+    for other in ("lookup_table", "ivc"):
+        vk2, td2, pl2, dp2, ov2 = circuits[other]
+        b2 = synth.forge_batch(vk2, td2, 2, seed=3, plan=pl2, workers=1)
+        with pytest.raises(be.H2VError, match="workspace"):
+            dp2.verify_batch(b2.proofs, b2.proof_off, b2.instances, b2.committed, ws=ws_small)
+    vk2, td2, pl2, dp2, ov2 = circuits["lookup_table"]
+    ws_big = be.Workspace(dp2, 8)
+    b1 = synth.forge_batch(vk, td, 4, seed=3, plan=pl, workers=1)
+    assert list(dp.verify_batch(b1.proofs, b1.proof_off, b1.instances, b1.committed, ws=ws_big)) == [1, 1, 1, 1]
+    with pytest.raises(be.H2VError):   # offsets beyond the bytes handed over
+        dp.verify_batch(b1.proofs[:-1], b1.proof_off, b1.instances, b1.committed)
 
 
 def _permute(batch, order, n_pi):

@@ -62,6 +62,7 @@ def test_forged_proofs_accept_and_corruptions_reject(orc, name):
     n_pi = vk.n_public_inputs
     expected_status = {"flip_first_scalar": "pairing", "flip_last_scalar": "pairing", "bad_point_flag": "point",
                        "point_not_on_curve": "point", "point_not_in_subgroup": "point", "noncanonical_scalar": "scalar",
+                       "noncanonical_instance": "scalar",
                        "wrong_public_input": "pairing", "wrong_pi": "pairing", "truncated": "short",
                        "infinity_commitment": "pairing", "acc_limb": "point", "acc_scalar": "pairing",
                        "acc_fixed_scalar": "pairing", "acc_sign": "pairing", "acc_vk_hash": "recursion"}
@@ -99,6 +100,21 @@ def test_plan_interpreter_matches_oracle_trace(simple, orc):
         for kind, idx in pl.terms:
             bases.append(pts[idx] if kind == PL.TERM_PROOF_POINT else pl.vk_bases[idx])
         assert orc.g1_msm(scal, bases) == tr.point("er")
+
+
+def test_legacy_layout_replays_the_golden_proof(simple, kats):
+    """compile_plan(legacy_no_trash_squeeze=True) is the layout of the reference's in-tree proof (transcript.ak:241-382):
+    the plan interpreter reproduces every value of that vector (the GPU test replays the same plan on the device)."""
+    vk, td, pl, ov = simple
+    k = kats["simple_mul_full"]
+    pl2 = PL.compile_plan(vk, legacy_no_trash_squeeze=True)
+    assert pl2.proof_len == 1120 and pl2.n_squeezes == pl.n_squeezes - 1
+    scal, regs, status = PL.run_plan(pl2, bytes.fromhex(k["proof"]), [42, 42, 42], None)
+    assert status is None
+    got = {PL.TRACE_NAMES[s]: regs[r] for s, r in pl2.trace if s < PL.TRACE_EXPR0}
+    for name in ("gamma", "y", "x", "advice_eval_1", "advice_eval_2", "advice_eval_3", "x1", "x2", "x3", "x4"):
+        assert got[name] == int(k[name], 16), name
+    assert pl2.points[pl2.pi_point] == 1120 - 48 and bytes.fromhex(k["proof"])[-48:] == bytes.fromhex(k["pi"])
 
 
 def test_plan_rejects_in_interpreter(simple):
@@ -218,7 +234,7 @@ def test_sharded_verify_two_ranks_gloo(tmp_path):
 
 
 def test_safegcd_model():
-    """Integer model of csrc/h2v_modinv.cuh (30 division steps per batch on the low words, transition matrix applied
+    """Integer model of csrc/h2v_modinv.hpp (30 division steps per batch on the low words, transition matrix applied
     to (f, g) and, modulo M with exact division by 2^30, to (d, e)) with the constants the device header carries:
     every intermediate stays inside the 64-bit / 32-bit ranges the kernel code assumes, the loop ends within the
     kernel's batch limit and the result is the modular inverse."""

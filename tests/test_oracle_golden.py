@@ -150,25 +150,108 @@ def test_proofdata_points_match_golden_proof(kats, orc):
         assert ok and pt == (H(pts[name][0]), H(pts[name][1])), name
 
 
+# Which queries the "pow2range column check" lookup of the ATMS-with-lookups circuit reads
+# (/root/reference/src/circuits/atms_with_lookups_circuit.rs:89-94: input = [tag, sel * val], table = [t_tag, t_val]).
+# The rendered query numbers exist only in the Rust build; they were recovered by exhaustive search over all
+# 21 * 21 * 11 * 21 * 21 assignments against lookup_expression_3_1 (tools/find_lookup_queries.py): exactly one fits.
+ATMS_LOOKUP_QUERIES = {"tag": 13, "sel": 20, "val": 10, "t_tag": 14, "t_val": 15}   # 0-based fixed / advice eval indices
+
+
 def test_lookup_identities(kats, orc):
-    """gates_test.hbs:9-25 inputs -> :75-79 outputs, identities 1,2,4,5 (identity 3 and gate_eq* need the ATMS
-    gate strings that only the Rust build renders: SURVEY.md §8c)."""
+    """gates_test.hbs:9-25 inputs -> :75-79 outputs through the lookup block orc_verify itself runs
+    (h2v_oracle.c: lookup_argument = theta-compression + the five identities).  All FIVE identities are checked:
+    identity 3 through the unique query assignment above.  gate_eq1..5 stay unpinned (they need the ATMS gate strings
+    that only the Rust build renders: SURVEY.md 8c)."""
     from plutus_halo2_verifier_gen_amd import vk as V
     i = {n: H(v) for n, v in kats["lookup_identities"]["inputs"].items()}
     e = {n: H(v) for n, v in kats["lookup_identities"]["expected"].items()}
-    # advice query slots: 0 l_0, 1 l_last, 2 active_rows, 3 product, 4 product_next, 5 permuted_input,
-    # 6 permuted_input_inv, 7 permuted_table
-    adv = [i["evaluation_at_0"], i["last_evaluation"], i["active_rows"], i["product_eval_1"], i["product_next_eval_1"],
-           i["permuted_input_eval_1"], i["permuted_input_inv_eval_1"], i["permuted_table_eval_1"]]
-    a = V.advice
-    l1 = V.mul(a(0), V.sub(V.const(1), a(3)))
-    l2 = V.mul(a(1), V.sub(V.mul(a(3), a(3)), a(3)))
-    l4 = V.mul(a(0), V.sub(a(5), a(7)))
-    l5 = V.mul(V.mul(V.sub(a(5), a(7)), V.sub(a(5), a(6))), a(2))
-    assert orc.eval_expr(l1, adv, []) == e["lookup_expression_1_1"]
-    assert orc.eval_expr(l2, adv, []) == e["lookup_expression_2_1"]
-    assert orc.eval_expr(l4, adv, []) == e["lookup_expression_4_1"]
-    assert orc.eval_expr(l5, adv, []) == e["lookup_expression_5_1"]
+    adv = [i["advice_eval_%d" % k] for k in range(1, 12)]
+    fix = [i["fixed_eval_%d" % k] for k in range(1, 22)]
+    q = ATMS_LOOKUP_QUERIES
+    inputs = [V.fixed(q["tag"]), V.mul(V.fixed(q["sel"]), V.advice(q["val"]))]
+    table = [V.fixed(q["t_tag"]), V.fixed(q["t_val"])]
+    got = orc.lookup_argument(inputs, table, adv, fix, i["theta"], i["beta"], i["gamma"], i["evaluation_at_0"],
+                              i["last_evaluation"], i["active_rows"],
+                              [i["product_eval_1"], i["product_next_eval_1"], i["permuted_input_eval_1"],
+                               i["permuted_input_inv_eval_1"], i["permuted_table_eval_1"]])
+    assert got == [e["lookup_expression_%d_1" % k] for k in range(1, 6)]
+    # the assignment is the only one: a different table column breaks identity 3 and nothing else
+    other = orc.lookup_argument(inputs, [V.fixed(q["t_tag"]), V.fixed(q["t_val"] + 1)], adv, fix, i["theta"], i["beta"],
+                                i["gamma"], i["evaluation_at_0"], i["last_evaluation"], i["active_rows"],
+                                [i["product_eval_1"], i["product_next_eval_1"], i["permuted_input_eval_1"],
+                                 i["permuted_input_inv_eval_1"], i["permuted_table_eval_1"]])
+    assert other[2] != got[2] and other[:2] + other[3:] == got[:2] + got[3:]
+
+
+def _golden_commitment_map(kats):
+    """ProofData.hs:184-197 as (commitment key, first-seen set index, {(rotation, eval key)}) in commitment order."""
+    names = {"a1": ("advice", 0), "a2": ("advice", 1), "permutations_committed_a": ("perm", 0),
+             "permutations_committed_b": ("perm", 1), "permutations_committed_c": ("perm", 2),
+             "f1_commitment": ("fixed", 0), "f2_commitment": ("fixed", 1), "p1_commitment": ("common", 0),
+             "p2_commitment": ("common", 1), "p3_commitment": ("common", 2), "vanishing_g": ("vanishing_g", 0),
+             "vanishingRand": ("vanishing_rand", 0)}
+    rots = {"x_current": "cur", "x_next": "next", "x_last": "last"}
+
+    def ev(name):
+        import re
+        m = re.fullmatch(r"adviceEval(\d)", name)
+        if m:
+            return ("advice", int(m.group(1)) - 1)
+        m = re.fullmatch(r"fixedEval(\d)", name)
+        if m:
+            return ("fixed", int(m.group(1)) - 1)
+        m = re.fullmatch(r"permutationCommon(\d)", name)
+        if m:
+            return ("common", int(m.group(1)) - 1)
+        m = re.fullmatch(r"permutations_evaluated_([abc])_(\d)", name)
+        if m:
+            return ("perm", "abc".index(m.group(1)), int(m.group(2)))
+        return {"vanishing_s": ("vanishing_s",), "randomEval": ("random",)}[name]
+
+    out = []
+    for entry in kats["multiopen"]["commitment_map"]:
+        out.append((names[entry["commitment"]], entry["set"],
+                    frozenset((rots[p], ev(v)) for p, v in zip(entry["points"], entry["evals"]))))
+    return out
+
+
+def test_commitment_map_matches_proofdata(kats, orc):
+    """build_sets (oracle) and plan.py's commitment map for the simple_mul key against the reference-held
+    commitmentMap of plinth-verifier/plutus-halo2/test/ProofData.hs:184-197: commitment ORDER (the x1 powers),
+    first-seen point-set index of every commitment (before the cardinality sort of aiken.rs:580-587, which the
+    fixture predates) and which evaluation pairs with which rotation.  Forged proofs cannot see a wrong order inside a
+    set, so this vector is what pins it."""
+    import json
+    from plutus_halo2_verifier_gen_amd import plan as PL, vk as V
+    want = _golden_commitment_map(kats)
+    vk, td = V.simple_mul_vk()
+    ov = orc.OracleVK(orc.vk_desc(json.loads(vk.to_json()), vk.omega, vk.omega_inv, vk.barycentric_weight))
+    got_o = []
+    for c in ov.commitment_map():
+        pairs = set()
+        for rot, (ek, eidx, esub) in c["pairs"]:
+            key = {"advice": ("advice", eidx), "fixed": ("fixed", eidx), "common": ("common", eidx),
+                   "perm": ("perm", eidx, esub), "vanishing_s": ("vanishing_s",), "random": ("random",)}[ek]
+            pairs.add((rot, key))
+        got_o.append((c["commitment"], c["set"], frozenset(pairs)))
+    assert got_o == want
+    pl = PL.compile_plan(vk)
+    rot_name = {0: "cur", 1: "next", -1: "prev", PL.ROT_LAST: "last"}
+    got_p = []
+    for c in pl.commitment_map:
+        pairs = set()
+        for rot, ek in c["pairs"]:
+            key = ("perm", ek[1], ek[2] + 1) if ek[0] == "perm" else tuple(ek)
+            pairs.add((rot_name[rot], key))
+        got_p.append((tuple(c["commitment"]), c["set"], frozenset(pairs)))
+    assert got_p == want
+    # and the two builders agree on the order after the cardinality sort, for every circuit shape
+    for name, build in V.BUILDERS.items():
+        k2, _ = build()
+        o2 = orc.OracleVK(orc.vk_desc(json.loads(k2.to_json()), k2.omega, k2.omega_inv, k2.barycentric_weight))
+        p2 = PL.compile_plan(k2)
+        assert [(c["commitment"], c["set"], c["sorted_set"]) for c in o2.commitment_map()] == \
+               [(tuple(c["commitment"]), c["set"], c["sorted_set"]) for c in p2.commitment_map], name
 
 
 def test_fr_inverse(orc):

@@ -40,7 +40,7 @@ def build_program():
         line += n
     assert line == 68
     # x < 0: the Miller value is m = conj(F).  Easy part m^(p^6-1) = conj(m) * m^-1 = F * conj(F^-1); written so that
-    # every CONJ / INV operand is an engine output (the lazily reduced field bounds of h2v_pairing_coop.cuh).
+    # every CONJ / INV operand is an engine output (the lazily reduced field bounds of h2v_pairing_coop.hpp).
     e(OP_CONJ, U, F)
     e(OP_DUMP, 0, U)
     e(OP_INV, A, F)
@@ -78,7 +78,7 @@ def build_program():
 
 
 def check_bounds(prog):
-    """Static check of the value bounds the kernel's lazily reduced field relies on (h2v_pairing_coop.cuh): with
+    """Static check of the value bounds the kernel's lazily reduced field relies on (h2v_pairing_coop.hpp): with
     `v` = the multiple of p a variable may reach, engine results are 3, CONJ needs v <= 5 and gives 6, FROB gives 5,
     and every staged operand needs v <= 6."""
     v = [None] * N_VARS
