@@ -19,9 +19,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# Integer-multiply issue ceiling measured on this chip with tools/ubench/imad.hip: v_mad_u64_u32 sustains one
-# wave-instruction per 5.4 cycles per SIMD at >= 2 waves/SIMD  ->  1024 SIMDs * 64 lanes * 2.4e9 / 5.4 lane-mads/s.
-IMAD_PEAK_TOPS = 1024 * 64 * 2.4e9 / 5.4 / 1e12
+# Integer-multiply issue ceiling: MEASURED on this chip with tools/ubench/imad.hip
+# (hipcc --offload-arch=gfx950 -O3 tools/ubench/imad.hip -o imad && ./imad > profiles/rNN_imad_ubench.txt); the kept
+# stdout is read here: cycles per v_mad_u64_u32 wave-instruction per SIMD at 4 waves per SIMD (2.4 GHz, 1024 SIMDs).
+# No file, no peak: int_roofline.peak / frac are null rather than a remembered constant.
+
+
+def imad_peak():
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_imad_ubench.txt")), key=os.path.getmtime)
+    if not files:
+        return None, None
+    cyc, sect = None, None
+    for line in open(files[-1]):
+        m = re.match(r"--- (\d+) wave", line)
+        if m:
+            sect = int(m.group(1))
+        m = re.match(r"mad_u64_u32 .*~([0-9.]+) cycles", line)
+        if m and sect == 4:
+            cyc = float(m.group(1))
+    if not cyc:
+        return None, None
+    return 1024 * 64 * 2.4e9 / cyc / 1e12, os.path.basename(files[-1])
+
+
+IMAD_PEAK_TOPS, IMAD_PEAK_SOURCE = imad_peak()
 # v_mad_u64_u32 per field operation (csrc/h2v_field.hpp): product-scanning multiply 392, square 301
 MAD_MUL, MAD_SQR = 392, 301
 MAD_DBL = 2 * MAD_MUL + 5 * MAD_SQR          # dbl-2009-l
@@ -216,7 +239,8 @@ def main():
         def int_roof(k):
             tops = mads[k] / (kernel_ms[k] * 1e-3) / 1e12 if kernel_ms[k] > 0 else 0.0
             return {"kernel": kname[k], "bound": "int-mad issue (measured v_mad_u64_u32 ceiling)", "achieved": round(tops, 3),
-                    "peak": round(IMAD_PEAK_TOPS, 2), "unit": "T lane-mad/s", "frac": round(tops / IMAD_PEAK_TOPS, 4),
+                    "peak": round(IMAD_PEAK_TOPS, 2) if IMAD_PEAK_TOPS else None, "peak_source": IMAD_PEAK_SOURCE,
+                    "unit": "T lane-mad/s", "frac": round(tops / IMAD_PEAK_TOPS, 4) if IMAD_PEAK_TOPS else None,
                     "mads_per_launch": mads[k] // launches}
 
         dominant = max(kernel_ms, key=kernel_ms.get)

@@ -100,6 +100,34 @@ int h2v_verify_batch(const h2v_plan *plan, const h2v_batch *batch, uint8_t *acce
 int h2v_verify_batch_device(const h2v_plan *plan, const h2v_batch *batch, uint8_t *accept, uint32_t *status,
                             h2v_workspace *ws, void *stream, h2v_timings *timings);
 
+/* ---- batch-accept fast path: random linear combination (RLC) of the batch's pairing equations -------------------
+ * Same inputs and the same accept[] / status[] outputs as h2v_verify_batch(_device).  Instead of one MSM and one pairing
+ * per proof, the batch is folded with 128-bit coefficients r_i (blake2b-256(seed || i), seed from the OS unless given)
+ * into ONE check  e(sum_i r_i pi_i, s_g2) == e(sum_i r_i er_i, G2)  - the dual-MSM form of
+ * aiken-verifier/aiken_halo2/lib/halo2_kzg.ak:37-43 and the pairing equation of verification_h2.hbs:125-128 summed over
+ * the batch - computed by a bucketed (Pippenger) G1 MSM over every per-proof point of the batch.  Proofs that are rejected
+ * before the pairing (malformed encodings, points off the curve or outside G1, inverse of zero ...) are rejected
+ * individually and take no part in the combination.  If the batch check fails, the per-proof MSM and pairing kernels run
+ * for the whole batch, so accept[] is always what the per-proof mode returns, except with probability <= 2^-128 over the
+ * seed (a rejecting proof hidden by the combination).  Recursive (IVC) plans have no batch form and run per proof.
+ * ws must not be NULL for the device form. */
+#define H2V_RLC_SEED_GIVEN 1u
+typedef struct {
+    uint8_t seed[32];   /* used when flags & H2V_RLC_SEED_GIVEN (tests, reproducible runs); must be unpredictable to provers */
+    uint32_t flags;
+} h2v_rlc_opts;
+typedef struct {
+    float transcript_combiner_ms, g1_decompress_ms, prepare_ms, bucket_sort_ms, bucket_accumulate_ms, bucket_reduce_ms,
+          pairing_ms, total_ms;   /* total: first phase-1 launch .. the batch verdict (a fall-back run is not included) */
+    uint32_t msm_terms, window_bits, windows, lanes_per_bucket;   /* shape of the right-hand bucket MSM */
+} h2v_rlc_timings;
+int h2v_verify_batch_rlc(const h2v_plan *plan, const h2v_batch *batch, uint8_t *accept, h2v_workspace *ws,
+                         const h2v_rlc_opts *opts /* or NULL */, int *fell_back /* or NULL: 1 = the per-proof kernels ran */);
+int h2v_verify_batch_rlc_device(const h2v_plan *plan, const h2v_batch *batch, uint8_t *accept, uint32_t *status,
+                                h2v_workspace *ws, void *stream, const h2v_rlc_opts *opts /* or NULL */);
+/* after synchronising the stream of an RLC call: the batch verdict (1 = passed) and the kernel times of that call */
+int h2v_workspace_rlc_result(h2v_workspace *ws, uint32_t calls_back, uint32_t *batch_accepted, h2v_rlc_timings *timings);
+
 /* ---- parity / debugging surface ----------------------------------------------------------------------------
  * The reference's own intermediate-value trace (cargo feature plutus_debug, src/plutus_gen/emitters/plinth.rs:792-831):
  * theta, beta, gamma, x, y, hEval, vanishing_s, ..., every expression_i, plus el / er.
@@ -117,6 +145,10 @@ int h2v_probe_g1_decompress(int device, uint32_t n, const uint8_t *compressed, u
 /* sum_t s_t * B_t per group: n groups of T terms; scalars n*T*32 B LE, bases n*T*48 B compressed; out n*96 B affine BE */
 int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_t *scalars, const uint8_t *bases_compressed,
                      uint8_t *out_xy_be);
+/* the bucket (Pippenger) MSM of the RLC mode on its own: sum_n s_n * B_n; scalars n*32 B LE (< r), bases n*48 B compressed
+ * (encodings that do not decompress count as infinity); out 96 B affine BE (all-zero = infinity) */
+int h2v_probe_g1_msm_pippenger(int device, uint32_t n, const uint8_t *scalars, const uint8_t *bases_compressed,
+                               uint8_t *out_xy_be);
 /* e(p1, s_g2 of plan) == e(p2, G2) for n pairs of compressed G1 points; out[i] = 1/0 */
 int h2v_probe_pairing(const h2v_plan *plan, uint32_t n, const uint8_t *p1_compressed, const uint8_t *p2_compressed,
                       uint8_t *out);

@@ -86,9 +86,12 @@ class Verifier:
         return self._ws
 
     def verify_batch(self, proofs: Sequence[bytes], instances: Sequence[Sequence[int]],
-                     committed: Optional[Sequence[Optional[bytes]]] = None) -> List[bool]:
+                     committed: Optional[Sequence[Optional[bytes]]] = None, mode: str = "per-proof",
+                     seed: Optional[bytes] = None) -> List[bool]:
         """accept[i] for n independent proofs of this circuit (instances[i]: the public-input scalars of proof i;
-        committed[i]: its committed instance as 48 compressed bytes, when the circuit has one)."""
+        committed[i]: its committed instance as 48 compressed bytes, when the circuit has one).
+        mode="rlc": the batch-accept fast path (one bucket MSM + one pairing for the batch, per-proof kernels only if
+        the batch check fails; same accept vector up to a 2^-128 soundness error over `seed`, drawn from the OS when None)."""
         n = len(proofs)
         if n == 0:
             return []
@@ -107,7 +110,12 @@ class Verifier:
             if committed is None or len(committed) != n:
                 raise ValueError("this circuit takes one committed instance per proof")
             ci = b"".join(bls.g1_compress(None) if c is None else bytes(c) for c in committed)
-        acc = self.device_plan.verify_batch(b"".join(proofs), off, inst, ci, ws=self._workspace(n))
+        if mode == "rlc":
+            acc, _fell_back = self.device_plan.verify_batch_rlc(b"".join(proofs), off, inst, ci, ws=self._workspace(n), seed=seed)
+        elif mode == "per-proof":
+            acc = self.device_plan.verify_batch(b"".join(proofs), off, inst, ci, ws=self._workspace(n))
+        else:
+            raise ValueError("mode is 'per-proof' or 'rlc'")
         return [bool(a) for a in acc]
 
 

@@ -30,10 +30,34 @@ class Timings(C.Structure):
                 ("msm_lanes_per_term", C.c_uint32)]
 
 
+class RlcOpts(C.Structure):
+    _fields_ = [("seed", C.c_uint8 * 32), ("flags", C.c_uint32)]
+
+
+class RlcTimings(C.Structure):
+    _fields_ = [("transcript_combiner_ms", C.c_float), ("g1_decompress_ms", C.c_float), ("prepare_ms", C.c_float),
+                ("bucket_sort_ms", C.c_float), ("bucket_accumulate_ms", C.c_float), ("bucket_reduce_ms", C.c_float),
+                ("pairing_ms", C.c_float), ("total_ms", C.c_float), ("msm_terms", C.c_uint32),
+                ("window_bits", C.c_uint32), ("windows", C.c_uint32), ("lanes_per_bucket", C.c_uint32)]
+
+
+RLC_SEED_GIVEN = 1
+
+
+def _rlc_opts(seed):
+    if seed is None:
+        return None
+    seed = bytes(seed)
+    if len(seed) != 32:
+        raise ValueError("the RLC seed is 32 bytes")
+    return RlcOpts((C.c_uint8 * 32)(*seed), RLC_SEED_GIVEN)
+
+
 EXPORTS = [
     "h2v_plan_load", "h2v_plan_free", "h2v_plan_info", "h2v_workspace_create", "h2v_workspace_free",
     "h2v_workspace_timings",
-    "h2v_verify_batch", "h2v_verify_batch_device", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
+    "h2v_verify_batch", "h2v_verify_batch_device", "h2v_verify_batch_rlc", "h2v_verify_batch_rlc_device",
+    "h2v_workspace_rlc_result", "h2v_probe_g1_msm_pippenger", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
     "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_pairing", "h2v_probe_pairing_ex",
     "h2v_last_error", "h2v_build_id",
     "h2v_device_count",
@@ -61,6 +85,12 @@ def lib():
         L.h2v_verify_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
         L.h2v_verify_batch_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.POINTER(Timings)]
+        L.h2v_verify_batch_rlc.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.POINTER(RlcOpts),
+                                           C.POINTER(C.c_int)]
+        L.h2v_verify_batch_rlc_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.POINTER(RlcOpts)]
+        L.h2v_workspace_rlc_result.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(RlcTimings)]
+        L.h2v_probe_g1_msm_pippenger.argtypes = [C.c_int, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p]
         L.h2v_plan_trace_slots.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
         L.h2v_trace.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
@@ -115,7 +145,7 @@ class DevicePlan:
             pass
 
     # ---- host-buffer batch verify
-    def verify_batch(self, proofs: bytes, proof_off, instances: bytes, committed: Optional[bytes], ws=None) -> bytes:
+    def _host_batch(self, proofs: bytes, proof_off, instances: bytes, committed: Optional[bytes]):
         n = len(proof_off) - 1
         if n < 0 or any(proof_off[i + 1] < proof_off[i] for i in range(n)) or (n >= 0 and proof_off[0] < 0):
             raise H2VError("proof offsets must be non-decreasing")
@@ -132,9 +162,31 @@ class DevicePlan:
         b = Batch(n, C.cast(pbuf, C.c_void_p), C.cast(off, C.c_void_p),
                   C.cast(ibuf, C.c_void_p) if ibuf is not None else None,
                   C.cast(cbuf, C.c_void_p) if cbuf is not None else None)
+        return n, b, (off, pbuf, ibuf, cbuf)   # (the buffers must outlive the call)
+
+    def verify_batch(self, proofs: bytes, proof_off, instances: bytes, committed: Optional[bytes], ws=None) -> bytes:
+        n, b, _keep = self._host_batch(proofs, proof_off, instances, committed)
         acc = (C.c_uint8 * max(1, n))()
         check(lib().h2v_verify_batch(self._h, C.byref(b), acc, ws.handle if ws else None))
         return bytes(acc[:n])
+
+    def verify_batch_rlc(self, proofs: bytes, proof_off, instances: bytes, committed: Optional[bytes], ws=None,
+                         seed: Optional[bytes] = None):
+        """Batch-accept fast path (h2v_verify_batch_rlc): returns (accept bytes, fell_back)."""
+        n, b, _keep = self._host_batch(proofs, proof_off, instances, committed)
+        acc = (C.c_uint8 * max(1, n))()
+        fb = C.c_int(0)
+        opts = _rlc_opts(seed)
+        check(lib().h2v_verify_batch_rlc(self._h, C.byref(b), acc, ws.handle if ws else None,
+                                         C.byref(opts) if opts is not None else None, C.byref(fb)))
+        return bytes(acc[:n]), bool(fb.value)
+
+    def verify_batch_rlc_device(self, n, d_proofs, d_off, d_inst, d_ci, d_accept, d_status=None, ws=None, stream=None,
+                                seed: Optional[bytes] = None):
+        b = Batch(n, d_proofs, d_off, d_inst, d_ci)
+        opts = _rlc_opts(seed)
+        check(lib().h2v_verify_batch_rlc_device(self._h, C.byref(b), d_accept, d_status, ws.handle if ws else None, stream,
+                                                C.byref(opts) if opts is not None else None))
 
     # ---- device-resident batch verify (pointers = torch tensor data_ptr())
     def verify_batch_device(self, n, d_proofs, d_off, d_inst, d_ci, d_accept, d_status=None, ws=None, stream=None,
@@ -178,6 +230,13 @@ class Workspace:
         tm = Timings()
         check(lib().h2v_workspace_timings(self._h, calls_back, C.byref(tm)))
         return tm
+
+    def rlc_result(self, calls_back: int = 0, timings: bool = True):
+        """(batch check passed?, RlcTimings) of a past RLC call on this workspace; synchronise its stream first."""
+        ok = C.c_uint32(0)
+        tm = RlcTimings() if timings else None
+        check(lib().h2v_workspace_rlc_result(self._h, calls_back, C.byref(ok), C.byref(tm) if timings else None))
+        return bool(ok.value), tm
 
     def close(self):
         if getattr(self, "_h", None):
@@ -236,6 +295,15 @@ def probe_g1_msm(scalar_groups, base_groups, device: int = 0):
     out = C.create_string_buffer(96 * n)
     check(lib().h2v_probe_g1_msm(device, n, T, sc, bs, out))
     return [_unxy(out.raw[96 * i:96 * i + 96]) for i in range(n)]
+
+
+def probe_g1_msm_pippenger(scalars, bases_compressed, device: int = 0):
+    """sum_n s_n * B_n through the bucket MSM (scalars: ints < r; bases: 48-byte compressed)."""
+    n = len(scalars)
+    sc = b"".join(int(s).to_bytes(32, "little") for s in scalars)
+    out = C.create_string_buffer(96)
+    check(lib().h2v_probe_g1_msm_pippenger(device, n, sc, b"".join(bases_compressed), out))
+    return _unxy(out.raw)
 
 
 def probe_pairing(plan: DevicePlan, p1_list, p2_list):

@@ -82,6 +82,7 @@ struct h2v_workspace {
     hipEvent_t ring[RING][MAXP][NEV] = {};
     uint8_t ring_pipes[RING] = {}, ring_split[RING] = {}, ring_lpt[RING] = {};
     uint64_t calls = 0;
+    struct RlcWs *rlc = nullptr;   // buffers of the RLC batch mode, created by its first call
 };
 
 // LDS left for the combiner's register file in a block: 160 KB minus the 8 KB hash buffer and 1 KB of slack
@@ -342,8 +343,10 @@ extern "C" int h2v_plan_trace_slots(const h2v_plan *p, uint32_t *slot_ids, uint3
 }
 
 // ---------------------------------------------------------------------------------------------- workspace
+static void rlc_release(struct RlcWs *r);
 static void ws_release(h2v_workspace *w) {
     (void)hipSetDevice(w->device);
+    if (w->rlc) { rlc_release(w->rlc); w->rlc = nullptr; }
     void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->er_fix, w->dec_ctr, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off, w->msm_tab,
                     w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2, w->pt_tab};
     for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -572,9 +575,9 @@ static void launch_ivc_fold(const H2vDevPlan &d, uint32_t n, const uint32_t *pts
 // Pairing kernel selection: the cooperative 16-lanes-per-proof kernel is the product path; the one-lane-per-proof
 // kernel stays as a cross-check (H2V_PAIRING=legacy, or impl = 0 in the probe).
 static void launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
-                                const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st) {
+                                const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st, const uint32_t *skip = nullptr) {
     if (impl == 0) hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
-    else hipLaunchKernelGGL(k_pairing_coop, dim3((n + 1) / 2), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
+    else hipLaunchKernelGGL(k_pairing_coop, dim3((n + 1) / 2), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, skip);
 }
 static void launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
                            const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st) {
@@ -849,6 +852,280 @@ extern "C" int h2v_verify_batch(const h2v_plan *p, const h2v_batch *b, uint8_t *
     return rc;
 }
 
+
+// ---------------------------------------------------------------------------------------------- bucket MSM (Pippenger)
+// Device buffers of one bucket MSM over at most cap_n terms (h2v_pippenger.hpp).
+struct PipWs {
+    uint32_t cap_n = 0, cap_halves = 0;
+    uint32_t *pts28 = nullptr, *cnt = nullptr, *off = nullptr, *order = nullptr, *list = nullptr, *partial = nullptr, *wsum = nullptr;
+    int16_t *dig = nullptr;
+};
+static void pip_free(PipWs &w) {
+    void *ptrs[] = {w.pts28, w.cnt, w.off, w.order, w.list, w.partial, w.wsum, w.dig};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    w = PipWs();
+}
+static int pip_alloc(PipWs &w, uint32_t cap_n, uint32_t halves) {
+    const size_t nbmax = (size_t)PIP_MAX_W * (1u << (PIP_MAX_C - 1));
+    const size_t ent = (size_t)cap_n * halves * PIP_MAX_W;
+    w.cap_n = cap_n; w.cap_halves = halves;
+    bool ok = hipMalloc((void **)&w.pts28, (size_t)(cap_n ? cap_n : 1) * PIP_PT_DW * 4) == hipSuccess &&
+              hipMalloc((void **)&w.dig, (ent ? ent : 1) * 2) == hipSuccess && hipMalloc((void **)&w.list, (ent ? ent : 1) * 4) == hipSuccess &&
+              hipMalloc((void **)&w.cnt, nbmax * 4) == hipSuccess && hipMalloc((void **)&w.off, (nbmax + 1) * 4) == hipSuccess &&
+              hipMalloc((void **)&w.order, nbmax * 4) == hipSuccess && hipMalloc((void **)&w.partial, nbmax * PIP_PART_DW * 4) == hipSuccess &&
+              hipMalloc((void **)&w.wsum, (size_t)PIP_MAX_W * PIP_PART_DW * 4) == hipSuccess;
+    if (!ok) { pip_free(w); return fail(H2V_E_DEVICE, "hipMalloc(bucket MSM workspace) failed"); }
+    return H2V_OK;
+}
+// Window width and lanes per bucket for n terms.  Larger windows mean fewer windows (W = floor(128 / c) + 1 per GLV half)
+// but 2^(c-1) buckets per window, capped at 512 so that one block's LDS holds a window in k_pip_reduce; a bucket's slice
+// is shared by 2^lpb lanes so that the launch has about one wave per SIMD (chains shorter than ~4 additions are not
+// worth a lane: the partial sums meet in complete additions).  H2V_PIP_C / H2V_PIP_LPB force a shape (tests).
+static void pip_shape(PipArgs &a) {
+    static const int env_c = []() { const char *e = getenv("H2V_PIP_C"); return e ? atoi(e) : 0; }();
+    static const int env_lpb = []() { const char *e = getenv("H2V_PIP_LPB"); return e ? atoi(e) : -1; }();
+    const double entries_per_window = (double)a.n * a.halves;
+    uint32_t c = PIP_MAX_C;
+    while (c > 4 && entries_per_window / (double)(1u << (c - 1)) < 24.0) c--;   // keep ~24+ entries per bucket
+    if (env_c >= 3 && env_c <= PIP_MAX_C) c = (uint32_t)env_c;
+    a.c = c; a.NB = 1u << (c - 1); a.W = 128 / c + 1;
+    while (a.W > PIP_MAX_W) { a.c++; a.NB <<= 1; a.W = 128 / a.c + 1; }
+    const double per_bucket = entries_per_window / a.NB, lanes1 = (double)a.W * a.NB;
+    uint32_t lg = 0;
+    while (lg < 4 && lanes1 * (1u << (lg + 1)) <= 4.0 * msm_n_simd() * 64.0 / 4.0 * 1.5 && per_bucket / (1u << (lg + 1)) >= 4.0) lg++;
+    if (env_lpb >= 0 && env_lpb <= 4) lg = (uint32_t)env_lpb;
+    a.lpb_log = lg;
+}
+// Enqueues the six kernels of one bucket MSM on `st`.  a: n, halves, scal, pidx, pool0 / n_pool0 / pool1, out filled in.
+// ev (optional): 4 events recorded at the start, before and after k_pip_accumulate, and at the end.
+static int pip_launch(const PipWs &w, PipArgs a, hipStream_t st, hipEvent_t *ev) {
+    if (a.n > w.cap_n || a.halves > w.cap_halves) return fail(H2V_E_ARG, "bucket MSM workspace too small");
+    pip_shape(a);
+    a.pts28 = w.pts28; a.dig = w.dig; a.cnt = w.cnt; a.off = w.off; a.order = w.order; a.list = w.list; a.partial = w.partial; a.wsum = w.wsum;
+    const uint32_t nb = a.W * a.NB;
+    if (ev) HIPCHK(hipEventRecord(ev[0], st));
+    HIPCHK(hipMemsetAsync(a.cnt, 0, (size_t)nb * 4, st));
+    if (a.n) hipLaunchKernelGGL(k_pip_digits, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_pip_scan, dim3(1), dim3(1024), 0, st, a);
+    if (a.n) hipLaunchKernelGGL(k_pip_scatter, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+    if (ev) HIPCHK(hipEventRecord(ev[1], st));
+    hipLaunchKernelGGL(k_pip_accumulate, dim3((uint32_t)(((uint64_t)nb << a.lpb_log) + 255) / 256), dim3(256), 0, st, a);
+    if (ev) HIPCHK(hipEventRecord(ev[2], st));
+    const size_t lds = (size_t)43 * a.NB * 4;
+    HIPCHK(hipFuncSetAttribute((const void *)k_pip_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_pip_reduce, dim3(a.W), dim3(a.NB), lds, st, a);
+    hipLaunchKernelGGL(k_pip_combine, dim3(1), dim3(64), 0, st, a);
+    if (ev) HIPCHK(hipEventRecord(ev[3], st));
+    HIPCHK(hipGetLastError());
+    return H2V_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- RLC batch mode
+struct RlcWs {
+    uint64_t cap = 0;
+    uint32_t n_var = 0, n_fix = 0;
+    uint32_t *r_scal = nullptr, *r_idx = nullptr, *l_scal = nullptr, *l_idx = nullptr, *vk_part = nullptr;
+    uint8_t *good = nullptr;
+    PipWs R, L;
+    uint32_t *sums = nullptr;   // er (36 dwords) then el (36): the two MSM results
+    uint32_t *misc = nullptr;   // [0..23] a dummy affine point, [24] status of the batch check, [25] skip flag, [26] its valid byte, [27] its accept byte
+    hipStream_t sl = nullptr;   // the left-hand MSM runs beside the right-hand one
+    hipEvent_t ev_prep = nullptr, ev_l = nullptr;
+    static constexpr int NEV = 10;
+    hipEvent_t ring[h2v_workspace::RING][NEV] = {};
+    uint64_t calls = 0;
+    uint32_t last_c = 0, last_W = 0, last_lpb = 0, last_terms = 0;
+};
+static void rlc_release(RlcWs *r) {
+    void *ptrs[] = {r->r_scal, r->r_idx, r->l_scal, r->l_idx, r->vk_part, r->good, r->sums, r->misc};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    pip_free(r->R); pip_free(r->L);
+    if (r->sl) (void)hipStreamDestroy(r->sl);
+    if (r->ev_prep) (void)hipEventDestroy(r->ev_prep);
+    if (r->ev_l) (void)hipEventDestroy(r->ev_l);
+    for (auto &set : r->ring) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
+    delete r;
+}
+static int rlc_ensure(h2v_workspace *w, const h2v_plan *p) {
+    if (w->rlc && w->rlc->n_var == p->n_var && w->rlc->n_fix == p->n_fix) return H2V_OK;
+    if (w->rlc) { rlc_release(w->rlc); w->rlc = nullptr; }
+    RlcWs *r = new RlcWs();
+    r->cap = w->cap; r->n_var = p->n_var; r->n_fix = p->n_fix;
+    const size_t nr = (size_t)w->cap * p->n_var + p->n_fix, blocks = (w->cap + 63) / 64;
+    bool ok = hipMalloc((void **)&r->r_scal, nr * 32) == hipSuccess && hipMalloc((void **)&r->r_idx, nr * 4) == hipSuccess &&
+              hipMalloc((void **)&r->l_scal, (size_t)w->cap * 32) == hipSuccess && hipMalloc((void **)&r->l_idx, (size_t)w->cap * 4) == hipSuccess &&
+              hipMalloc((void **)&r->vk_part, blocks * (p->n_fix ? p->n_fix : 1) * 32) == hipSuccess && hipMalloc((void **)&r->good, w->cap) == hipSuccess &&
+              hipMalloc((void **)&r->sums, 72 * 4) == hipSuccess && hipMalloc((void **)&r->misc, 32 * 4) == hipSuccess &&
+              hipMemset(r->misc, 0, 32 * 4) == hipSuccess &&
+              hipStreamCreateWithFlags(&r->sl, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&r->ev_prep, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&r->ev_l, hipEventDisableTiming) == hipSuccess;
+    for (auto &set : r->ring) for (hipEvent_t &e : set) if (ok) ok = hipEventCreate(&e) == hipSuccess;
+    if (ok) ok = pip_alloc(r->R, (uint32_t)nr, 2) == H2V_OK && pip_alloc(r->L, (uint32_t)w->cap, 1) == H2V_OK;
+    if (!ok) { rlc_release(r); return fail(H2V_E_DEVICE, "RLC workspace allocation failed"); }
+    w->rlc = r;
+    return H2V_OK;
+}
+static bool rlc_supported(const h2v_plan *p) { return !p->d.ivc && p->n_var > 0 && p->n_fix > 0 && p->n_var + p->n_fix == p->d.n_terms; }
+
+// One batch in RLC mode.  Phase 1 as in run_pipeline (the decompression launch builds no window tables), then the batch
+// check; the per-proof MSM + pairing kernels are queued behind it and return at once unless the batch check failed.
+static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
+                   uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, const uint32_t seed[8]) {
+    const H2vDevPlan &d = p->d;
+    int rc = rlc_ensure(w, p);
+    if (rc) return rc;
+    RlcWs *r = w->rlc;
+    const uint32_t slots = H2V_SLOTS(d);
+    hipEvent_t *ev = r->ring[r->calls % h2v_workspace::RING];
+    r->calls++;
+    hipStream_t pm = w->pmain[0], ps = w->pside[0];
+    HIPCHK(hipEventRecord(w->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(pm, w->ev_fork, 0));
+    HIPCHK(hipStreamWaitEvent(ps, w->ev_fork, 0));
+    // phase 1
+    HIPCHK(hipEventRecord(ev[0], ps));
+    {
+        const uint32_t dec_grid = (n * slots + 63) / 64, units = 2 * dec_grid, max_blocks = (uint32_t)(msm_n_simd() / 4.0);
+        uint32_t blocks = (units + 3) / 4;
+        if (blocks > max_blocks) blocks = max_blocks;
+        HIPCHK(hipMemsetAsync(w->dec_ctr, 0, 4, ps));
+        hipLaunchKernelGGL(k_g1_decompress_queue, dim3(blocks), dim3(256), 0, ps, d, n, proofs, off, ci, inst, w->pts, w->valid, (uint32_t *)nullptr, w->valid_sub, w->dec_ctr, dec_grid);
+    }
+    HIPCHK(hipEventRecord(ev[1], ps));
+    HIPCHK(hipEventRecord(w->ev_join[0], ps));
+    HIPCHK(hipEventRecord(ev[2], pm));
+    rc = launch_vm(d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, w->status, nullptr, pm);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ev[3], pm));
+    HIPCHK(hipStreamWaitEvent(pm, w->ev_join[0], 0));
+    // the batch check
+    RlcArgs ra = {n, p->n_var, p->n_fix, slots, d.pi_point, d.n_terms, d.terms, w->scalars, w->status, w->valid, w->valid_sub, {},
+                  r->r_scal, r->r_idx, r->l_scal, r->l_idx, r->vk_part, r->good};
+    for (int k = 0; k < 8; k++) ra.seed[k] = seed[k];
+    const uint32_t blocks = (n + 63) / 64;
+    hipLaunchKernelGGL(k_rlc_prepare, dim3(blocks), dim3(64), 0, pm, ra);
+    HIPCHK(hipEventRecord(r->ev_prep, pm));
+    hipLaunchKernelGGL(k_rlc_vk_sum, dim3((p->n_fix + 63) / 64), dim3(64), 0, pm, ra, blocks);
+    HIPCHK(hipEventRecord(ev[4], pm));
+    // left-hand side on its own stream (needs only r_i and pi_i)
+    HIPCHK(hipStreamWaitEvent(r->sl, r->ev_prep, 0));
+    PipArgs la = {};
+    la.n = n; la.halves = 1; la.scal = r->l_scal; la.pidx = r->l_idx; la.pool0 = w->pts; la.n_pool0 = n * slots; la.pool1 = nullptr; la.out = r->sums + 36;
+    if ((rc = pip_launch(r->L, la, r->sl, nullptr))) return rc;
+    HIPCHK(hipEventRecord(r->ev_l, r->sl));
+    PipArgs rga = {};
+    rga.n = n * p->n_var + p->n_fix; rga.halves = 2; rga.scal = r->r_scal; rga.pidx = r->r_idx; rga.pool0 = w->pts; rga.n_pool0 = n * slots;
+    rga.pool1 = d.vk_bases; rga.out = r->sums;
+    if ((rc = pip_launch(r->R, rga, pm, ev + 5))) return rc;   // ev[5..8]
+    { PipArgs tmp = rga; pip_shape(tmp); r->last_c = tmp.c; r->last_W = tmp.W; r->last_lpb = tmp.lpb_log; r->last_terms = rga.n; }
+    HIPCHK(hipStreamWaitEvent(pm, r->ev_l, 0));
+    // one pairing check over a one-proof view of the plan: el = L, er = R (both Jacobian), no per-proof points
+    H2vDevPlan d1 = d;
+    d1.n_points = 1; d1.n_ci = 0; d1.ivc = 0; d1.pi_point = 0;
+    uint32_t *st1 = r->misc + 24, *skip = r->misc + 25;
+    uint8_t *valid1 = (uint8_t *)(r->misc + 26), *acc1 = (uint8_t *)(r->misc + 27);
+    HIPCHK(hipMemsetAsync(r->misc + 24, 0, 8, pm));            // status of the batch check, skip flag
+    HIPCHK(hipMemsetAsync(valid1, 1, 1, pm));
+    launch_pairing_impl(1, d1, 1, r->misc, valid1, nullptr, r->sums, r->sums + 36, st1, acc1, nullptr, pm);
+    hipLaunchKernelGGL(k_rlc_finalize, dim3((n + 255) / 256), dim3(256), 0, pm, n, r->good, acc1, accept, skip);
+    HIPCHK(hipEventRecord(ev[9], pm));
+    // fall-back, skipped on the device when the batch check passed: window tables, per-proof MSM, per-proof pairing
+    hipLaunchKernelGGL(k_build_tables, dim3((n * slots + 63) / 64), dim3(64), 0, pm, n * slots, w->pts, w->valid, w->pt_tab, skip);
+    {
+        H2vMsmArgs ma = {d.terms, 0, d.n_main_terms, d.n_terms, 0, slots, {d.n_main_terms, d.n_main_terms, d.n_main_terms}, {w->er, nullptr, nullptr},
+                         w->pt_tab, d.vk_tab, nullptr, 0, 0, skip};
+        launch_msm_range(d, ma, n, w->scalars, w->pts, nullptr, pm);
+    }
+    launch_pairing_impl(1, d, n, w->pts, w->valid, w->valid_sub, w->er, nullptr, w->status, accept, nullptr, pm, skip);
+    HIPCHK(hipEventRecord(w->ev_done[0], pm));
+    HIPCHK(hipStreamWaitEvent(st, w->ev_done[0], 0));
+    HIPCHK(hipGetLastError());
+    if (status_out) HIPCHK(hipMemcpyAsync(status_out, w->status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    return H2V_OK;
+}
+static int rlc_seed(const h2v_rlc_opts *o, uint32_t seed[8]) {
+    if (o && (o->flags & H2V_RLC_SEED_GIVEN)) { memcpy(seed, o->seed, 32); return H2V_OK; }
+    FILE *f = fopen("/dev/urandom", "rb");
+    const bool ok = f && fread(seed, 1, 32, f) == 32;
+    if (f) fclose(f);
+    return ok ? H2V_OK : fail(H2V_E_DEVICE, "no OS randomness for the batch coefficients (/dev/urandom)");
+}
+static int rlc_check_batch(const h2v_plan *p, const h2v_batch *b, const uint8_t *accept) {
+    if (!p || !b || !accept) return fail(H2V_E_ARG, "null argument");
+    if (b->n && (!b->proofs || !b->proof_off)) return fail(H2V_E_ARG, "null proofs / offsets");
+    if (b->n && p->d.n_pi && !b->instances) return fail(H2V_E_ARG, "plan has public inputs but instances == NULL");
+    if (b->n && p->d.n_ci && !b->committed) return fail(H2V_E_ARG, "plan has a committed instance but committed == NULL");
+    if (b->n > (1ull << 22)) return fail(H2V_E_LIMIT, "RLC batches are limited to 2^22 proofs");
+    return H2V_OK;
+}
+extern "C" int h2v_verify_batch_rlc_device(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, uint32_t *status, h2v_workspace *ws,
+                                           void *stream, const h2v_rlc_opts *opts) {
+    int rc = rlc_check_batch(p, b, accept);
+    if (rc) return rc;
+    if (b->n == 0) return H2V_OK;
+    if (!ws) return fail(H2V_E_ARG, "the RLC entry points need a workspace (results of the batch check live in it)");
+    HIPCHK(hipSetDevice(p->device));
+    if ((rc = ws_fits(ws, p, b->n, false))) return rc;
+    // recursive plans fold an accumulator per proof (the challenge hashes that proof's own MSM result): no batch form
+    if (!rlc_supported(p))
+        return run_pipeline(p->d, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, nullptr, false);
+    uint32_t seed[8];
+    if ((rc = rlc_seed(opts, seed))) return rc;
+    return run_rlc(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, seed);
+}
+extern "C" int h2v_verify_batch_rlc(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, h2v_workspace *ws, const h2v_rlc_opts *opts,
+                                    int *fell_back) {
+    int rc = rlc_check_batch(p, b, accept);
+    if (rc) return rc;
+    if (fell_back) *fell_back = 0;
+    if (b->n == 0) return H2V_OK;
+    HIPCHK(hipSetDevice(p->device));
+    h2v_workspace *tmp = nullptr;
+    if (!ws) {
+        if ((rc = ws_create_for(p->d, p->device, b->n, false, &tmp))) return rc;
+        ws = tmp;
+    }
+    rc = ws_fits(ws, p, b->n, false);
+    if (rc == H2V_OK) rc = stage_inputs(p, b, ws);
+    const h2v_batch db = {b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci};
+    if (rc == H2V_OK) rc = h2v_verify_batch_rlc_device(p, &db, ws->accept, nullptr, ws, nullptr, opts);
+    if (rc == H2V_OK && hipMemcpy(accept, ws->accept, b->n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(H2V_E_DEVICE, "accept download failed");
+    if (rc == H2V_OK && fell_back && ws->rlc && rlc_supported(p)) {
+        uint32_t skip = 1;
+        if (hipMemcpy(&skip, ws->rlc->misc + 25, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(H2V_E_DEVICE, "flag download failed");
+        *fell_back = skip ? 0 : 1;
+    }
+    if (tmp) h2v_workspace_free(tmp);
+    return rc;
+}
+// After the stream of an RLC call has been synchronised: did the batch check pass (1) or did the per-proof kernels run (0)?
+// kernel times of a past call (calls_back = 0: the most recent).
+extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, uint32_t *batch_accepted, h2v_rlc_timings *tm) {
+    if (!w || !w->rlc || w->rlc->calls == 0) return fail(H2V_E_ARG, "no RLC call was made with this workspace");
+    RlcWs *r = w->rlc;
+    HIPCHK(hipSetDevice(w->device));
+    if (batch_accepted) HIPCHK(hipMemcpy(batch_accepted, r->misc + 25, 4, hipMemcpyDeviceToHost));
+    if (tm) {
+        if (calls_back >= h2v_workspace::RING || calls_back >= r->calls) return fail(H2V_E_ARG, "no such call in the event ring");
+        hipEvent_t *ev = r->ring[(r->calls - 1 - calls_back) % h2v_workspace::RING];
+        memset(tm, 0, sizeof *tm);
+        HIPCHK(hipEventSynchronize(ev[9]));
+        HIPCHK(hipEventElapsedTime(&tm->g1_decompress_ms, ev[0], ev[1]));
+        HIPCHK(hipEventElapsedTime(&tm->transcript_combiner_ms, ev[2], ev[3]));
+        HIPCHK(hipEventElapsedTime(&tm->prepare_ms, ev[3], ev[4]));
+        HIPCHK(hipEventElapsedTime(&tm->bucket_sort_ms, ev[5], ev[6]));
+        HIPCHK(hipEventElapsedTime(&tm->bucket_accumulate_ms, ev[6], ev[7]));
+        HIPCHK(hipEventElapsedTime(&tm->bucket_reduce_ms, ev[7], ev[8]));
+        HIPCHK(hipEventElapsedTime(&tm->pairing_ms, ev[8], ev[9]));
+        float a0, a1;
+        HIPCHK(hipEventElapsedTime(&a0, ev[0], ev[9]));
+        HIPCHK(hipEventElapsedTime(&a1, ev[2], ev[9]));
+        tm->total_ms = a0 > a1 ? a0 : a1;
+        tm->msm_terms = r->last_terms; tm->window_bits = r->last_c; tm->windows = r->last_W; tm->lanes_per_bucket = 1u << r->last_lpb;
+    }
+    return H2V_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- trace
 extern "C" int h2v_trace(const h2v_plan *p, const uint8_t *proof, size_t proof_len, const uint8_t *instances,
                          const uint8_t *committed, uint8_t *scalars_out, uint8_t *msm_scalars_out, uint8_t el_out[96],
@@ -986,6 +1263,32 @@ extern "C" int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out_xy_be, dout.p, (size_t)n * 96, hipMemcpyDeviceToHost));
     return H2V_OK;
+}
+
+// sum_n s_n * P_n through the bucket MSM: n scalars (32 B LE, < r) and n compressed bases; out 96 B affine big-endian
+extern "C" int h2v_probe_g1_msm_pippenger(int device, uint32_t n, const uint8_t *scalars, const uint8_t *bases_compressed, uint8_t *out_xy_be) {
+    int rc = pick_device(device);
+    if (rc) return rc;
+    if (!scalars || !bases_compressed || !out_xy_be || n == 0 || n > (1u << 24)) return fail(H2V_E_ARG, "bad argument");
+    MiniPlan mp;
+    DevBuf din, doff, dsc, dpts, dvalid, dres, dout;
+    if (mp.build(1, 0, nullptr, nullptr) || upload_offsets(doff, n, 48) || din.alloc((size_t)n * 48) || dsc.alloc((size_t)n * 32) ||
+        dpts.alloc((size_t)n * 96) || dvalid.alloc(n) || dres.alloc(144) || dout.alloc(96)) return fail(H2V_E_DEVICE, "probe setup failed");
+    HIPCHK(hipMemcpy(din.p, bases_compressed, (size_t)n * 48, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dsc.p, scalars, (size_t)n * 32, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), (uint32_t *)nullptr, 0u, (uint8_t *)nullptr);
+    PipWs pw;
+    if ((rc = pip_alloc(pw, n, 2))) return rc;
+    PipArgs a = {};
+    a.n = n; a.halves = 2; a.scal = dsc.as<uint32_t>(); a.pidx = nullptr; a.pool0 = dpts.as<uint32_t>(); a.n_pool0 = n; a.pool1 = nullptr; a.out = dres.as<uint32_t>();
+    rc = pip_launch(pw, a, nullptr, nullptr);
+    if (rc == H2V_OK) {
+        hipLaunchKernelGGL(k_export_points, dim3(1), dim3(64), 0, nullptr, 1u, 1, dres.as<uint32_t>(), dout.as<uint8_t>());
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = fail(H2V_E_DEVICE, "bucket MSM kernels failed");
+        else if (hipMemcpy(out_xy_be, dout.p, 96, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(H2V_E_DEVICE, "download failed");
+    }
+    pip_free(pw);
+    return rc;
 }
 extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t *p1c, const uint8_t *p2c, uint8_t *out, int impl, uint8_t *dbg);
 extern "C" int h2v_probe_pairing(const h2v_plan *p, uint32_t n, const uint8_t *p1c, const uint8_t *p2c, uint8_t *out) {

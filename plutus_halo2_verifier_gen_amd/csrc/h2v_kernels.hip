@@ -604,6 +604,8 @@ struct H2vMsmArgs {
     // lanes sums the fix_k terms f * fix_k ... of the range from the all-window tables fix_tab [base][65 windows][8][28]
     const uint32_t *fix_tab;
     uint32_t fix_k, n_fixl;
+    // RLC batch mode: the per-proof MSM queued behind the batch check returns at once when *skip != 0 (NULL: always runs)
+    const uint32_t *skip;
 };
 // A proof owns exactly LPT * n_terms consecutive lanes of a block (no power-of-two padding: 34 terms used to occupy
 // 128 lanes); the block holds as many whole proofs as fit, the rest of its lanes idle.
@@ -624,6 +626,7 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
                      const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws,
                      uint32_t *red /* Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t] */) {
     static_assert(!FIX || LPT == 1, "fixed-base mode runs merged ladders");
+    if (ma.skip && ma.skip[0]) return;   // (uniform over the launch: before any barrier)
     constexpr int NH = 2 / LPT;   // GLV halves per lane
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
     const uint32_t lanes_per_proof = FIX ? ma.n_fixl : LPT * ma.n_terms;
@@ -1190,3 +1193,6 @@ extern "C" __global__ void k_export_points(uint32_t n, int jacobian, const uint3
         o[48 + 4 * k] = wy >> 24; o[48 + 4 * k + 1] = wy >> 16; o[48 + 4 * k + 2] = wy >> 8; o[48 + 4 * k + 3] = wy;
     }
 }
+
+// ============================================================================ RLC batch mode + bucket MSM
+#include "h2v_rlc.hpp"

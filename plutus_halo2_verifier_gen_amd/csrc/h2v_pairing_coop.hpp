@@ -369,7 +369,9 @@ H2V_DI F28 coop_inv(const Coop &c, const F28 &f, bool &ok) {
 extern "C" __global__ void __launch_bounds__(64, 2)
 k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
                const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac /* folded el (recursion) or NULL */,
-               uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
+               uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg,
+               const uint32_t *__restrict__ skip /* RLC mode: return at once when *skip != 0; NULL = always run */) {
+    if (skip && skip[0]) return;
     const int lane = threadIdx.x, grp = lane >> 5;
     Coop c;
     c.g = lane & 15;

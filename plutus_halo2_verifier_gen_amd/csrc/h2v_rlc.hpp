@@ -1,0 +1,144 @@
+// Random-linear-combination (RLC) batch mode: the kernels around the bucket MSM of h2v_pippenger.hpp.
+// Included at the end of h2v_kernels.hip (uses its transcript hash and field helpers).
+//
+// For a batch of B proofs of one plan, after the unchanged per-proof phase 1 (transcript + combiner -> the T MSM scalars
+// s_{i,t}; decompression + subgroup test of every G1 element):
+//   k_rlc_prepare   per proof: good_i = "nothing rejected so far"; r_i = low 128 bits of blake2b-256(seed || i) (0 when
+//                   !good_i: the proof is rejected by itself and takes no part in the combination); the scaled scalars
+//                   r_i s_{i,t} mod r of its per-proof terms, its share of the VK-base sums, and (r_i, pi_i) for the left side
+//   k_rlc_vk_sum    sum_i r_i s_{i,f} per VK base f (the bases are the same for every proof: one term each)
+//   bucket MSMs     R = sum_i r_i er_i (255-bit scalars, GLV)  and  L = sum_i r_i pi_i (128-bit scalars)
+//   k_pairing_coop  ONE check e(L, s_g2) == e(R, G2)
+//   k_rlc_finalize  accepted: accept[i] = good_i.  Rejected (some good-looking proof fails its own pairing equation, caught
+//                   with probability >= 1 - 2^-128 over the seed): the per-proof MSM + pairing kernels that follow on the
+//                   stream are NOT skipped and produce accept[] exactly as the per-proof mode does.
+#pragma once
+#include "h2v_pippenger.hpp"
+
+struct RlcArgs {
+    uint32_t n, n_var, n_fix, slots, pi_point, scal_stride;
+    const uint32_t *terms;      // the plan's (kind, index) table: [0, n_var) per-proof slots, [n_var, n_var + n_fix) VK bases
+    const uint32_t *scalars;    // n x scal_stride x 8, canonical
+    uint32_t *status;           // n (H2V_ST_BAD_POINT is folded in here)
+    const uint8_t *valid, *valid_sub;
+    uint32_t seed[8];
+    uint32_t *r_scal, *r_idx;   // n * n_var + n_fix terms of the right-hand MSM
+    uint32_t *l_scal, *l_idx;   // n terms of the left-hand MSM
+    uint32_t *vk_part;          // ceil(n / 64) x n_fix x 8 (Montgomery): per-block sums of r_i s_{i,f}
+    uint8_t *good;              // n
+};
+
+extern "C" __global__ void __launch_bounds__(64)
+k_rlc_prepare(RlcArgs a) {
+    __shared__ uint32_t sbuf[32 * 64];
+    const int lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * 64 + lane;
+    const bool live = i < a.n;
+    const uint32_t ii = live ? i : a.n - 1;
+    uint32_t st = a.status[ii];
+    for (uint32_t j = 0; j < a.slots; j++)
+        if (!a.valid[(size_t)ii * a.slots + j] || (a.valid_sub && !a.valid_sub[(size_t)ii * a.slots + j])) st |= H2V_ST_BAD_POINT;
+    const bool good = live && st == 0;
+    // r_i: blake2b-256(seed || LE32(i)), low 128 bits (never 0 for a proof that takes part)
+    Transcript tr;
+    tr_init(tr);
+#pragma unroll 1
+    for (int k = 0; k < 32; k++) tr_put(tr, sbuf, lane, (a.seed[k >> 2] >> (8 * (k & 3))) & 0xffu);
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) tr_put(tr, sbuf, lane, (ii >> (8 * k)) & 0xffu);
+    uint64_t h[4];
+    tr_digest(tr, sbuf, lane, h);
+    Fr r, rm;
+#pragma unroll
+    for (int l = 0; l < 8; l++) r.v[l] = 0;
+    r.v[0] = (uint32_t)h[0]; r.v[1] = (uint32_t)(h[0] >> 32); r.v[2] = (uint32_t)h[1]; r.v[3] = (uint32_t)(h[1] >> 32);
+    if ((r.v[0] | r.v[1] | r.v[2] | r.v[3]) == 0) r.v[0] = 1;
+    if (!good) { r.v[0] = 0; r.v[1] = 0; r.v[2] = 0; r.v[3] = 0; }
+    fr_to_mont(rm, r);
+    if (live) {
+        a.status[i] = st;
+        a.good[i] = good ? 1 : 0;
+#pragma unroll
+        for (int l = 0; l < 8; l++) a.l_scal[(size_t)i * 8 + l] = r.v[l];
+        a.l_idx[i] = i * a.slots + a.pi_point;
+    }
+    const uint32_t *sp = a.scalars + (size_t)ii * a.scal_stride * 8;
+#pragma unroll 1
+    for (uint32_t t = 0; t < a.n_var; t++) {
+        Fr s, sm, p, pc;
+#pragma unroll
+        for (int l = 0; l < 8; l++) s.v[l] = sp[t * 8 + l];
+        fr_to_mont(sm, s);
+        fr_mul(p, sm, rm);
+        fr_from_mont(pc, p);
+        if (live) {
+            const size_t e = (size_t)i * a.n_var + t;
+#pragma unroll
+            for (int l = 0; l < 8; l++) a.r_scal[e * 8 + l] = pc.v[l];
+            a.r_idx[e] = i * a.slots + a.terms[2 * t + 1];
+        }
+    }
+#pragma unroll 1
+    for (uint32_t f = 0; f < a.n_fix; f++) {
+        Fr s, sm, p;
+#pragma unroll
+        for (int l = 0; l < 8; l++) s.v[l] = sp[(a.n_var + f) * 8 + l];
+        fr_to_mont(sm, s);
+        fr_mul(p, sm, rm);               // 0 for lanes that take no part (rm = 0)
+#pragma unroll 1
+        for (int d = 32; d >= 1; d >>= 1) {
+            Fr o;
+#pragma unroll
+            for (int l = 0; l < 8; l++) o.v[l] = __shfl_down(p.v[l], d);
+            fr_add(p, p, o);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int l = 0; l < 8; l++) a.vk_part[((size_t)blockIdx.x * a.n_fix + f) * 8 + l] = p.v[l];
+        }
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+k_rlc_vk_sum(RlcArgs a, uint32_t n_blocks) {
+    const uint32_t f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= a.n_fix) return;
+    Fr acc, c;
+    FrF::set_zero(acc);
+#pragma unroll 1
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        Fr p;
+#pragma unroll
+        for (int l = 0; l < 8; l++) p.v[l] = a.vk_part[((size_t)b * a.n_fix + f) * 8 + l];
+        fr_add(acc, acc, p);
+    }
+    fr_from_mont(c, acc);
+    const size_t e = (size_t)a.n * a.n_var + f;
+#pragma unroll
+    for (int l = 0; l < 8; l++) a.r_scal[e * 8 + l] = c.v[l];
+    a.r_idx[e] = a.n * a.slots + a.terms[2 * (a.n_var + f) + 1];   // pool 1 (the plan's VK bases) starts at n * slots
+}
+
+// rlc_accept: the one-group pairing kernel's verdict.  *skip = 1 tells the per-proof kernels queued behind to return at once.
+extern "C" __global__ void __launch_bounds__(256)
+k_rlc_finalize(uint32_t n, const uint8_t *__restrict__ good, const uint8_t *__restrict__ rlc_accept, uint8_t *__restrict__ accept,
+               uint32_t *__restrict__ skip) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = rlc_accept[0] != 0;
+    if (i == 0) skip[0] = ok ? 1u : 0u;
+    if (i < n && ok) accept[i] = good[i];
+}
+
+// fall-back path only: the MSM window tables of every per-proof point, which the RLC mode's decompression launch skips
+extern "C" __global__ void __launch_bounds__(64)
+k_build_tables(uint32_t n_points, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, uint32_t *__restrict__ pt_tab,
+               const uint32_t *__restrict__ skip) {
+    if (skip && skip[0]) return;
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_points || !valid[g]) return;
+    G1A p;
+#pragma unroll
+    for (int k = 0; k < 12; k++) { p.x.v[k] = pts[(size_t)g * 24 + k]; p.y.v[k] = pts[(size_t)g * 24 + 12 + k]; }
+    if (g1a_is_inf(p)) return;
+    g1_build_window_tables_glv(pt_tab + (size_t)g * 448, p);
+}
