@@ -3,15 +3,21 @@
 
   python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the hot path over one batch of synthetic proofs per GPU: transcript replay + Fr combiner,
-G1 decompression, per-proof G1 MSM and the fused pairing check, with every input already resident in HBM.
-Workload: BASELINE.json configs[1] - simple_mul, 4096 proofs per GPU (independent proofs shard across GPUs with no
-data-path collective: weak scaling; the per-step accept vectors are gathered on rank 0 over RCCL as the north star
-asks).  Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic proofs per GPU, every input already resident in HBM:
+transcript replay + Fr combiner, G1 decompression, then
+  --mode per-proof (default; BASELINE configs[1] "G1 MSM + one pairing per proof"): per-proof G1 MSM + fused pairing check;
+  --mode rlc: the batch-accept fast path (h2v_verify_batch_rlc_device): one bucketed Pippenger G1 MSM over every per-proof
+              point of the batch + ONE pairing (+ the per-proof kernels, skipped on the device unless the batch check fails).
+Workload: BASELINE.json configs[1] - simple_mul, 4096 proofs per GPU; --workload / --batch select the other configs.
+--scaling weak (default): every rank verifies --batch proofs; strong: the ranks split ONE batch of --batch proofs by
+contiguous index ranges (shard.shard_range).  Either way there is no data-path collective; the per-step accept bytes are
+gathered on rank 0 over RCCL as the north star asks.  --inflight P keeps P steps in flight on P workspaces / streams
+(every step still runs completely inside the timed region).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -27,8 +33,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 def imad_peak():
     import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_imad_ubench.txt")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_imad_ubench.txt")))
     if not files:
         return None, None
     cyc, sect = None, None
@@ -56,10 +61,37 @@ WORKLOADS = {
     "simple_mul": ("simple_mul", 4096, "simple_mul x4096 per GPU (BASELINE configs[1])"),
     "lookup_mixed": ("lookup_table", 2048, "lookup_table x2048 (half of BASELINE configs[2])"),
     "atms_with_lookups": ("atms_with_lookups", 2048, "atms_with_lookups x2048 (half of BASELINE configs[2])"),
-    "sha256": ("sha256", 1024, "sha256-shaped x1024 per GPU (BASELINE configs[3])"),
-    "secp256k1": ("secp256k1", 512, "secp256k1-shaped x512 per GPU (BASELINE configs[4])"),
+    "sha256": ("sha256", 1024, "sha256-shaped x1024 (BASELINE configs[3])"),
+    "secp256k1": ("secp256k1", 512, "secp256k1-shaped x512 (BASELINE configs[4])"),
     "ivc": ("ivc", 1024, "IVC-shaped recursive circuit x1024 per GPU (accumulator fold, DESIGN.md section 10)"),
 }
+
+
+def pmc_traffic(kernel, workload, batch, mode):
+    """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB on gfx950) of `kernel` from the newest committed PMC summary
+    that was collected on THIS workload / batch / mode (header line `# workload=... batch=... mode=...`, written by
+    tools/scripts/profile_round.sh over separate rocprofv3 --pmc passes of this command); (None, None) otherwise."""
+    import glob
+
+    def version_key(path):
+        m = re.match(r"r(\d+)_v(\d+)", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.txt")), key=version_key, reverse=True):
+        lines = open(path).read().splitlines()
+        if not lines or not lines[0].startswith("#"):
+            continue
+        hdr = dict(kv.split("=", 1) for kv in lines[0][1:].split() if "=" in kv)
+        if hdr.get("workload") != workload or hdr.get("batch") != str(batch) or hdr.get("mode") != mode:
+            continue
+        vals = {}
+        for line in lines[1:]:
+            f = line.split()
+            if len(f) >= 4 and f[0] == kernel and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[f[1]] = float(f[3])
+        if len(vals) == 2:
+            return int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.basename(path)
+    return None, None
 
 
 def main():
@@ -68,17 +100,25 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="simple_mul", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0, help="proofs per GPU (default: the workload's BASELINE size)")
+    ap.add_argument("--batch", type=int, default=0, help="proofs per GPU (weak) / in total (strong); default: the workload's BASELINE size")
+    ap.add_argument("--mode", default="per-proof", choices=["per-proof", "rlc"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--inflight", type=int, default=0, help="steps in flight (workspaces / streams); default 1 (per-proof), 5 (rlc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rlc-secondary", action="store_true", help="per-proof runs: skip the extra measurement of the RLC mode")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    inflight = args.inflight or (5 if args.mode == "rlc" else 1)
+    # several steps in flight use 3 streams each: more hardware queues than the runtime's default of 4, or they serialise
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
     torch.cuda.set_device(local_rank)          # one process per GPU; bind before the communicator is created
@@ -89,10 +129,19 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
-    from plutus_halo2_verifier_gen_amd import backend, plan as PL, synth, vk as V
+    from plutus_halo2_verifier_gen_amd import backend, plan as PL, shard, synth, vk as V
 
     vk_name, default_batch, label = WORKLOADS[args.workload]
-    B = args.batch or default_batch
+    B_arg = args.batch or default_batch
+    if args.scaling == "strong":
+        lo, hi = shard.shard_range(B_arg, rank, world)   # this rank's contiguous range of the ONE batch
+        B = hi - lo
+        B_total = B_arg
+    else:
+        B = B_arg
+        B_total = B_arg * world
+    if B == 0:
+        raise SystemExit("strong scaling: more ranks than proofs")
     vk, td = V.BUILDERS[vk_name]()
     pl = PL.compile_plan(vk)
     ncpu = os.cpu_count() or 1
@@ -102,63 +151,113 @@ def main():
     t_forge = time.time() - t0
 
     dp = backend.DevicePlan(pl.to_bytes(), device=local_rank)
-    ws = backend.Workspace(dp, B)
 
-    def to_dev(b, dtype=torch.uint8):
+    def to_dev(b):
         return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) if b else torch.zeros(1, dtype=torch.uint8, device=dev)
 
     d_proofs = to_dev(batch.proofs)
     d_off = torch.tensor(batch.proof_off, dtype=torch.int64).to(dev)
     d_inst = to_dev(batch.instances)
     d_ci = to_dev(batch.committed) if batch.committed else None
-    d_accept = torch.zeros(B, dtype=torch.uint8, device=dev)
-    d_status = torch.zeros(B, dtype=torch.int32, device=dev)
-    gathered = [torch.zeros(B, dtype=torch.uint8, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
-    torch.cuda.synchronize()
-
-    def step():
-        stream = torch.cuda.current_stream().cuda_stream
-        dp.verify_batch_device(B, d_proofs.data_ptr(), d_off.data_ptr(), d_inst.data_ptr(),
-                               d_ci.data_ptr() if d_ci is not None else None, d_accept.data_ptr(), d_status.data_ptr(),
-                               ws=ws, stream=stream)
-        if world > 1:
-            # final accept/reject gather over RCCL (xGMI): B bytes per rank
-            dist.gather(d_accept, gathered, dst=0)
-
-    for _ in range(args.warmup):
-        step()
+    Bmax = B
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([B], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        Bmax = int(t.item())
+    rlc_seed = bytes((7 * k + 1) & 0xff for k in range(32))   # fixed for the timed steps (reproducible); a service draws it per batch
 
-    # per-kernel device time over the timed steps (HIP events recorded on the kernels' own streams)
-    # (a step launches every kernel once per pipeline chunk; *_ms are sums over the chunks of one step)
+    def timed_run(mode, inflight, steps, warmup, gather):
+        """warmup + `steps` timed passes in `mode` with `inflight` steps in flight; returns (elapsed s, workspaces, accept)"""
+        wss = [backend.Workspace(dp, B) for _ in range(inflight)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(inflight)] if inflight > 1 else [None]
+        d_accepts = [torch.zeros(B, dtype=torch.uint8, device=dev) for _ in range(inflight)]
+        d_statuses = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(inflight)]
+        use_gather = gather and world > 1
+        g_send = [torch.zeros(Bmax, dtype=torch.uint8, device=dev) for _ in range(inflight)] if use_gather else None
+        gathered = [[torch.zeros(Bmax, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(inflight)] if (use_gather and rank == 0) else None
+        torch.cuda.synchronize()
+
+        def step(k):
+            slot = k % inflight
+            st = streams[slot]
+            ctx = torch.cuda.stream(st) if st is not None else None
+            if ctx is not None:
+                ctx.__enter__()
+            try:
+                stream = torch.cuda.current_stream().cuda_stream
+                ptrs = (B, d_proofs.data_ptr(), d_off.data_ptr(), d_inst.data_ptr(), d_ci.data_ptr() if d_ci is not None else None,
+                        d_accepts[slot].data_ptr(), d_statuses[slot].data_ptr())
+                if mode == "rlc":
+                    dp.verify_batch_rlc_device(*ptrs, ws=wss[slot], stream=stream, seed=rlc_seed)
+                else:
+                    dp.verify_batch_device(*ptrs, ws=wss[slot], stream=stream)
+                if use_gather:
+                    # final accept/reject gather over RCCL (xGMI): the rank's accept bytes (padded to the widest shard)
+                    g_send[slot][:B].copy_(d_accepts[slot])
+                    dist.gather(g_send[slot], gathered[slot] if gathered else None, dst=0)
+            finally:
+                if ctx is not None:
+                    ctx.__exit__(None, None, None)
+
+        for k in range(warmup):
+            step(k)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, wss, d_accepts[(steps - 1) % inflight].cpu().numpy()
+
+    elapsed, wss, accept = timed_run(args.mode, inflight, args.steps, args.warmup, True)
+
+    # per-kernel device time over the timed steps (HIP events recorded on the kernels' own streams, event rings of the
+    # workspaces): averages over the last min(steps, 64) steps
     k_steps = min(args.steps, 64)
-    acc = {"transcript_combiner": 0.0, "g1_decompress": 0.0, "g1_msm": 0.0, "pairing": 0.0}
-    launches = 1
-    msm_lpt = 2
-    for back in range(k_steps):
-        tm = ws.timings(back)
-        launches = max(1, tm.launches)
-        msm_lpt = tm.msm_lanes_per_term or 2
-        acc["transcript_combiner"] += tm.transcript_combiner_ms
-        acc["g1_decompress"] += tm.g1_decompress_ms
-        acc["g1_msm"] += tm.g1_msm_ms
-        acc["pairing"] += tm.pairing_ms
-    kernel_ms = {k: v / max(1, k_steps) for k, v in acc.items()}
+    rlc_shape = None
+    if args.mode == "rlc":
+        names = ["transcript_combiner", "g1_decompress", "rlc_prepare", "bucket_sort", "bucket_accumulate", "bucket_reduce", "pairing"]
+        acc = {k: 0.0 for k in names}
+        span = 0.0
+        all_batch_ok = True
+        for j in range(k_steps):
+            slot = (args.steps - 1 - j) % inflight
+            ok, tm = wss[slot].rlc_result(calls_back=j // inflight)
+            all_batch_ok = all_batch_ok and ok
+            for nm, v in zip(names, [tm.transcript_combiner_ms, tm.g1_decompress_ms, tm.prepare_ms, tm.bucket_sort_ms,
+                                     tm.bucket_accumulate_ms, tm.bucket_reduce_ms, tm.pairing_ms]):
+                acc[nm] += v
+            span += tm.total_ms
+            rlc_shape = {"msm_terms": tm.msm_terms, "window_bits": tm.window_bits, "windows_per_glv_half": tm.windows,
+                         "max_entries_per_lane": tm.max_chain}
+        kernel_ms = {k: v / k_steps for k, v in acc.items()}
+        batch_latency_ms = span / k_steps
+        launches, msm_lpt = 1, 0
+    else:
+        acc = {"transcript_combiner": 0.0, "g1_decompress": 0.0, "g1_msm": 0.0, "pairing": 0.0}
+        launches, msm_lpt, span = 1, 2, 0.0
+        for j in range(k_steps):
+            slot = (args.steps - 1 - j) % inflight
+            tm = wss[slot].timings(j // inflight)
+            launches = max(1, tm.launches)
+            msm_lpt = tm.msm_lanes_per_term or 2
+            acc["transcript_combiner"] += tm.transcript_combiner_ms
+            acc["g1_decompress"] += tm.g1_decompress_ms
+            acc["g1_msm"] += tm.g1_msm_ms
+            acc["pairing"] += tm.pairing_ms
+            span += tm.total_ms
+        kernel_ms = {k: v / k_steps for k, v in acc.items()}
+        batch_latency_ms = span / k_steps
+        all_batch_ok = None
 
-    accept = d_accept.cpu().numpy()
     n_accept = int(accept.sum())
     ok_all = n_accept == B  # the synthetic batch is 100 % accepting
     if world > 1:
@@ -166,75 +265,101 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok_all = bool(flag.item())
 
+    # In the default (per-proof) run the batch-accept mode is measured as well - same batch, same resident inputs, its own
+    # timed region - and reported under "rlc_mode" of the one JSON line; `value` stays the per-proof figure the BASELINE
+    # config ("G1 MSM + one pairing per proof") names.
+    rlc_secondary = None
+    if args.mode == "per-proof" and not args.no_rlc_secondary and vk.recursion_vks is None:
+        inflight2 = 5
+        el2, wss2, acc2 = timed_run("rlc", inflight2, args.steps, args.warmup, False)
+        ok2, tm2 = wss2[0].rlc_result()
+        rlc_secondary = {"value": round(B_total * args.steps / el2, 2), "unit": "proofs/s", "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                         "steps_in_flight": inflight2, "all_accepted": bool(int(acc2.sum()) == B), "batch_check_passed": ok2,
+                         "bucket_msm_terms": tm2.msm_terms, "k_pip_accumulate_ms": round(tm2.bucket_accumulate_ms, 4),
+                         "msm_GBps_algorithmic": round((128 * tm2.msm_terms + 144) / (tm2.bucket_accumulate_ms * 1e-3) / 1e9, 3) if tm2.bucket_accumulate_ms > 0 else None,
+                         "note": "python bench.py --mode rlc prints the full line (roofline of the bucket kernel, kernel times)"}
+        del wss2
+
     # second dataset (untimed): 1 % of the proofs get the reference example's byte flip (examples/simple_mul.rs:87-95,
-    # first scalar of the proof) - exactly those proofs must be rejected
+    # first scalar of the proof) - exactly those proofs must be rejected (rlc: through the per-proof fall-back)
     reject_check = None
     if rank == 0:
         rej = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.01, seed=77, kinds=["flip_first_scalar"])
-        got = dp.verify_batch(rej.proofs, rej.proof_off, rej.instances, rej.committed, ws=ws)
+        if args.mode == "rlc":
+            got, fell_back = dp.verify_batch_rlc(rej.proofs, rej.proof_off, rej.instances, rej.committed, ws=wss[0])
+        else:
+            got, fell_back = dp.verify_batch(rej.proofs, rej.proof_off, rej.instances, rej.committed, ws=wss[0]), None
         reject_check = {"fraction": 0.01, "corrupted": rej.expected.count(0), "rejected": int(B - sum(got)),
-                        "exactly_the_corrupted_ones": list(got) == rej.expected}
+                        "exactly_the_corrupted_ones": list(got) == rej.expected, "fell_back_to_per_proof_kernels": fell_back}
 
     if rank == 0:
         T = pl.n_terms
         slots = len(pl.points) + pl.n_ci
-        # ALGORITHMIC bytes per launch (SURVEY.md §8d / DESIGN.md §4)
-        bytes_per_launch = {
-            "g1_msm": B * (128 * T + 144),
-            "g1_decompress": B * slots * (48 + 96 + 1),
-            "transcript_combiner": B * (pl.proof_len + 32 * pl.n_pi + 48 * pl.n_ci + 32 * T + 4),
-            "pairing": B * (96 + 144 + 1 + 4) + 2 * 68 * 192,
-        }
+        n_fix_terms = sum(1 for kind, _ in pl.terms if kind == PL.TERM_VK_BASE)
         # the combiner keeps its Fr register file in LDS when >= 8 proofs per block fit (h2v_capi.hip: vm_lds_slots)
         lds_slots = 64
         while lds_slots >= 8 and pl.n_regs * 32 * lds_slots + 8192 + 1024 > 160 * 1024:
             lds_slots >>= 1
-        kname = {"g1_msm": "k_g1_msm_fixed" if msm_lpt == 3 else "k_g1_msm_merged" if msm_lpt == 1 else "k_g1_msm", "g1_decompress": "k_g1_decompress" if (os.environ.get("H2V_DEC_QUEUE") == "0" or os.environ.get("H2V_SPLIT_DEC") == "0") else "k_g1_decompress_queue",
-                 "transcript_combiner": "k_transcript_combiner_lds" if lds_slots >= 8 else "k_transcript_combiner",
-                 "pairing": "k_pairing_coop" if os.environ.get("H2V_PAIRING") != "legacy" else "k_pairing_check"}
-
-        def pmc_traffic(kernel):
-            """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB on gfx950) from the newest committed PMC summary
-            (tools/pmc_summary.py over separate rocprofv3 --pmc passes of this same command); None when absent."""
-            import glob
-            files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_summary.txt")))
-            if not files:
-                return None, None
-            vals = {}
-            for line in open(files[-1]):
-                f = line.split()
-                if len(f) >= 4 and f[0] == kernel and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
-                    vals[f[1]] = float(f[3])
-            if len(vals) != 2:
-                return None, None
-            return int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.basename(files[-1])
+        dec_name = "k_g1_decompress" if (os.environ.get("H2V_DEC_QUEUE") == "0" or os.environ.get("H2V_SPLIT_DEC") == "0") else "k_g1_decompress_queue"
+        vm_name = "k_transcript_combiner_lds" if lds_slots >= 8 else "k_transcript_combiner"
+        tab_point = 4 * MAD_DBL + 3 * MAD_ADD + 48 * MAD_MUL + 14 * MAD_SQR    # window tables of one point: [1..8]P, normalised, and x beta
+        pairing_lane = 35 * (6 * 196 + 196) + 63 * (4 * 196 + 196) + 315 * (2 * 196 + 196) + 136 * (3 * 196 + 196)   # coop program: MUL / SQR / CSQR / LINE
+        # ALGORITHMIC bytes per launch (SURVEY.md section 8d / DESIGN.md section 4) and analytical lane-level multiply-adds
+        if args.mode == "rlc":
+            n_terms_r = rlc_shape["msm_terms"]
+            W = rlc_shape["windows_per_glv_half"]
+            kname = {"transcript_combiner": vm_name, "g1_decompress": dec_name, "rlc_prepare": "k_rlc_prepare", "bucket_sort": "k_pip_digits",
+                     "bucket_accumulate": "k_pip_accumulate", "bucket_reduce": "k_pip_reduce", "pairing": "k_pairing_coop"}
+            bytes_per_launch = {
+                "bucket_accumulate": 128 * n_terms_r + 144,                   # the G1 MSM the metric names: 32 B scalar + 96 B base per term
+                "g1_decompress": B * slots * (48 + 96 + 1),
+                "transcript_combiner": B * (pl.proof_len + 32 * pl.n_pi + 48 * pl.n_ci + 32 * T + 4),
+                "pairing": 2 * 144 + 1 + 4 + 2 * 68 * 192,
+                "rlc_prepare": B * (32 * T + 5 + 32 * (T - n_fix_terms) + 4),
+                "bucket_sort": 128 * n_terms_r, "bucket_reduce": W * (1 << (rlc_shape["window_bits"] - 1)) * 176,
+            }
+            mads = {
+                "bucket_accumulate": 2 * n_terms_r * W * MAD_MADD,           # one mixed addition per (term, GLV half, window); zero digits are rare
+                "g1_decompress": B * slots * (377 * MAD_SQR + 86 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD),
+                "transcript_combiner": B * sum(128 for ins in pl.instrs if ins[0] == PL.OP_MUL),
+                "pairing": 32 * pairing_lane,
+                "rlc_prepare": B * T * 3 * 128, "bucket_sort": n_terms_r * MAD_MUL,
+                "bucket_reduce": W * (1 << (rlc_shape["window_bits"] - 1)) * 19 * MAD_ADD,
+            }
+            msm_key = "bucket_accumulate"
+        else:
+            kname = {"g1_msm": "k_g1_msm_fixed" if msm_lpt == 3 else "k_g1_msm_merged" if msm_lpt == 1 else "k_g1_msm", "g1_decompress": dec_name,
+                     "transcript_combiner": vm_name, "pairing": "k_pairing_coop" if os.environ.get("H2V_PAIRING") != "legacy" else "k_pairing_check"}
+            bytes_per_launch = {
+                "g1_msm": B * (128 * T + 144),
+                "g1_decompress": B * slots * (48 + 96 + 1),
+                "transcript_combiner": B * (pl.proof_len + 32 * pl.n_pi + 48 * pl.n_ci + 32 * T + 4),
+                "pairing": B * (96 + 144 + 1 + 4) + 2 * 68 * 192,
+            }
+            # per MSM lane: 32 windows of 4 doublings + one mixed addition per GLV half the lane carries (tables are built
+            # ahead); the launcher reports whether a term ran on two lanes (one half each) or on one (both halves)
+            msm_fixed = msm_lpt == 3   # fixed-base mode: VK-base terms cost 65 mixed additions and no doubling
+            lpt = 1 if msm_fixed else msm_lpt
+            msm_halves = 2 // lpt
+            msm_lane = 128 * MAD_DBL + (32 * msm_halves - 1) * MAD_MADD
+            mads = {
+                "g1_msm": (B * (T - n_fix_terms) * msm_lane + B * n_fix_terms * 65 * MAD_MADD + B * (T - 1) * MAD_ADD + B * 3 * MAD_MUL) if msm_fixed
+                          else B * T * lpt * msm_lane + B * (lpt * T - 1) * MAD_ADD + B * 3 * MAD_MUL,
+                "pairing": B * 32 * pairing_lane,
+                "g1_decompress": B * slots * (377 * MAD_SQR + 86 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD + tab_point),
+                "transcript_combiner": B * sum(128 for ins in pl.instrs if ins[0] == PL.OP_MUL),
+            }
+            msm_key = "g1_msm"
 
         def roof(k):
-            # one launch handles B / launches proofs; average launch duration = per-step sum / launches
+            # the contract's HBM roofline of one kernel: ALGORITHMIC bytes per launch / its average launch duration
             gbps = bytes_per_launch[k] / (kernel_ms[k] * 1e-3) / 1e9 if kernel_ms[k] > 0 else 0.0
-            traffic, src = pmc_traffic(kname[k])
+            traffic, src = pmc_traffic(kname[k], args.workload, B, args.mode)
             return {"kernel": kname[k], "bound": "hbm", "achieved": round(gbps, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(gbps / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": src,
                     "avg_launch_ms": round(kernel_ms[k] / launches, 4), "launches_per_step": launches,
-                    "algorithmic_bytes_per_launch": bytes_per_launch[k] // launches}
-
-        # analytical multiply-add counts per launch (lane-level v_mad_u64_u32), see DESIGN.md section 6
-        # per MSM lane: 32 windows of 4 doublings + one mixed addition per GLV half the lane carries (tables are built
-        # ahead); the launcher reports whether a term ran on two lanes (one half each) or on one (both halves)
-        n_fix_terms = sum(1 for kind, _ in pl.terms if kind == PL.TERM_VK_BASE)
-        msm_fixed = msm_lpt == 3   # fixed-base mode: VK-base terms cost 65 mixed additions and no doubling
-        if msm_fixed:
-            msm_lpt = 1
-        msm_halves = 2 // msm_lpt
-        msm_lane = 128 * MAD_DBL + (32 * msm_halves - 1) * MAD_MADD
-        tab_point = 4 * MAD_DBL + 3 * MAD_ADD + 48 * MAD_MUL + 14 * MAD_SQR    # window tables of one point: [1..8]P, normalised, and x beta
-        mads = {
-            "g1_msm": (B * (T - n_fix_terms) * msm_lane + B * n_fix_terms * 65 * MAD_MADD + B * (T - 1) * MAD_ADD + B * 3 * MAD_MUL) if msm_fixed
-                      else B * T * msm_lpt * msm_lane + B * (msm_lpt * T - 1) * MAD_ADD + B * 3 * MAD_MUL,
-            "pairing": B * 32 * (35 * (6 * 196 + 196) + 63 * (4 * 196 + 196) + 315 * (2 * 196 + 196) + 136 * (3 * 196 + 196)),   # coop program: MUL / SQR / CSQR / LINE
-            "g1_decompress": B * slots * (377 * MAD_SQR + 86 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD + tab_point),
-            "transcript_combiner": B * sum(128 for ins in pl.instrs if ins[0] == PL.OP_MUL),
-        }
+                    "algorithmic_bytes_per_launch": bytes_per_launch[k] // launches,
+                    "note": "integer-issue bound (see int_roofline): ~10^5 multiply-adds per 128-byte MSM term"}
 
         def int_roof(k):
             tops = mads[k] / (kernel_ms[k] * 1e-3) / 1e12 if kernel_ms[k] > 0 else 0.0
@@ -246,30 +371,37 @@ def main():
         dominant = max(kernel_ms, key=kernel_ms.get)
         result = {
             "metric": "halo2_proofs_verified_per_sec",
-            "value": round(B * world * args.steps / elapsed, 2),
+            "value": round(B_total * args.steps / elapsed, 2),
             "unit": "proofs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": label, "proofs_per_gpu": B, "proof_bytes": pl.proof_len, "msm_terms_per_proof": T,
-                       "g1_points_per_proof": slots, "public_inputs": pl.n_pi, "plan_instructions": len(pl.instrs),
-                       "parallelism": "independent proofs sharded per GPU; accept gather over RCCL" if world > 1 else "1 GPU"},
+            "config": {"workload": label, "mode": args.mode, "proofs_per_gpu": B, "proofs_per_step_all_gpus": B_total, "proof_bytes": pl.proof_len,
+                       "msm_terms_per_proof": T, "g1_points_per_proof": slots, "public_inputs": pl.n_pi, "plan_instructions": len(pl.instrs),
+                       "steps_in_flight": inflight,
+                       "parallelism": ("independent proofs sharded per GPU (%s); accept gather over RCCL" % args.scaling) if world > 1 else "1 GPU"},
             "roofline": roof(dominant),
-            "msm_roofline": roof("g1_msm"),
+            "msm_roofline": roof(msm_key),
             "int_roofline": int_roof(dominant),
-            "msm_int_roofline": int_roof("g1_msm"),
+            "msm_int_roofline": int_roof(msm_key),
             "kernel_ms": {kname[k]: round(v, 4) for k, v in kernel_ms.items()},
+            "batch_latency_ms": round(batch_latency_ms, 4),
             "pipelines_per_step": launches, "msm_lanes_per_term": msm_lpt,
             "all_accepted": ok_all,
             "reject_dataset": reject_check,
             "forge_seconds": round(t_forge, 2),
         }
+        if rlc_secondary is not None:
+            result["rlc_mode"] = rlc_secondary
+        if args.mode == "rlc":
+            result["rlc"] = dict(rlc_shape, batch_check_passed_every_step=all_batch_ok,
+                                 soundness="accept[] equals the per-proof mode's except with probability <= 2^-128 over the seed")
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(vk, batch, pl, args.cpu_sample, accept)
         elif not args.no_cpu_baseline:

@@ -119,7 +119,7 @@ typedef struct {
 typedef struct {
     float transcript_combiner_ms, g1_decompress_ms, prepare_ms, bucket_sort_ms, bucket_accumulate_ms, bucket_reduce_ms,
           pairing_ms, total_ms;   /* total: first phase-1 launch .. the batch verdict (a fall-back run is not included) */
-    uint32_t msm_terms, window_bits, windows, lanes_per_bucket;   /* shape of the right-hand bucket MSM */
+    uint32_t msm_terms, window_bits, windows, max_chain;   /* shape of the right-hand bucket MSM; max_chain: entries per lane */
 } h2v_rlc_timings;
 int h2v_verify_batch_rlc(const h2v_plan *plan, const h2v_batch *batch, uint8_t *accept, h2v_workspace *ws,
                          const h2v_rlc_opts *opts /* or NULL */, int *fell_back /* or NULL: 1 = the per-proof kernels ran */);

@@ -38,7 +38,7 @@ class RlcTimings(C.Structure):
     _fields_ = [("transcript_combiner_ms", C.c_float), ("g1_decompress_ms", C.c_float), ("prepare_ms", C.c_float),
                 ("bucket_sort_ms", C.c_float), ("bucket_accumulate_ms", C.c_float), ("bucket_reduce_ms", C.c_float),
                 ("pairing_ms", C.c_float), ("total_ms", C.c_float), ("msm_terms", C.c_uint32),
-                ("window_bits", C.c_uint32), ("windows", C.c_uint32), ("lanes_per_bucket", C.c_uint32)]
+                ("window_bits", C.c_uint32), ("windows", C.c_uint32), ("max_chain", C.c_uint32)]
 
 
 RLC_SEED_GIVEN = 1

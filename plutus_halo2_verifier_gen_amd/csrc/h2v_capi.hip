@@ -395,10 +395,11 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
         WSALLOC(fold_scal, (size_t)max_batch * 4 * 32)
     }
 #undef WSALLOC
+    // Streams are created on first use (ws_streams): the runtime maps streams onto a few hardware queues round robin, and
+    // streams that are never used would only make the ones in use collide (several batches in flight: bench.py --inflight).
     bool ok = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < h2v_workspace::MAXP && ok; k++)
-        ok = hipStreamCreateWithFlags(&w->pmain[k], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&w->pside[k], hipStreamNonBlocking) == hipSuccess &&
-             hipStreamCreateWithFlags(&w->psub[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&w->ev_sub[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->ev_fix[k], hipEventDisableTiming) == hipSuccess &&
+        ok = hipEventCreateWithFlags(&w->ev_sub[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->ev_fix[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&w->ev_join[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->ev_done[k], hipEventDisableTiming) == hipSuccess;
     for (auto &call : w->ring) for (auto &set : call) for (hipEvent_t &e : set)
         if (ok) ok = hipEventCreate(&e) == hipSuccess;
@@ -427,6 +428,14 @@ static int ws_fits(const h2v_workspace *w, const h2v_plan *p, uint64_t n, bool w
     if (d.ivc && !w->sz_ivc) return fail(H2V_E_ARG, "workspace was created for a non-recursive plan");
     if (d.fix_tab && !w->sz_fix) return fail(H2V_E_ARG, "workspace lacks the fixed-base sum buffer of this plan");
     if (want_trace && d.n_trace > w->sz_trace) return fail(H2V_E_ARG, "workspace has no trace buffer for this plan");
+    return H2V_OK;
+}
+
+// the main / side / third stream of pipeline chunk k, created when first asked for
+static int ws_streams(h2v_workspace *w, int k, bool need_main, bool need_side, bool need_sub) {
+    if (need_main && !w->pmain[k]) HIPCHK(hipStreamCreateWithFlags(&w->pmain[k], hipStreamNonBlocking));
+    if (need_side && !w->pside[k]) HIPCHK(hipStreamCreateWithFlags(&w->pside[k], hipStreamNonBlocking));
+    if (need_sub && !w->psub[k]) HIPCHK(hipStreamCreateWithFlags(&w->psub[k], hipStreamNonBlocking));
     return H2V_OK;
 }
 
@@ -514,7 +523,10 @@ static uint32_t launch_msm_ladders(const H2vDevPlan &d, const H2vMsmArgs &ma, ui
     const uint32_t lpp = sh.lpt * ma.n_terms;
     const uint32_t per_block = sh.bs / lpp;
     const uint32_t blocks = (n + per_block - 1) / per_block;
-    if (sh.lpt == 1) hipLaunchKernelGGL(k_g1_msm_merged, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+    if (ma.skip) {   // fall-back of the RLC batch mode
+        if (sh.lpt == 1) hipLaunchKernelGGL(k_g1_msm_merged_cond, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+        else hipLaunchKernelGGL(k_g1_msm_cond, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+    } else if (sh.lpt == 1) hipLaunchKernelGGL(k_g1_msm_merged, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
     else hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
     return sh.lpt;
 }
@@ -634,6 +646,8 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
     for (int k = 0; k < pipes; k++) {
         const uint32_t lo = (uint32_t)((uint64_t)n * k / pipes), hi = (uint32_t)((uint64_t)n * (k + 1) / pipes), m = hi - lo;
         hipEvent_t *ev = w->ring[slot][k];
+        static const bool dec_queue_on = []() { const char *e = getenv("H2V_DEC_QUEUE"); return e ? atoi(e) != 0 : true; }();
+        if (int rcs = ws_streams(w, k, true, true, split_dec && !dec_queue_on)) return rcs;
         hipStream_t pm = w->pmain[k], ps = w->pside[k];
         const uint64_t *off_k = off + lo;
         const uint8_t *inst_k = inst ? inst + (size_t)lo * d.n_pi * 32 : nullptr;
@@ -677,7 +691,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         auto sub_half = [&]() {
             // the subgroup tests as a launch of their own (only without the queue)
             if (!split_dec) return 0;
-            hipStream_t pb = w->psub[k];
+            hipStream_t pb = dec_queue ? ps : w->psub[k];   // (with the queue there is no third launch: only the events are recorded)
             HIPCHK(hipStreamWaitEvent(pb, w->ev_fork, 0));
             HIPCHK(hipEventRecord(ev[7], pb));
             if (!dec_queue) hipLaunchKernelGGL(k_g1_decompress, dim3(dec_grid), dim3(64), 0, pb, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, (uint32_t *)nullptr, 2u, vsub_k);
@@ -857,11 +871,11 @@ extern "C" int h2v_verify_batch(const h2v_plan *p, const h2v_batch *b, uint8_t *
 // Device buffers of one bucket MSM over at most cap_n terms (h2v_pippenger.hpp).
 struct PipWs {
     uint32_t cap_n = 0, cap_halves = 0;
-    uint32_t *pts28 = nullptr, *cnt = nullptr, *off = nullptr, *order = nullptr, *list = nullptr, *partial = nullptr, *wsum = nullptr;
+    uint32_t *pts28 = nullptr, *cnt = nullptr, *off = nullptr, *order = nullptr, *cls = nullptr, *list = nullptr, *partial = nullptr, *wsum = nullptr;
     int16_t *dig = nullptr;
 };
 static void pip_free(PipWs &w) {
-    void *ptrs[] = {w.pts28, w.cnt, w.off, w.order, w.list, w.partial, w.wsum, w.dig};
+    void *ptrs[] = {w.pts28, w.cnt, w.off, w.order, w.cls, w.list, w.partial, w.wsum, w.dig};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     w = PipWs();
 }
@@ -872,49 +886,60 @@ static int pip_alloc(PipWs &w, uint32_t cap_n, uint32_t halves) {
     bool ok = hipMalloc((void **)&w.pts28, (size_t)(cap_n ? cap_n : 1) * PIP_PT_DW * 4) == hipSuccess &&
               hipMalloc((void **)&w.dig, (ent ? ent : 1) * 2) == hipSuccess && hipMalloc((void **)&w.list, (ent ? ent : 1) * 4) == hipSuccess &&
               hipMalloc((void **)&w.cnt, nbmax * 4) == hipSuccess && hipMalloc((void **)&w.off, (nbmax + 1) * 4) == hipSuccess &&
-              hipMalloc((void **)&w.order, nbmax * 4) == hipSuccess && hipMalloc((void **)&w.partial, nbmax * PIP_PART_DW * 4) == hipSuccess &&
+              hipMalloc((void **)&w.order, nbmax * 4) == hipSuccess && hipMalloc((void **)&w.cls, PIP_CLS_DW * 4) == hipSuccess && hipMalloc((void **)&w.partial, nbmax * PIP_PART_DW * 4) == hipSuccess &&
               hipMalloc((void **)&w.wsum, (size_t)PIP_MAX_W * PIP_PART_DW * 4) == hipSuccess;
     if (!ok) { pip_free(w); return fail(H2V_E_DEVICE, "hipMalloc(bucket MSM workspace) failed"); }
     return H2V_OK;
 }
-// Window width and lanes per bucket for n terms.  Larger windows mean fewer windows (W = floor(128 / c) + 1 per GLV half)
-// but 2^(c-1) buckets per window, capped at 512 so that one block's LDS holds a window in k_pip_reduce; a bucket's slice
-// is shared by 2^lpb lanes so that the launch has about one wave per SIMD (chains shorter than ~4 additions are not
-// worth a lane: the partial sums meet in complete additions).  H2V_PIP_C / H2V_PIP_LPB force a shape (tests).
+// Window width for n terms.  Larger windows mean fewer windows (W = floor(128 / c) + 1 per GLV half) but 2^(c-1) buckets
+// per window, capped at 512 so that one block's LDS holds a window in k_pip_reduce; at least ~24 entries per bucket on
+// average.  chain = the most entries one lane of k_pip_accumulate sums (a bucket of more gets 2, 4, ... 256 lanes): short
+// chains mean more lanes and deeper trees of complete additions.  H2V_PIP_C / H2V_PIP_CHAIN force a shape (tests, tuning).
 static void pip_shape(PipArgs &a) {
     static const int env_c = []() { const char *e = getenv("H2V_PIP_C"); return e ? atoi(e) : 0; }();
-    static const int env_lpb = []() { const char *e = getenv("H2V_PIP_LPB"); return e ? atoi(e) : -1; }();
+    static const int env_chain = []() { const char *e = getenv("H2V_PIP_CHAIN"); return e ? atoi(e) : 0; }();
     const double entries_per_window = (double)a.n * a.halves;
     uint32_t c = PIP_MAX_C;
-    while (c > 4 && entries_per_window / (double)(1u << (c - 1)) < 24.0) c--;   // keep ~24+ entries per bucket
+    while (c > 4 && entries_per_window / (double)(1u << (c - 1)) < 24.0) c--;
     if (env_c >= 3 && env_c <= PIP_MAX_C) c = (uint32_t)env_c;
     a.c = c; a.NB = 1u << (c - 1); a.W = 128 / c + 1;
     while (a.W > PIP_MAX_W) { a.c++; a.NB <<= 1; a.W = 128 / a.c + 1; }
-    const double per_bucket = entries_per_window / a.NB, lanes1 = (double)a.W * a.NB;
-    uint32_t lg = 0;
-    while (lg < 4 && lanes1 * (1u << (lg + 1)) <= 4.0 * msm_n_simd() * 64.0 / 4.0 * 1.5 && per_bucket / (1u << (lg + 1)) >= 4.0) lg++;
-    if (env_lpb >= 0 && env_lpb <= 4) lg = (uint32_t)env_lpb;
-    a.lpb_log = lg;
+    a.chain = env_chain >= 2 && env_chain <= 1024 ? (uint32_t)env_chain : 20u;
 }
-// Enqueues the six kernels of one bucket MSM on `st`.  a: n, halves, scal, pidx, pool0 / n_pool0 / pool1, out filled in.
-// ev (optional): 4 events recorded at the start, before and after k_pip_accumulate, and at the end.
-static int pip_launch(const PipWs &w, PipArgs a, hipStream_t st, hipEvent_t *ev) {
-    if (a.n > w.cap_n || a.halves > w.cap_halves) return fail(H2V_E_ARG, "bucket MSM workspace too small");
+static void pip_bind(const PipWs &w, PipArgs &a) {
     pip_shape(a);
-    a.pts28 = w.pts28; a.dig = w.dig; a.cnt = w.cnt; a.off = w.off; a.order = w.order; a.list = w.list; a.partial = w.partial; a.wsum = w.wsum;
-    const uint32_t nb = a.W * a.NB;
+    a.pts28 = w.pts28; a.dig = w.dig; a.cnt = w.cnt; a.off = w.off; a.order = w.order; a.cls = w.cls; a.list = w.list; a.partial = w.partial; a.wsum = w.wsum;
+}
+// Enqueues the six kernels of one or two bucket MSMs (np problems side by side in every launch) on `st`.
+// a[]: n, halves, scal, pidx, pool0 / n_pool0 / pool1, out filled in.  ev (optional): 4 events recorded at the start,
+// before and after k_pip_accumulate, and at the end.
+static int pip_launch(const PipWs *const *ws, PipArgs *a, uint32_t np, hipStream_t st, hipEvent_t *ev) {
+    PipArgs2 a2 = {};
+    uint32_t max_n = 0, max_W = 0, max_NB = 0, max_acc_blocks = 0;
+    for (uint32_t q = 0; q < np; q++) {
+        if (a[q].n > ws[q]->cap_n || a[q].halves > ws[q]->cap_halves) return fail(H2V_E_ARG, "bucket MSM workspace too small");
+        pip_bind(*ws[q], a[q]);
+        a2.p[q] = a[q];
+        const uint32_t nb = a[q].W * a[q].NB;
+        // lanes of k_pip_accumulate: a bucket of count cnt > T gets fewer than 2 cnt / T lanes, any other non-empty one 1; each
+        // class is padded to whole blocks
+        const uint64_t lanes = 2ull * a[q].n * a[q].halves * a[q].W / a[q].chain + nb + 256ull * PIP_N_CLASSES;
+        max_n = a[q].n > max_n ? a[q].n : max_n; max_W = a[q].W > max_W ? a[q].W : max_W; max_NB = a[q].NB > max_NB ? a[q].NB : max_NB;
+        const uint32_t blocks = (uint32_t)((lanes + 255) / 256);
+        max_acc_blocks = blocks > max_acc_blocks ? blocks : max_acc_blocks;
+    }
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
-    HIPCHK(hipMemsetAsync(a.cnt, 0, (size_t)nb * 4, st));
-    if (a.n) hipLaunchKernelGGL(k_pip_digits, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_pip_scan, dim3(1), dim3(1024), 0, st, a);
-    if (a.n) hipLaunchKernelGGL(k_pip_scatter, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+    for (uint32_t q = 0; q < np; q++) HIPCHK(hipMemsetAsync(a[q].cnt, 0, (size_t)a[q].W * a[q].NB * 4, st));
+    if (max_n) hipLaunchKernelGGL(k_pip_digits, dim3((max_n + 255) / 256, np), dim3(256), 0, st, a2);
+    hipLaunchKernelGGL(k_pip_scan, dim3(1, np), dim3(1024), 0, st, a2);
+    if (max_n) hipLaunchKernelGGL(k_pip_scatter, dim3((max_n + 255) / 256, np), dim3(256), 0, st, a2);
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
-    hipLaunchKernelGGL(k_pip_accumulate, dim3((uint32_t)(((uint64_t)nb << a.lpb_log) + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_pip_accumulate, dim3(max_acc_blocks, np), dim3(256), 0, st, a2);
     if (ev) HIPCHK(hipEventRecord(ev[2], st));
-    const size_t lds = (size_t)43 * a.NB * 4;
+    const size_t lds = (size_t)43 * max_NB * 4;
     HIPCHK(hipFuncSetAttribute((const void *)k_pip_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_pip_reduce, dim3(a.W), dim3(a.NB), lds, st, a);
-    hipLaunchKernelGGL(k_pip_combine, dim3(1), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_pip_reduce, dim3(max_W, np), dim3(max_NB), lds, st, a2);
+    hipLaunchKernelGGL(k_pip_combine, dim3(1, np), dim3(64), 0, st, a2);
     if (ev) HIPCHK(hipEventRecord(ev[3], st));
     HIPCHK(hipGetLastError());
     return H2V_OK;
@@ -929,20 +954,15 @@ struct RlcWs {
     PipWs R, L;
     uint32_t *sums = nullptr;   // er (36 dwords) then el (36): the two MSM results
     uint32_t *misc = nullptr;   // [0..23] a dummy affine point, [24] status of the batch check, [25] skip flag, [26] its valid byte, [27] its accept byte
-    hipStream_t sl = nullptr;   // the left-hand MSM runs beside the right-hand one
-    hipEvent_t ev_prep = nullptr, ev_l = nullptr;
-    static constexpr int NEV = 10;
+    static constexpr int NEV = 11;
     hipEvent_t ring[h2v_workspace::RING][NEV] = {};
     uint64_t calls = 0;
-    uint32_t last_c = 0, last_W = 0, last_lpb = 0, last_terms = 0;
+    uint32_t last_c = 0, last_W = 0, last_chain = 0, last_terms = 0;
 };
 static void rlc_release(RlcWs *r) {
     void *ptrs[] = {r->r_scal, r->r_idx, r->l_scal, r->l_idx, r->vk_part, r->good, r->sums, r->misc};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     pip_free(r->R); pip_free(r->L);
-    if (r->sl) (void)hipStreamDestroy(r->sl);
-    if (r->ev_prep) (void)hipEventDestroy(r->ev_prep);
-    if (r->ev_l) (void)hipEventDestroy(r->ev_l);
     for (auto &set : r->ring) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
     delete r;
 }
@@ -956,9 +976,7 @@ static int rlc_ensure(h2v_workspace *w, const h2v_plan *p) {
               hipMalloc((void **)&r->l_scal, (size_t)w->cap * 32) == hipSuccess && hipMalloc((void **)&r->l_idx, (size_t)w->cap * 4) == hipSuccess &&
               hipMalloc((void **)&r->vk_part, blocks * (p->n_fix ? p->n_fix : 1) * 32) == hipSuccess && hipMalloc((void **)&r->good, w->cap) == hipSuccess &&
               hipMalloc((void **)&r->sums, 72 * 4) == hipSuccess && hipMalloc((void **)&r->misc, 32 * 4) == hipSuccess &&
-              hipMemset(r->misc, 0, 32 * 4) == hipSuccess &&
-              hipStreamCreateWithFlags(&r->sl, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&r->ev_prep, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&r->ev_l, hipEventDisableTiming) == hipSuccess;
+              hipMemset(r->misc, 0, 32 * 4) == hipSuccess;
     for (auto &set : r->ring) for (hipEvent_t &e : set) if (ok) ok = hipEventCreate(&e) == hipSuccess;
     if (ok) ok = pip_alloc(r->R, (uint32_t)nr, 2) == H2V_OK && pip_alloc(r->L, (uint32_t)w->cap, 1) == H2V_OK;
     if (!ok) { rlc_release(r); return fail(H2V_E_DEVICE, "RLC workspace allocation failed"); }
@@ -978,9 +996,10 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     const uint32_t slots = H2V_SLOTS(d);
     hipEvent_t *ev = r->ring[r->calls % h2v_workspace::RING];
     r->calls++;
-    hipStream_t pm = w->pmain[0], ps = w->pside[0];
+    // two streams per batch: the caller's (transcript + combiner, then everything else) and one for the decompression
+    if ((rc = ws_streams(w, 0, false, true, false))) return rc;
+    hipStream_t pm = st, ps = w->pside[0];
     HIPCHK(hipEventRecord(w->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(pm, w->ev_fork, 0));
     HIPCHK(hipStreamWaitEvent(ps, w->ev_fork, 0));
     // phase 1
     HIPCHK(hipEventRecord(ev[0], ps));
@@ -989,7 +1008,8 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
         uint32_t blocks = (units + 3) / 4;
         if (blocks > max_blocks) blocks = max_blocks;
         HIPCHK(hipMemsetAsync(w->dec_ctr, 0, 4, ps));
-        hipLaunchKernelGGL(k_g1_decompress_queue, dim3(blocks), dim3(256), 0, ps, d, n, proofs, off, ci, inst, w->pts, w->valid, (uint32_t *)nullptr, w->valid_sub, w->dec_ctr, dec_grid);
+        static const bool dbg_tables = getenv("H2V_RLC_TABLES") != nullptr;   // experiment knob: build the (unused) window tables as the per-proof mode does
+        hipLaunchKernelGGL(k_g1_decompress_queue, dim3(blocks), dim3(256), 0, ps, d, n, proofs, off, ci, inst, w->pts, w->valid, dbg_tables ? w->pt_tab : (uint32_t *)nullptr, w->valid_sub, w->dec_ctr, dec_grid);
     }
     HIPCHK(hipEventRecord(ev[1], ps));
     HIPCHK(hipEventRecord(w->ev_join[0], ps));
@@ -998,27 +1018,23 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     if (rc) return rc;
     HIPCHK(hipEventRecord(ev[3], pm));
     HIPCHK(hipStreamWaitEvent(pm, w->ev_join[0], 0));
+    HIPCHK(hipEventRecord(ev[10], pm));
     // the batch check
     RlcArgs ra = {n, p->n_var, p->n_fix, slots, d.pi_point, d.n_terms, d.terms, w->scalars, w->status, w->valid, w->valid_sub, {},
                   r->r_scal, r->r_idx, r->l_scal, r->l_idx, r->vk_part, r->good};
     for (int k = 0; k < 8; k++) ra.seed[k] = seed[k];
     const uint32_t blocks = (n + 63) / 64;
     hipLaunchKernelGGL(k_rlc_prepare, dim3(blocks), dim3(64), 0, pm, ra);
-    HIPCHK(hipEventRecord(r->ev_prep, pm));
     hipLaunchKernelGGL(k_rlc_vk_sum, dim3((p->n_fix + 63) / 64), dim3(64), 0, pm, ra, blocks);
     HIPCHK(hipEventRecord(ev[4], pm));
-    // left-hand side on its own stream (needs only r_i and pi_i)
-    HIPCHK(hipStreamWaitEvent(r->sl, r->ev_prep, 0));
-    PipArgs la = {};
-    la.n = n; la.halves = 1; la.scal = r->l_scal; la.pidx = r->l_idx; la.pool0 = w->pts; la.n_pool0 = n * slots; la.pool1 = nullptr; la.out = r->sums + 36;
-    if ((rc = pip_launch(r->L, la, r->sl, nullptr))) return rc;
-    HIPCHK(hipEventRecord(r->ev_l, r->sl));
-    PipArgs rga = {};
-    rga.n = n * p->n_var + p->n_fix; rga.halves = 2; rga.scal = r->r_scal; rga.pidx = r->r_idx; rga.pool0 = w->pts; rga.n_pool0 = n * slots;
-    rga.pool1 = d.vk_bases; rga.out = r->sums;
-    if ((rc = pip_launch(r->R, rga, pm, ev + 5))) return rc;   // ev[5..8]
-    { PipArgs tmp = rga; pip_shape(tmp); r->last_c = tmp.c; r->last_W = tmp.W; r->last_lpb = tmp.lpb_log; r->last_terms = rga.n; }
-    HIPCHK(hipStreamWaitEvent(pm, r->ev_l, 0));
+    // both sums in the same launches: R = sum r_i er_i (255-bit scalars, GLV) and L = sum r_i pi_i (128-bit scalars)
+    PipArgs pa[2] = {};
+    pa[0].n = n * p->n_var + p->n_fix; pa[0].halves = 2; pa[0].scal = r->r_scal; pa[0].pidx = r->r_idx; pa[0].pool0 = w->pts; pa[0].n_pool0 = n * slots;
+    pa[0].pool1 = d.vk_bases; pa[0].out = r->sums;
+    pa[1].n = n; pa[1].halves = 1; pa[1].scal = r->l_scal; pa[1].pidx = r->l_idx; pa[1].pool0 = w->pts; pa[1].n_pool0 = n * slots; pa[1].pool1 = nullptr; pa[1].out = r->sums + 36;
+    const PipWs *pws[2] = {&r->R, &r->L};
+    if ((rc = pip_launch(pws, pa, 2, pm, ev + 5))) return rc;   // ev[5..8]
+    r->last_c = pa[0].c; r->last_W = pa[0].W; r->last_chain = pa[0].chain; r->last_terms = pa[0].n;
     // one pairing check over a one-proof view of the plan: el = L, er = R (both Jacobian), no per-proof points
     H2vDevPlan d1 = d;
     d1.n_points = 1; d1.n_ci = 0; d1.ivc = 0; d1.pi_point = 0;
@@ -1037,8 +1053,6 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
         launch_msm_range(d, ma, n, w->scalars, w->pts, nullptr, pm);
     }
     launch_pairing_impl(1, d, n, w->pts, w->valid, w->valid_sub, w->er, nullptr, w->status, accept, nullptr, pm, skip);
-    HIPCHK(hipEventRecord(w->ev_done[0], pm));
-    HIPCHK(hipStreamWaitEvent(st, w->ev_done[0], 0));
     HIPCHK(hipGetLastError());
     if (status_out) HIPCHK(hipMemcpyAsync(status_out, w->status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
     return H2V_OK;
@@ -1112,7 +1126,7 @@ extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, u
         HIPCHK(hipEventSynchronize(ev[9]));
         HIPCHK(hipEventElapsedTime(&tm->g1_decompress_ms, ev[0], ev[1]));
         HIPCHK(hipEventElapsedTime(&tm->transcript_combiner_ms, ev[2], ev[3]));
-        HIPCHK(hipEventElapsedTime(&tm->prepare_ms, ev[3], ev[4]));
+        HIPCHK(hipEventElapsedTime(&tm->prepare_ms, ev[10], ev[4]));
         HIPCHK(hipEventElapsedTime(&tm->bucket_sort_ms, ev[5], ev[6]));
         HIPCHK(hipEventElapsedTime(&tm->bucket_accumulate_ms, ev[6], ev[7]));
         HIPCHK(hipEventElapsedTime(&tm->bucket_reduce_ms, ev[7], ev[8]));
@@ -1121,7 +1135,7 @@ extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, u
         HIPCHK(hipEventElapsedTime(&a0, ev[0], ev[9]));
         HIPCHK(hipEventElapsedTime(&a1, ev[2], ev[9]));
         tm->total_ms = a0 > a1 ? a0 : a1;
-        tm->msm_terms = r->last_terms; tm->window_bits = r->last_c; tm->windows = r->last_W; tm->lanes_per_bucket = 1u << r->last_lpb;
+        tm->msm_terms = r->last_terms; tm->window_bits = r->last_c; tm->windows = r->last_W; tm->max_chain = r->last_chain;
     }
     return H2V_OK;
 }
@@ -1281,7 +1295,8 @@ extern "C" int h2v_probe_g1_msm_pippenger(int device, uint32_t n, const uint8_t 
     if ((rc = pip_alloc(pw, n, 2))) return rc;
     PipArgs a = {};
     a.n = n; a.halves = 2; a.scal = dsc.as<uint32_t>(); a.pidx = nullptr; a.pool0 = dpts.as<uint32_t>(); a.n_pool0 = n; a.pool1 = nullptr; a.out = dres.as<uint32_t>();
-    rc = pip_launch(pw, a, nullptr, nullptr);
+    const PipWs *pws[1] = {&pw};
+    rc = pip_launch(pws, &a, 1, nullptr, nullptr);
     if (rc == H2V_OK) {
         hipLaunchKernelGGL(k_export_points, dim3(1), dim3(64), 0, nullptr, 1u, 1, dres.as<uint32_t>(), dout.as<uint8_t>());
         if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = fail(H2V_E_DEVICE, "bucket MSM kernels failed");

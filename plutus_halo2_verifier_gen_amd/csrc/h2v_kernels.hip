@@ -604,7 +604,7 @@ struct H2vMsmArgs {
     // lanes sums the fix_k terms f * fix_k ... of the range from the all-window tables fix_tab [base][65 windows][8][28]
     const uint32_t *fix_tab;
     uint32_t fix_k, n_fixl;
-    // RLC batch mode: the per-proof MSM queued behind the batch check returns at once when *skip != 0 (NULL: always runs)
+    // RLC batch mode: the per-proof MSM queued behind the batch check (k_g1_msm*_cond) returns at once when *skip != 0
     const uint32_t *skip;
 };
 // A proof owns exactly LPT * n_terms consecutive lanes of a block (no power-of-two padding: 34 terms used to occupy
@@ -626,7 +626,6 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
                      const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws,
                      uint32_t *red /* Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t] */) {
     static_assert(!FIX || LPT == 1, "fixed-base mode runs merged ladders");
-    if (ma.skip && ma.skip[0]) return;   // (uniform over the launch: before any barrier)
     constexpr int NH = 2 / LPT;   // GLV halves per lane
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
     const uint32_t lanes_per_proof = FIX ? ma.n_fixl : LPT * ma.n_terms;
@@ -858,6 +857,23 @@ extern "C" __global__ void __launch_bounds__(512, 2)
 k_g1_msm_merged(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
                 const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];
+    msm_body<1, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red);
+}
+
+// the same two ladders as the fall-back of the RLC batch mode: they return at once when the batch check passed.  (Separate
+// entry points: the check costs the parity path's kernels nothing, not even a different register allocation.)
+extern "C" __global__ void __launch_bounds__(512, 2)
+k_g1_msm_cond(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, const uint32_t *__restrict__ scalars,
+              const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
+    extern __shared__ uint32_t red[];
+    if (ma.skip[0]) return;   // (uniform over the launch: before any barrier)
+    msm_body<2, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red);
+}
+extern "C" __global__ void __launch_bounds__(512, 2)
+k_g1_msm_merged_cond(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, const uint32_t *__restrict__ scalars,
+                     const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
+    extern __shared__ uint32_t red[];
+    if (ma.skip[0]) return;
     msm_body<1, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red);
 }
 

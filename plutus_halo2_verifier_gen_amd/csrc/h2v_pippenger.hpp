@@ -13,13 +13,17 @@
 //   k_pip_digits      one lane per term: re-cut the base to the 14 x 28-bit lazy form once (x, y, beta x), split the
 //                     scalar k = k1 + k2 lambda (GLV: both halves < 2^128, phi(P) = (beta x, y)), recode both halves into
 //                     W signed digits in [-2^(c-1), 2^(c-1)], count bucket sizes (one counter per (window, |digit|))
-//   k_pip_scan        one block: exclusive prefix sum of the counters, and the bucket order by descending size
+//   k_pip_scan        one block: exclusive prefix sum of the counters, the bucket order by descending size, and the size
+//                     CLASSES: a bucket with count in (T 2^(k-1), T 2^k] gets 2^k lanes (k = 0..8), so that every lane
+//                     of the accumulation sums at most T entries whatever the digit distribution is (the top window of a
+//                     128-bit half holds 128 mod c bits: a few buckets with thousands of entries; without classes those
+//                     lanes ran 3 ms chains beside 0.3 ms ones); empty buckets get no lane
 //   k_pip_scatter     one lane per term: (term, half, sign) into its bucket's slice of the entry list
-//   k_pip_accumulate  THE bulk kernel: 2^lpb lanes per bucket, buckets taken in descending size so that the lanes of a wave
-//                     run chains of equal length; each lane sums its slice with mixed additions (8M + 3S, affine base read
-//                     once per use as 2 x 56 coalescable bytes).  Exceptional additions (equal / opposite points, which
-//                     adversarial or merely repeated proof points can produce) zero the running Z: detected ONCE at the
-//                     end of the chain, and that chain is then redone with the complete addition
+//   k_pip_accumulate  THE bulk kernel: buckets in descending size, 2^k neighbouring lanes per bucket of class k (a block
+//                     holds one class); each lane sums its slice with mixed additions (8M + 3S, affine base read once per
+//                     use as 2 x 56 bytes), the 2^k partial sums meet in an LDS tree.  Exceptional additions (equal /
+//                     opposite points, which adversarial or merely repeated proof points can produce) zero the running Z:
+//                     detected ONCE at the end of the chain, and that chain is then redone with the complete addition
 //   k_pip_reduce      one block per window: bucket partials -> sum_j j B_j by a suffix scan + tree sum in LDS (complete
 //                     additions, log depth), then the window's 2^(c w) by doublings
 //   k_pip_combine     sum of the W window values -> canonical Jacobian point
@@ -32,12 +36,14 @@
 #define PIP_PART_DW 44        // Jacobian partial sum: 42 limbs + infinity flag + pad (16-byte multiple)
 #define PIP_MAX_W 20
 #define PIP_MAX_C 10          // NB = 2^(c-1) <= 512 buckets per window: one block's LDS holds a window's bucket sums
+#define PIP_N_CLASSES 9       // lanes per bucket: 2^0 .. 2^8
+#define PIP_CLS_DW (3 * PIP_N_CLASSES + 1)   // per class: first rank, end rank, first lane; then the lane total
 
 struct PipArgs {
     uint32_t n;               // terms
     uint32_t c, W, NB;        // window bits, windows per half, buckets per window (2^(c-1))
     uint32_t halves;          // 2: 255-bit scalars split by GLV; 1: scalars below 2^128 (k2 = 0)
-    uint32_t lpb_log;         // log2 of the lanes per bucket in k_pip_accumulate
+    uint32_t chain;           // T: most entries a lane of k_pip_accumulate sums (bucket classes above)
     const uint32_t *scal;     // n x 8 canonical little-endian limbs (< r)
     const uint32_t *pidx;     // n point indices, or NULL for the identity map
     const uint32_t *pool0;    // affine Montgomery points (24 dwords; all-zero = infinity): indices [0, n_pool0)
@@ -48,11 +54,15 @@ struct PipArgs {
     uint32_t *cnt;            // W*NB counters, zeroed before k_pip_digits; reused as scatter cursors
     uint32_t *off;            // W*NB + 1 exclusive offsets
     uint32_t *order;          // W*NB bucket ids by descending size
+    uint32_t *cls;            // PIP_CLS_DW dwords written by k_pip_scan: the size classes
     uint32_t *list;           // entries: (term * 2 + half) | sign << 31
     uint32_t *partial;        // W*NB x PIP_PART_DW: bucket sums
     uint32_t *wsum;           // W x PIP_PART_DW: window values, already multiplied by 2^(c w)
     uint32_t *out;            // 36 dwords: canonical Jacobian result (Z = 0: infinity)
 };
+// Up to two independent MSMs share every launch (blockIdx.y picks one): the RLC mode's right- and left-hand sums run their
+// phases - and above all their latency-bound tails - side by side without a second stream.
+struct PipArgs2 { PipArgs p[2]; };
 
 H2V_DI const uint32_t *pip_point_ptr(const PipArgs &a, uint32_t n) {
     const uint32_t idx = a.pidx ? a.pidx[n] : n;
@@ -60,7 +70,8 @@ H2V_DI const uint32_t *pip_point_ptr(const PipArgs &a, uint32_t n) {
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-k_pip_digits(PipArgs a) {
+k_pip_digits(PipArgs2 a2) {
+    const PipArgs &a = a2.p[blockIdx.y];
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= a.n) return;
     const uint32_t *pp = pip_point_ptr(a, n);
@@ -117,9 +128,11 @@ k_pip_digits(PipArgs a) {
 }
 
 // One block of 1024 threads: off[] = exclusive prefix sum of cnt[] (nb buckets, + the total at off[nb]); order[] = bucket
-// ids by descending count (counting sort on min(count, 2047)); cnt[] is cleared (it becomes the scatter cursors).
+// ids by descending count (counting sort on min(count, 2047)); cls[] = the size classes; cnt[] is cleared (it becomes
+// the scatter cursors).
 extern "C" __global__ void __launch_bounds__(1024)
-k_pip_scan(PipArgs a) {
+k_pip_scan(PipArgs2 a2) {
+    const PipArgs &a = a2.p[blockIdx.y];
     __shared__ uint32_t part[1024];
     __shared__ uint32_t hist[2048];
     const uint32_t nb = a.W * a.NB, tid = threadIdx.x;
@@ -129,7 +142,7 @@ k_pip_scan(PipArgs a) {
     part[tid] = sum;
     hist[tid] = 0; hist[tid + 1024] = 0;
     __syncthreads();
-    // exclusive scan of the 1024 partial sums (Hillis-Steele in place, double step with a barrier each)
+    // inclusive scan of the 1024 partial sums (Hillis-Steele in place, a barrier on either side of the update)
     for (uint32_t d = 1; d < 1024; d <<= 1) {
         const uint32_t v = tid >= d ? part[tid - d] : 0u;
         __syncthreads();
@@ -145,10 +158,21 @@ k_pip_scan(PipArgs a) {
     }
     if (tid == 1023) a.off[nb] = part[1023];
     __syncthreads();
-    // start position of every count value in descending order: pos[v] = #buckets with count > v
     if (tid == 0) {
+        // hist[v] := number of buckets with count > v = the first rank of count v in descending order
         uint32_t acc = 0;
         for (int v = 2047; v >= 0; v--) { const uint32_t hv = hist[v]; hist[v] = acc; acc += hv; }
+        // classes, largest buckets first: class k = counts in (T 2^(k-1), T 2^k] (k = 8: everything above T 2^7; k = 0:
+        // 1 .. T); ranks [first, end) of the descending order, lanes from a multiple of 256 (a block holds one class)
+        uint32_t lane = 0, first = 0;
+        for (int k = PIP_N_CLASSES - 1; k >= 0; k--) {
+            const uint32_t low = k == 0 ? 0u : (a.chain << (k - 1));       // the class holds counts > low
+            const uint32_t end = hist[low < 2047u ? low : 2046u];            // buckets with count > low
+            a.cls[3 * k] = first; a.cls[3 * k + 1] = end; a.cls[3 * k + 2] = lane;
+            lane += (((end - first) << k) + 255u) & ~255u;
+            first = end;
+        }
+        a.cls[3 * PIP_N_CLASSES] = lane;
     }
     __syncthreads();
     for (uint32_t b = lo; b < hi; b++) {
@@ -160,7 +184,8 @@ k_pip_scan(PipArgs a) {
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-k_pip_scatter(PipArgs a) {
+k_pip_scatter(PipArgs2 a2) {
+    const PipArgs &a = a2.p[blockIdx.y];
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= a.n) return;
 #pragma unroll 1
@@ -186,16 +211,25 @@ H2V_DN void pip_add_entry_complete(G1J28 &acc, bool &acc_inf, const uint32_t *pt
 }
 
 extern "C" __global__ void __launch_bounds__(256, 2)
-k_pip_accumulate(PipArgs a) {
+k_pip_accumulate(PipArgs2 a2) {
+    const PipArgs &a = a2.p[blockIdx.y];
     __shared__ uint32_t red[43 * 256];   // partial sums of the block's lanes (dword d of thread t at red[d * 256 + t])
     const uint32_t tid = threadIdx.x;
     const uint32_t g = blockIdx.x * 256 + tid;
-    const uint32_t nb = a.W * a.NB, lpb = 1u << a.lpb_log;
-    const bool live = g < nb * lpb;
-    const uint32_t rank = live ? g >> a.lpb_log : 0u, q = g & (lpb - 1u);
-    const uint32_t b = a.order[rank];
+    if (blockIdx.x * 256 >= a.cls[3 * PIP_N_CLASSES]) return;   // (uniform: the grid is an upper bound)
+    // the block's class k (lane ranges are 256-aligned and laid out from k = 8 down to 0; empty classes have no lanes)
+    uint32_t k = 0;
+#pragma unroll 1
+    for (int kk = PIP_N_CLASSES - 1; kk >= 0; kk--) {
+        const uint32_t base = a.cls[3 * kk + 2], lanes = (a.cls[3 * kk + 1] - a.cls[3 * kk]) << kk;
+        if (blockIdx.x * 256 >= base && blockIdx.x * 256 < base + ((lanes + 255u) & ~255u)) k = (uint32_t)kk;
+    }
+    const uint32_t lpb = 1u << k, rel = g - a.cls[3 * k + 2];
+    const uint32_t rank = a.cls[3 * k] + (rel >> k), q = rel & (lpb - 1u);
+    const bool live = rank < a.cls[3 * k + 1];
+    const uint32_t b = a.order[live ? rank : 0u];
     const uint32_t lo = a.off[b], cnt = live ? a.off[b + 1] - lo : 0u;
-    const uint32_t e0 = lo + (uint32_t)(((uint64_t)cnt * q) >> a.lpb_log), e1 = lo + (uint32_t)(((uint64_t)cnt * (q + 1)) >> a.lpb_log);
+    const uint32_t e0 = lo + (uint32_t)(((uint64_t)cnt * q) >> k), e1 = lo + (uint32_t)(((uint64_t)cnt * (q + 1)) >> k);
     G1J28 acc;
     bool inf = true;
 #pragma unroll 1
@@ -232,7 +266,7 @@ k_pip_accumulate(PipArgs a) {
             }
         }
     }
-    // the 2^lpb lanes of a bucket are neighbours in the block: tree through LDS, complete additions
+    // the 2^k lanes of a bucket are neighbours in the block: tree through LDS, complete additions
 #define PIP_ACC_STORE()                                                                      \
     do {                                                                                     \
         _Pragma("unroll") for (int k = 0; k < 14; k++) {                                     \
@@ -265,17 +299,20 @@ k_pip_accumulate(PipArgs a) {
     }
 }
 
-// One block of NB threads per window w.  Thread t owns bucket j = t + 1 and computes
+// One block per window w, NB of its threads at work.  Thread t owns bucket j = t + 1 and computes
 //   suffix scan  S_t = sum_{u >= t} B_u   (Hillis-Steele, log2 NB rounds)      and      T = sum_t S_t = sum_j j B_j
 // with the values of the other threads read from LDS (dword d of thread t at red[d * NB + t]: conflict-free) and the
 // thread's own value in registers.  All additions are complete.  Thread 0 then applies the window's weight 2^(c w).
 extern "C" __global__ void __launch_bounds__(512)
-k_pip_reduce(PipArgs a) {
+k_pip_reduce(PipArgs2 a2) {
+    const PipArgs &a = a2.p[blockIdx.y];
     extern __shared__ uint32_t red[];
     const uint32_t w = blockIdx.x, t = threadIdx.x, NB = a.NB;
+    if (w >= a.W) return;                       // (uniform per block: the grid covers the wider of the two MSMs)
+    const bool mine = t < NB;                   // (the block is as wide as the larger NB of the two)
     G1J28 val;
     bool inf = true;
-    {
+    if (mine && a.off[w * NB + t + 1] != a.off[w * NB + t]) {   // an empty bucket had no lane: nothing was written for it
         const uint32_t *src = a.partial + (size_t)(w * NB + t) * PIP_PART_DW;
         if (!src[42]) {
 #pragma unroll
@@ -296,15 +333,15 @@ k_pip_reduce(PipArgs a) {
             (o).x.l[k] = red[k * NB + (src_t)]; (o).y.l[k] = red[(14 + k) * NB + (src_t)]; (o).z.l[k] = red[(28 + k) * NB + (src_t)]; \
         }                                                                                     \
     } while (0)
-    PIP_RED_STORE();
+    if (mine) PIP_RED_STORE();
     __syncthreads();
     for (uint32_t d = 1; d < NB; d <<= 1) {
-        const bool take = t + d < NB && red[42 * NB + t + d] == 0;
+        const bool take = mine && t + d < NB && red[42 * NB + t + d] == 0;
         G1J28 o;
         if (take) PIP_RED_LOAD(o, t + d);
         __syncthreads();
         if (take) g1j28_acc_add(val, inf, o, false);
-        PIP_RED_STORE();
+        if (mine) PIP_RED_STORE();
         __syncthreads();
     }
     for (uint32_t s = NB >> 1; s >= 1; s >>= 1) {
@@ -334,7 +371,8 @@ k_pip_reduce(PipArgs a) {
 
 // sum of the W weighted window values (one wave, tree through LDS) -> canonical Jacobian coordinates
 extern "C" __global__ void __launch_bounds__(64)
-k_pip_combine(PipArgs a) {
+k_pip_combine(PipArgs2 a2) {
+    const PipArgs &a = a2.p[blockIdx.y];
     __shared__ uint32_t red[43 * 64];
     const uint32_t t = threadIdx.x;
     G1J28 val;
