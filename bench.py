@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="proofs per GPU (weak) / in total (strong); default: the workload's BASELINE size")
     ap.add_argument("--mode", default="per-proof", choices=["per-proof", "rlc"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--inflight", type=int, default=0, help="steps in flight (workspaces / streams); default 1 (per-proof), 5 (rlc)")
+    ap.add_argument("--inflight", type=int, default=0, help="steps in flight (workspaces / streams); default: 2 (per-proof, batches above 1024), 4 (per-proof, smaller), 5 (rlc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rlc-secondary", action="store_true", help="per-proof runs: skip the extra measurement of the RLC mode")
     ap.add_argument("--cpu-sample", type=int, default=1024)
@@ -112,7 +112,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    inflight = args.inflight or (5 if args.mode == "rlc" else 1)
+    # steps in flight: measured on MI355X - per-proof simple_mul x4096: 1 -> 6.11 ms per step, 2 -> 5.29,
+    # 3 -> 5.25; the 512 / 1024-proof batches of the large circuits, whose kernels are lone-wave chains: 1 -> 4.98 / 5.51 ms,
+    # 4 -> 2.74 / 3.31; RLC: 1 -> 5.7 ms, 5 -> 2.1 (its tail - bucket reduction, doublings, ONE pairing - is a few waves)
+    small = (args.batch or WORKLOADS[args.workload][1]) <= 1024
+    inflight = args.inflight or (5 if args.mode == "rlc" else 4 if small else 2)
     # several steps in flight use 3 streams each: more hardware queues than the runtime's default of 4, or they serialise
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
@@ -258,6 +262,18 @@ def main():
         batch_latency_ms = span / k_steps
         all_batch_ok = None
 
+    # with several steps in flight the event-timed kernel durations include what the kernels lose to each other; a short
+    # pass with ONE step in flight gives the kernels' own durations beside them
+    kernel_ms_alone = None
+    if inflight > 1 and args.mode == "per-proof":
+        _el1, wss1, _acc1 = timed_run("per-proof", 1, 5, 1, False)
+        a1 = {"transcript_combiner": 0.0, "g1_decompress": 0.0, "g1_msm": 0.0, "pairing": 0.0}
+        for j in range(5):
+            tm = wss1[0].timings(j)
+            a1["transcript_combiner"] += tm.transcript_combiner_ms / 5; a1["g1_decompress"] += tm.g1_decompress_ms / 5
+            a1["g1_msm"] += tm.g1_msm_ms / 5; a1["pairing"] += tm.pairing_ms / 5
+        kernel_ms_alone = dict(a1, ms_per_step=_el1 / 5 * 1e3)
+        del wss1
     n_accept = int(accept.sum())
     ok_all = n_accept == B  # the synthetic batch is 100 % accepting
     if world > 1:
@@ -391,6 +407,11 @@ def main():
             "int_roofline": int_roof(dominant),
             "msm_int_roofline": int_roof(msm_key),
             "kernel_ms": {kname[k]: round(v, 4) for k, v in kernel_ms.items()},
+            "kernel_ms_one_step_in_flight": ({kname[k]: round(v, 4) for k, v in kernel_ms_alone.items() if k in kname} if kernel_ms_alone else None),
+            "ms_per_step_one_step_in_flight": round(kernel_ms_alone["ms_per_step"], 4) if kernel_ms_alone else None,
+            "step_int_roofline": {"what": "analytical lane-level multiply-adds of ALL kernels of a step / ms_per_step, against the measured v_mad_u64_u32 ceiling",
+                                  "achieved": round(sum(mads.values()) / (elapsed / args.steps) / 1e12, 3), "peak": round(IMAD_PEAK_TOPS, 2) if IMAD_PEAK_TOPS else None,
+                                  "unit": "T lane-mad/s", "frac": round(sum(mads.values()) / (elapsed / args.steps) / 1e12 / IMAD_PEAK_TOPS, 4) if IMAD_PEAK_TOPS else None},
             "batch_latency_ms": round(batch_latency_ms, 4),
             "pipelines_per_step": launches, "msm_lanes_per_term": msm_lpt,
             "all_accepted": ok_all,

@@ -93,6 +93,17 @@ int h2v_workspace_timings(h2v_workspace *ws, uint32_t calls_back, h2v_timings *o
  * ws may be NULL (a temporary workspace is created for the call). */
 int h2v_verify_batch(const h2v_plan *plan, const h2v_batch *batch, uint8_t *accept, h2v_workspace *ws);
 
+/* Asynchronous host-buffer form, for callers that stream batches: _submit copies the caller's buffers into pinned staging
+ * memory of `ws` (they may be reused at once), enqueues ONE upload, the verification (per proof, or the RLC batch mode with
+ * H2V_SUBMIT_RLC - see below) and the download of accept[] on the workspace's own stream, and returns; _wait blocks until
+ * that batch is done and copies its accept bytes out.  One batch at a time per workspace: alternate two workspaces and the
+ * upload of batch k+1 runs beside the kernels of batch k.  h2v_verify_batch is _submit + _wait. */
+#define H2V_SUBMIT_RLC 1u
+struct h2v_rlc_opts_s;
+int h2v_verify_batch_submit(const h2v_plan *plan, const h2v_batch *batch, h2v_workspace *ws, uint32_t flags,
+                            const struct h2v_rlc_opts_s *rlc_opts /* or NULL */);
+int h2v_verify_batch_wait(h2v_workspace *ws, uint8_t *accept, int *fell_back /* or NULL */);
+
 /* Device-resident form: every pointer in `batch` and `accept`/`status` are DEVICE pointers on the plan's device
  * (e.g. torch tensors' data_ptr()); work is enqueued on `stream` (a hipStream_t, NULL = default stream) and the
  * call returns after enqueueing unless `timings` is given (then it synchronises to read the events).
@@ -112,7 +123,7 @@ int h2v_verify_batch_device(const h2v_plan *plan, const h2v_batch *batch, uint8_
  * seed (a rejecting proof hidden by the combination).  Recursive (IVC) plans have no batch form and run per proof.
  * ws must not be NULL for the device form. */
 #define H2V_RLC_SEED_GIVEN 1u
-typedef struct {
+typedef struct h2v_rlc_opts_s {
     uint8_t seed[32];   /* used when flags & H2V_RLC_SEED_GIVEN (tests, reproducible runs); must be unpredictable to provers */
     uint32_t flags;
 } h2v_rlc_opts;

@@ -42,6 +42,7 @@ class RlcTimings(C.Structure):
 
 
 RLC_SEED_GIVEN = 1
+SUBMIT_RLC = 1
 
 
 def _rlc_opts(seed):
@@ -56,7 +57,7 @@ def _rlc_opts(seed):
 EXPORTS = [
     "h2v_plan_load", "h2v_plan_free", "h2v_plan_info", "h2v_workspace_create", "h2v_workspace_free",
     "h2v_workspace_timings",
-    "h2v_verify_batch", "h2v_verify_batch_device", "h2v_verify_batch_rlc", "h2v_verify_batch_rlc_device",
+    "h2v_verify_batch", "h2v_verify_batch_submit", "h2v_verify_batch_wait", "h2v_verify_batch_device", "h2v_verify_batch_rlc", "h2v_verify_batch_rlc_device",
     "h2v_workspace_rlc_result", "h2v_probe_g1_msm_pippenger", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
     "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_pairing", "h2v_probe_pairing_ex",
     "h2v_last_error", "h2v_build_id",
@@ -85,6 +86,8 @@ def lib():
         L.h2v_verify_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
         L.h2v_verify_batch_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.POINTER(Timings)]
+        L.h2v_verify_batch_submit.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_uint32, C.POINTER(RlcOpts)]
+        L.h2v_verify_batch_wait.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.h2v_verify_batch_rlc.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.POINTER(RlcOpts),
                                            C.POINTER(C.c_int)]
         L.h2v_verify_batch_rlc_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -170,6 +173,17 @@ class DevicePlan:
         check(lib().h2v_verify_batch(self._h, C.byref(b), acc, ws.handle if ws else None))
         return bytes(acc[:n])
 
+    def host_batch(self, proofs: bytes, proof_off, instances: bytes, committed: Optional[bytes]):
+        """The batch as ctypes buffers a caller owns (what a Rust / C caller hands over): (h2v_batch, keep-alive)."""
+        n, b, keep = self._host_batch(proofs, proof_off, instances, committed)
+        return b, keep
+
+    def submit(self, batch: "Batch", ws, rlc: bool = False, seed: Optional[bytes] = None):
+        """h2v_verify_batch_submit: copy + upload + verification + download enqueued on the workspace's stream."""
+        opts = _rlc_opts(seed)
+        check(lib().h2v_verify_batch_submit(self._h, C.byref(batch), ws.handle, SUBMIT_RLC if rlc else 0,
+                                            C.byref(opts) if opts is not None else None))
+
     def verify_batch_rlc(self, proofs: bytes, proof_off, instances: bytes, committed: Optional[bytes], ws=None,
                          seed: Optional[bytes] = None):
         """Batch-accept fast path (h2v_verify_batch_rlc): returns (accept bytes, fell_back)."""
@@ -230,6 +244,13 @@ class Workspace:
         tm = Timings()
         check(lib().h2v_workspace_timings(self._h, calls_back, C.byref(tm)))
         return tm
+
+    def wait(self, n: int):
+        """h2v_verify_batch_wait for the batch submitted on this workspace: (accept bytes, fell_back)."""
+        acc = (C.c_uint8 * max(1, n))()
+        fb = C.c_int(0)
+        check(lib().h2v_verify_batch_wait(self._h, acc, C.byref(fb)))
+        return bytes(acc[:n]), bool(fb.value)
 
     def rlc_result(self, calls_back: int = 0, timings: bool = True):
         """(batch check passed?, RlcTimings) of a past RLC call on this workspace; synchronise its stream first."""

@@ -66,10 +66,18 @@ struct h2v_workspace {
     uint32_t *er_fix = nullptr;  // sum of the VK-base terms when the MSM is split into a ladder and a fixed-base launch
     uint32_t *dec_ctr = nullptr; // work-queue counters of the decompression launch (one per pipeline chunk)
     uint8_t *valid = nullptr, *valid_sub = nullptr, *accept = nullptr;
-    // staging for the host-buffer entry point
+    // Host-buffer entry points: the batch is packed into ONE pinned host block (offsets | instances | committed | proofs),
+    // uploaded with one asynchronous copy on the workspace's own stream `hs`, verified there, and the accept bytes come
+    // back into pinned memory the same way: h2v_verify_batch_submit returns once everything is enqueued, _wait collects.
+    // in_* point into the device block.
+    uint8_t *in_block = nullptr, *h_block = nullptr, *h_accept = nullptr;
+    size_t in_block_cap = 0, h_accept_cap = 0;
     uint8_t *in_proofs = nullptr, *in_inst = nullptr, *in_ci = nullptr;
     uint64_t *in_off = nullptr;
-    size_t in_proofs_cap = 0, in_inst_cap = 0, in_ci_cap = 0, in_off_cap = 0;
+    hipStream_t hs = nullptr;
+    hipEvent_t ev_host = nullptr;
+    bool pending = false, pending_rlc = false;
+    uint64_t pending_n = 0;
     // A batch is cut into up to MAXP chunks that run as independent pipelines on their own stream pairs, so that one
     // chunk's decompression / transcript kernels (few waves) overlap another chunk's MSM / pairing kernels.
     static constexpr int MAXP = 4;
@@ -347,9 +355,13 @@ static void rlc_release(struct RlcWs *r);
 static void ws_release(h2v_workspace *w) {
     (void)hipSetDevice(w->device);
     if (w->rlc) { rlc_release(w->rlc); w->rlc = nullptr; }
-    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->er_fix, w->dec_ctr, w->accept, w->in_proofs, w->in_inst, w->in_ci, w->in_off, w->msm_tab,
+    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->er_fix, w->dec_ctr, w->accept, w->in_block, w->msm_tab,
                     w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2, w->pt_tab};
     for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (w->h_block) (void)hipHostFree(w->h_block);
+    if (w->h_accept) (void)hipHostFree(w->h_accept);
+    if (w->hs) (void)hipStreamDestroy(w->hs);
+    if (w->ev_host) (void)hipEventDestroy(w->ev_host);
     for (hipStream_t q : w->pmain) if (q) (void)hipStreamDestroy(q);
     for (hipStream_t q : w->pside) if (q) (void)hipStreamDestroy(q);
     for (hipStream_t q : w->psub) if (q) (void)hipStreamDestroy(q);
@@ -818,38 +830,113 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
     return H2V_OK;
 }
 
+static int host_stream(h2v_workspace *ws) {
+    if (!ws->hs) HIPCHK(hipStreamCreateWithFlags(&ws->hs, hipStreamNonBlocking));
+    if (!ws->ev_host) HIPCHK(hipEventCreateWithFlags(&ws->ev_host, hipEventDisableTiming));
+    return H2V_OK;
+}
+// Packs the caller's host buffers into the pinned block and enqueues ONE upload on ws->hs.
 static int stage_inputs(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws) {
     const uint64_t n = b->n;
     const uint64_t total = b->proof_off[n];
     for (uint64_t i = 0; i < n; i++)
         if (b->proof_off[i + 1] < b->proof_off[i]) return fail(H2V_E_ARG, "proof offsets must be non-decreasing");
-    auto grow = [&](void **ptr, size_t *cap, size_t need) -> int {
-        if (need <= *cap && *ptr) return H2V_OK;
-        if (*ptr) (void)hipFree(*ptr);
-        *ptr = nullptr;
-        *cap = 0;
-        if (hipMalloc(ptr, need ? need : 8) != hipSuccess) return fail(H2V_E_DEVICE, "hipMalloc(staging) failed");
-        *cap = need ? need : 8;
-        return H2V_OK;
-    };
-    int rc;
-    if ((rc = grow((void **)&ws->in_proofs, &ws->in_proofs_cap, total + 64))) return rc;
-    if ((rc = grow((void **)&ws->in_off, &ws->in_off_cap, (n + 1) * 8))) return rc;
-    if ((rc = grow((void **)&ws->in_inst, &ws->in_inst_cap, n * p->d.n_pi * 32))) return rc;
-    if ((rc = grow((void **)&ws->in_ci, &ws->in_ci_cap, n * p->d.n_ci * 48))) return rc;
-    HIPCHK(hipMemcpy(ws->in_proofs, b->proofs, total, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ws->in_off, b->proof_off, (n + 1) * 8, hipMemcpyHostToDevice));
-    if (p->d.n_pi) HIPCHK(hipMemcpy(ws->in_inst, b->instances, n * p->d.n_pi * 32, hipMemcpyHostToDevice));
-    if (p->d.n_ci) HIPCHK(hipMemcpy(ws->in_ci, b->committed, n * 48, hipMemcpyHostToDevice));
+    int rc = host_stream(ws);
+    if (rc) return rc;
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_off = 0, o_inst = up16((n + 1) * 8), o_ci = o_inst + up16(n * p->d.n_pi * 32), o_proofs = o_ci + up16(n * p->d.n_ci * 48),
+                 need = o_proofs + up16(total + 64);
+    if (need > ws->in_block_cap) {
+        HIPCHK(hipStreamSynchronize(ws->hs));
+        if (ws->in_block) (void)hipFree(ws->in_block);
+        if (ws->h_block) (void)hipHostFree(ws->h_block);
+        ws->in_block = nullptr; ws->h_block = nullptr; ws->in_block_cap = 0;
+        const size_t cap = need + need / 4;
+        if (hipMalloc((void **)&ws->in_block, cap) != hipSuccess || hipHostMalloc((void **)&ws->h_block, cap, hipHostMallocDefault) != hipSuccess)
+            return fail(H2V_E_DEVICE, "staging allocation failed");
+        ws->in_block_cap = cap;
+    }
+    if (n > ws->h_accept_cap) {
+        if (ws->h_accept) (void)hipHostFree(ws->h_accept);
+        ws->h_accept = nullptr; ws->h_accept_cap = 0;
+        if (hipHostMalloc((void **)&ws->h_accept, n + n / 4 + 64, hipHostMallocDefault) != hipSuccess) return fail(H2V_E_DEVICE, "staging allocation failed");
+        ws->h_accept_cap = n + n / 4 + 64;
+    }
+    memcpy(ws->h_block + o_off, b->proof_off, (n + 1) * 8);
+    if (p->d.n_pi) memcpy(ws->h_block + o_inst, b->instances, n * p->d.n_pi * 32);
+    if (p->d.n_ci) memcpy(ws->h_block + o_ci, b->committed, n * 48);
+    memcpy(ws->h_block + o_proofs, b->proofs, total);
+    memset(ws->h_block + o_proofs + total, 0, 64);
+    HIPCHK(hipMemcpyAsync(ws->in_block, ws->h_block, need, hipMemcpyHostToDevice, ws->hs));
+    ws->in_off = (uint64_t *)(ws->in_block + o_off);
+    ws->in_inst = ws->in_block + o_inst;
+    ws->in_ci = ws->in_block + o_ci;
+    ws->in_proofs = ws->in_block + o_proofs;
     return H2V_OK;
 }
+static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
+                   uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, const uint32_t seed[8]);
+static bool rlc_supported(const h2v_plan *p);
+static int rlc_seed(const h2v_rlc_opts *o, uint32_t seed[8]);
 
-extern "C" int h2v_verify_batch(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, h2v_workspace *ws) {
+// Asynchronous host-buffer form: packs + uploads the batch, enqueues the verification (per-proof, or the RLC batch mode
+// with H2V_SUBMIT_RLC) and the download of accept[] on the workspace's stream, and returns.  The caller's buffers may be
+// reused as soon as this returns (they were copied into pinned memory).  One batch at a time per workspace: alternate two
+// workspaces to overlap the upload of batch k+1 with the kernels of batch k.
+extern "C" int h2v_verify_batch_submit(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws, uint32_t flags, const h2v_rlc_opts *opts) {
+    if (!p || !b || !ws) return fail(H2V_E_ARG, "null argument");
+    if (ws->pending) return fail(H2V_E_ARG, "the workspace already has a batch in flight: call h2v_verify_batch_wait first");
+    if (b->n && (!b->proofs || !b->proof_off)) return fail(H2V_E_ARG, "null proofs / offsets");
+    if (b->n && p->d.n_pi && !b->instances) return fail(H2V_E_ARG, "plan has public inputs but instances == NULL");
+    if (b->n && p->d.n_ci && !b->committed) return fail(H2V_E_ARG, "plan has a committed instance but committed == NULL");
+    HIPCHK(hipSetDevice(p->device));
+    int rc = host_stream(ws);
+    if (rc) return rc;
+    ws->pending_n = b->n;
+    ws->pending_rlc = false;
+    if (b->n) {
+        if ((rc = ws_fits(ws, p, b->n, false))) return rc;
+        if ((rc = stage_inputs(p, b, ws))) return rc;
+        const bool rlc = (flags & H2V_SUBMIT_RLC) && rlc_supported(p);
+        if (rlc) {
+            uint32_t seed[8];
+            if ((rc = rlc_seed(opts, seed))) return rc;
+            rc = run_rlc(p, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, ws->hs, seed);
+            ws->pending_rlc = true;
+        } else {
+            rc = run_pipeline(p->d, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, ws->hs, nullptr, false);
+        }
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(ws->h_accept, ws->accept, b->n, hipMemcpyDeviceToHost, ws->hs));
+    }
+    HIPCHK(hipEventRecord(ws->ev_host, ws->hs));
+    ws->pending = true;
+    return H2V_OK;
+}
+// Waits for the batch submitted on `ws`, copies its accept bytes out.  fell_back (optional): 1 when the batch was submitted
+// in RLC mode and the batch check failed, so that the per-proof kernels produced accept[].
+extern "C" int h2v_verify_batch_wait(h2v_workspace *ws, uint8_t *accept, int *fell_back) {
+    if (!ws || !accept) return fail(H2V_E_ARG, "null argument");
+    if (!ws->pending) return fail(H2V_E_ARG, "no batch in flight on this workspace");
+    HIPCHK(hipSetDevice(ws->device));
+    ws->pending = false;
+    HIPCHK(hipEventSynchronize(ws->ev_host));
+    if (ws->pending_n) memcpy(accept, ws->h_accept, ws->pending_n);
+    if (fell_back) {
+        *fell_back = 0;
+        if (ws->pending_rlc && ws->pending_n) {
+            uint32_t ok = 1;
+            int rc = h2v_workspace_rlc_result(ws, 0, &ok, nullptr);
+            if (rc) return rc;
+            *fell_back = ok ? 0 : 1;
+        }
+    }
+    return H2V_OK;
+}
+static int verify_host(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, h2v_workspace *ws, uint32_t flags, const h2v_rlc_opts *opts, int *fell_back) {
     if (!p || !b || !accept) return fail(H2V_E_ARG, "null argument");
+    if (fell_back) *fell_back = 0;
     if (b->n == 0) return H2V_OK;
-    if (!b->proofs || !b->proof_off) return fail(H2V_E_ARG, "null proofs / offsets");
-    if (p->d.n_pi && !b->instances) return fail(H2V_E_ARG, "plan has public inputs but instances == NULL");
-    if (p->d.n_ci && !b->committed) return fail(H2V_E_ARG, "plan has a committed instance but committed == NULL");
     HIPCHK(hipSetDevice(p->device));
     h2v_workspace *tmp = nullptr;
     int rc;
@@ -857,13 +944,13 @@ extern "C" int h2v_verify_batch(const h2v_plan *p, const h2v_batch *b, uint8_t *
         if ((rc = ws_create_for(p->d, p->device, b->n, false, &tmp))) return rc;
         ws = tmp;
     }
-    if ((rc = ws_fits(ws, p, b->n, false))) { if (tmp) h2v_workspace_free(tmp); return rc; }
-    rc = stage_inputs(p, b, ws);
-    if (rc == H2V_OK)
-        rc = run_pipeline(p->d, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, nullptr, nullptr, false);
-    if (rc == H2V_OK && hipMemcpy(accept, ws->accept, b->n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(H2V_E_DEVICE, "accept download failed");
+    rc = h2v_verify_batch_submit(p, b, ws, flags, opts);
+    if (rc == H2V_OK) rc = h2v_verify_batch_wait(ws, accept, fell_back);
     if (tmp) h2v_workspace_free(tmp);
     return rc;
+}
+extern "C" int h2v_verify_batch(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, h2v_workspace *ws) {
+    return verify_host(p, b, accept, ws, 0, nullptr, nullptr);
 }
 
 
@@ -1091,26 +1178,7 @@ extern "C" int h2v_verify_batch_rlc(const h2v_plan *p, const h2v_batch *b, uint8
                                     int *fell_back) {
     int rc = rlc_check_batch(p, b, accept);
     if (rc) return rc;
-    if (fell_back) *fell_back = 0;
-    if (b->n == 0) return H2V_OK;
-    HIPCHK(hipSetDevice(p->device));
-    h2v_workspace *tmp = nullptr;
-    if (!ws) {
-        if ((rc = ws_create_for(p->d, p->device, b->n, false, &tmp))) return rc;
-        ws = tmp;
-    }
-    rc = ws_fits(ws, p, b->n, false);
-    if (rc == H2V_OK) rc = stage_inputs(p, b, ws);
-    const h2v_batch db = {b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci};
-    if (rc == H2V_OK) rc = h2v_verify_batch_rlc_device(p, &db, ws->accept, nullptr, ws, nullptr, opts);
-    if (rc == H2V_OK && hipMemcpy(accept, ws->accept, b->n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(H2V_E_DEVICE, "accept download failed");
-    if (rc == H2V_OK && fell_back && ws->rlc && rlc_supported(p)) {
-        uint32_t skip = 1;
-        if (hipMemcpy(&skip, ws->rlc->misc + 25, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(H2V_E_DEVICE, "flag download failed");
-        *fell_back = skip ? 0 : 1;
-    }
-    if (tmp) h2v_workspace_free(tmp);
-    return rc;
+    return verify_host(p, b, accept, ws, H2V_SUBMIT_RLC, opts, fell_back);
 }
 // After the stream of an RLC call has been synchronised: did the batch check pass (1) or did the per-proof kernels run (0)?
 // kernel times of a past call (calls_back = 0: the most recent).
@@ -1153,7 +1221,8 @@ extern "C" int h2v_trace(const h2v_plan *p, const uint8_t *proof, size_t proof_l
     h2v_batch b = {1, proof, off, instances, committed};
     uint8_t *d_pts96 = nullptr;
     rc = stage_inputs(p, &b, ws);
-    if (rc == H2V_OK) rc = run_pipeline(p->d, 1, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, nullptr, nullptr, true);
+    if (rc == H2V_OK) rc = run_pipeline(p->d, 1, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, ws->hs, nullptr, true);
+    if (rc == H2V_OK && hipStreamSynchronize(ws->hs) != hipSuccess) rc = fail(H2V_E_DEVICE, "trace pipeline failed");
     do {
         if (rc) break;
         if (hipMalloc((void **)&d_pts96, 192) != hipSuccess) { rc = fail(H2V_E_DEVICE, "hipMalloc failed"); break; }

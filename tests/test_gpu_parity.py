@@ -265,6 +265,52 @@ def test_api_errors(be, circuits):
         dp.verify_batch(b1.proofs[:-1], b1.proof_off, b1.instances, b1.committed)
 
 
+def test_submit_wait_streams_batches_over_two_workspaces(be, circuits):
+    """h2v_verify_batch_submit / _wait: several different batches in flight on two workspaces (pinned staging, one
+    upload per batch), per-proof and RLC mode interleaved; every result == the oracle's vector for THAT batch; misuse
+    (second submit on a busy workspace, wait without submit) is an API error."""
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    n = 64
+    wss = [be.Workspace(dp, n), be.Workspace(dp, n)]
+    batches = []
+    for k in range(5):
+        b = synth.forge_batch(vk, td, n - 3 * k, seed=60 + k, plan=pl, workers=1)
+        b = synth.with_rejects(pl, b, 3, fraction=0.25 if k % 2 else 0.0, seed=k, kinds=["flip_first_scalar", "bad_point_flag", "truncated"])
+        batches.append(b)
+    got = [None] * 5
+    held = []
+    for k, b in enumerate(batches):
+        ws = wss[k % 2]
+        if k >= 2:
+            got[k - 2] = ws.wait(batches[k - 2].n)
+        hb, keep = dp.host_batch(b.proofs, b.proof_off, b.instances, b.committed)
+        dp.submit(hb, ws, rlc=(k % 3 == 1), seed=bytes([k]) * 32)
+        del hb, keep          # the caller's buffers may go away as soon as submit returns
+    with pytest.raises(be.H2VError, match="in flight"):
+        hb, keep = dp.host_batch(batches[0].proofs, batches[0].proof_off, batches[0].instances, None)
+        dp.submit(hb, wss[0])
+    for k in (3, 4):
+        got[k] = wss[k % 2].wait(batches[k].n)
+    with pytest.raises(be.H2VError, match="no batch"):
+        wss[0].wait(1)
+    for k, b in enumerate(batches):
+        want = ov.verify_batch(b.proofs, b.proof_off, b.instances, b.committed, threads=4)
+        assert list(got[k][0]) == list(want) == b.expected, k
+        assert got[k][1] == (k % 3 == 1 and any(e == 0 for e in b.expected) and k % 2 == 1 and _has_pairing_reject(b, batches, k, ov))
+
+
+def _has_pairing_reject(b, batches, k, ov):
+    """does batch b hold a proof that only the pairing rejects (the RLC batch check then fails and falls back)?"""
+    for i in range(b.n):
+        if b.expected[i] == 0:
+            ok, tr = ov.verify(b.proof(i), b.instance_ints(i, 3), None, trace=True)
+            from oracle import binding as orc
+            if orc.STATUS[tr.status] == "pairing":
+                return True
+    return False
+
+
 def _permute(batch, order, n_pi):
     from plutus_halo2_verifier_gen_amd import synth
     proofs = [batch.proof(i) for i in order]
