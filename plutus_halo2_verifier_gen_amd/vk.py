@@ -61,6 +61,8 @@ class VerifyingKey:
     # IVC / recursion (instantiation_data.rs:40,117-135): None = no accumulator in the public inputs; a list (possibly
     # empty) of inner verifying keys {name, transcript_repr, fixed_commitments, permutation_commitments} otherwise.
     recursion_vks: Optional[list] = None
+    # the JSON form of this object is frozen as docs/vk_schema.json ("h2v-vk/1"); a change of meaning bumps the number
+    schema_version: int = 1
 
     # ---- derived (instantiation_data.rs:84-103)
     @property
@@ -101,7 +103,8 @@ class VerifyingKey:
         return VKConstants(fixed_commitments=list(self.fixed_commitments),
                            permutation_commitments=list(self.permutation_commitments), s_g2=self.s_g2,
                            omega=self.omega, omega_inv=self.omega_inv, barycentric_weight=self.barycentric_weight,
-                           transcript_repr=self.transcript_repr, blinding_factors=self.blinding_factors)
+                           transcript_repr=self.transcript_repr, blinding_factors=self.blinding_factors,
+                           recursion_vks=[dict(v) for v in self.recursion_vks] if self.recursion_vks else None)
 
     def with_constants(self, c) -> "VerifyingKey":
         """This circuit shape with the commitments / s_g2 / transcript representation of an exported
@@ -116,9 +119,16 @@ class VerifyingKey:
         if len(c.fixed_commitments) != len(self.fixed_commitments) or \
                 len(c.permutation_commitments) != len(self.permutation_commitments):
             raise WireError("commitment counts differ from the circuit shape")
+        rec = self.recursion_vks
+        if c.recursion_vks is not None:   # the file carries the inner keys of a recursive circuit: they replace ours
+            if rec is None or [v["name"] for v in rec] != [v["name"] for v in c.recursion_vks] or \
+                    any(len(a["fixed_commitments"]) != len(b["fixed_commitments"]) or
+                        len(a["permutation_commitments"]) != len(b["permutation_commitments"]) for a, b in zip(rec, c.recursion_vks)):
+                raise WireError("inner verifying keys differ from the circuit shape")
+            rec = [dict(v) for v in c.recursion_vks]
         return replace(self, fixed_commitments=list(c.fixed_commitments),
                        permutation_commitments=list(c.permutation_commitments), s_g2=c.s_g2,
-                       transcript_repr=c.transcript_repr)
+                       transcript_repr=c.transcript_repr, recursion_vks=rec)
 
     @staticmethod
     def from_json(s: str) -> "VerifyingKey":
@@ -136,7 +146,118 @@ class VerifyingKey:
         d["lookups"] = [([tup(e) for e in i], [tup(e) for e in t]) for i, t in d["lookups"]]
         d["trashcans"] = [(tup(s), [tup(e) for e in c]) for s, c in d["trashcans"]]
         d["permutation_columns"] = [tuple(c) for c in d["permutation_columns"]]
-        return VerifyingKey(**d)
+        known = {f for f in VerifyingKey.__dataclass_fields__}
+        extra = sorted(set(d) - known)
+        if extra:
+            raise VKError("unknown field(s) in the verifying-key description: %s" % ", ".join(extra))
+        key = VerifyingKey(**d)
+        validate(key)
+        return key
+
+
+class VKError(ValueError):
+    """The verifying-key description is malformed, or describes a circuit the reference cannot emit a verifier for."""
+
+
+SCHEMA_VERSION = 1
+_EXPR_ARITY = {"const": 1, "fixed": 1, "advice": 1, "neg": 1, "sum": 2, "prod": 2, "scaled": 2}
+# Expression variants the reference panics on when it transpiles a gate / lookup / trashcan expression
+# (extraction/data/languages/aiken.rs:134-156): they must never reach the plan compiler either.
+_REFERENCE_PANICS = {"selector": "Selector not supported in custom gate", "instance": "Instance not supported",
+                     "challenge": "Challenge not supported"}
+
+
+def validate(vk: "VerifyingKey", strict_rotations: bool = False) -> None:
+    """Checks a verifying-key description against docs/vk_schema.json and against what the reference itself accepts:
+    raises VKError for a shape `extract_circuit` / the emitters would reject or panic on.
+      * expression nodes: only Constant / Fixed / Advice / Negated / Sum / Product / Scaled; Selector, Instance and
+        Challenge are a panic in the reference (languages/aiken.rs:134-156);
+      * every query index an expression uses exists; every permutation column has the query at rotation 0 the
+        permutation argument reads; committed-instance count 0 or 1 (extraction/mod.rs:41-55);
+      * with strict_rotations: only the rotations the emitted Aiken verifier can name - prev, cur, next, last and the
+        pre-computed x_rot_2 / x_rot_3 (rotation_description.rs:17-48, verification_h2.hbs:35-36).  This backend itself
+        handles any rotation."""
+    if vk.schema_version != SCHEMA_VERSION:
+        raise VKError("unsupported schema_version %r (this build reads %d)" % (vk.schema_version, SCHEMA_VERSION))
+    if not (1 <= vk.k <= TWO_ADICITY):
+        raise VKError("k out of range")
+    if vk.cs_degree < 3:
+        raise VKError("cs_degree must be at least 3 (chunk length cs_degree - 2)")
+    if vk.n_committed_instances not in (0, 1):
+        raise VKError("the reference supports 0 or 1 committed instance columns (extraction/mod.rs:41-55)")
+    if not (0 <= vk.transcript_repr < bls.R):
+        raise VKError("transcript_repr is not a canonical scalar")
+    for name, qs, ncols in (("advice", vk.advice_queries, vk.num_advice_columns), ("fixed", vk.fixed_queries, vk.num_fixed_columns),
+                            ("instance", vk.instance_queries, vk.n_committed_instances + 1)):
+        for col, rot in qs:
+            if not (0 <= col < ncols):
+                raise VKError("%s query names column %d of %d" % (name, col, ncols))
+            if strict_rotations and rot not in (-1, 0, 1, 2, 3):
+                raise VKError("rotation %d has no pre-computed point in the emitted verifier (verification_h2.hbs:32-37)" % rot)
+        if len(set(qs)) != len(qs):
+            raise VKError("duplicate %s query" % name)
+
+    def walk(e, where):
+        if not isinstance(e, (tuple, list)) or not e or not isinstance(e[0], str):
+            raise VKError("%s: not an expression node: %r" % (where, e))
+        tag = e[0]
+        if tag in _REFERENCE_PANICS:
+            raise VKError("%s: %s (the reference panics here: languages/aiken.rs:134-156)" % (where, _REFERENCE_PANICS[tag]))
+        if tag not in _EXPR_ARITY:
+            raise VKError("%s: unknown expression node %r" % (where, tag))
+        if tag == "const":
+            if len(e) != 2 or not isinstance(e[1], int) or not (0 <= e[1] < bls.R):
+                raise VKError("%s: constant is not a canonical scalar" % where)
+        elif tag in ("fixed", "advice"):
+            n = len(vk.fixed_queries if tag == "fixed" else vk.advice_queries)
+            if len(e) != 2 or not isinstance(e[1], int) or not (0 <= e[1] < n):
+                raise VKError("%s: %s query index %r out of range (%d queries)" % (where, tag, e[1] if len(e) > 1 else None, n))
+        elif tag == "neg":
+            if len(e) != 2:
+                raise VKError("%s: neg takes one operand" % where)
+            walk(e[1], where)
+        elif tag == "scaled":
+            if len(e) != 3 or not isinstance(e[2], int) or not (0 <= e[2] < bls.R):
+                raise VKError("%s: scaled takes an expression and a canonical scalar" % where)
+            walk(e[1], where)
+        else:
+            if len(e) != 3:
+                raise VKError("%s: %s takes two operands" % (where, tag))
+            walk(e[1], where)
+            walk(e[2], where)
+
+    for i, g in enumerate(vk.gates):
+        walk(g, "gate polynomial %d" % i)
+    for i, lk in enumerate(vk.lookups):
+        if len(lk) != 2 or len(lk[0]) != len(lk[1]) or not lk[0]:
+            raise VKError("lookup %d: input and table expression lists must be non-empty and of equal length" % i)
+        for e in list(lk[0]) + list(lk[1]):
+            walk(e, "lookup %d" % i)
+    for i, tc in enumerate(vk.trashcans):
+        if len(tc) != 2:
+            raise VKError("trashcan %d: (selector, constraint expressions)" % i)
+        walk(tc[0], "trashcan %d selector" % i)
+        for e in tc[1]:
+            walk(e, "trashcan %d" % i)
+    kinds = {"advice": vk.advice_queries, "fixed": vk.fixed_queries, "instance": vk.instance_queries}
+    for ty, col in vk.permutation_columns:
+        if ty not in kinds:
+            raise VKError("permutation column of unknown type %r" % (ty,))
+        if (col, 0) not in kinds[ty]:
+            raise VKError("permutation column %s[%d] has no query at the current rotation" % (ty, col))
+    for h in list(vk.fixed_commitments) + list(vk.permutation_commitments):
+        if len(bytes.fromhex(h)) != 48:
+            raise VKError("commitments are 48-byte compressed G1 points")
+    if len(vk.fixed_commitments) != vk.num_fixed_columns:
+        raise VKError("one fixed commitment per fixed column")
+    if len(vk.permutation_commitments) != len(vk.permutation_columns):
+        raise VKError("one permutation commitment per permutation column")
+    if len(bytes.fromhex(vk.s_g2)) != 96:
+        raise VKError("s_g2 is a 96-byte compressed G2 point")
+    if vk.recursion_vks is not None:
+        for inner in vk.recursion_vks:
+            if set(inner) != {"name", "transcript_repr", "fixed_commitments", "permutation_commitments"}:
+                raise VKError("inner verifying key: fields name / transcript_repr / fixed_commitments / permutation_commitments")
 
 
 @dataclass

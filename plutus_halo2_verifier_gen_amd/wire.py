@@ -152,12 +152,17 @@ class VKConstants:
     barycentric_weight: int = 0
     transcript_repr: int = 0
     blinding_factors: int = 0
+    # inner verifying keys of a recursive (IVC) circuit, as the {{{RECURSION_CONSTANTS}}} block of vk_constants.hbs carries
+    # them (emitters/aiken.rs:1089-1134): None when the file has no such block, else a list of
+    # {name, transcript_repr, fixed_commitments, permutation_commitments} in file order
+    recursion_vks: Optional[List[dict]] = None
 
     def check(self, k: Optional[int] = None) -> None:
         """Internal consistency the reference guarantees by construction."""
         if self.omega * self.omega_inv % R != 1:
             raise WireError("omega * omega_inv != 1")
-        for h in self.fixed_commitments + self.permutation_commitments:
+        inner = [h for v in (self.recursion_vks or []) for h in v["fixed_commitments"] + v["permutation_commitments"]]
+        for h in self.fixed_commitments + self.permutation_commitments + inner:
             bls.g1_decompress(bytes.fromhex(h), True)
         bls.g2_decompress(bytes.fromhex(self.s_g2))
         if k is not None:
@@ -187,6 +192,13 @@ def render_vk_constants_aiken(c: VKConstants) -> str:
     o.append("pub const barycentric_weight: State<Scalar> = from_int( 0x%064x )" % c.barycentric_weight)
     o.append("pub const transcript_rep: State<Scalar> = from_int( 0x%064x )" % c.transcript_repr)
     o.append("pub const blinding_factors: Int = %d" % c.blinding_factors)
+    for v in c.recursion_vks or []:      # emitters/aiken.rs:1089-1134: transcript_rep_<name>, f<i>_<name>, p<i>_<name>
+        o.append("")
+        o.append("pub const transcript_rep_%s = 0x%064x" % (v["name"], v["transcript_repr"]))
+        for i, h in enumerate(v["fixed_commitments"]):
+            o.append('pub const f%d_%s: ByteArray = #"%s"' % (i + 1, v["name"], h))
+        for i, h in enumerate(v["permutation_commitments"]):
+            o.append('pub const p%d_%s: ByteArray = #"%s"' % (i + 1, v["name"], h))
     return "\n".join(o) + "\n"
 
 
@@ -219,7 +231,36 @@ def parse_vk_constants_aiken(text: str) -> VKConstants:
     if not m:
         raise WireError("blinding_factors not found")
     c.blinding_factors = int(m.group(1))
+    c.recursion_vks = _parse_recursion_constants_aiken(text)
     return c
+
+
+def _parse_recursion_constants_aiken(text: str) -> Optional[List[dict]]:
+    """The {{{RECURSION_CONSTANTS}}} block (emitters/aiken.rs:1089-1134): per inner key `pub const transcript_rep_<name> =
+    <Scalar Debug>` followed by `pub const f<i>_<name>: ByteArray = #"<48 bytes>"` and `p<i>_<name>` lines.  The scalar is
+    printed with Rust's `{:?}`, which for the field type is `0x` + 64 hex digits; a decimal integer is accepted too.
+    The key's own constants use the fixed suffix `_commitment` and the name `transcript_rep`: not matched here."""
+    names = []
+    for m in re.finditer(r"pub const transcript_rep_(\w+)\s*=\s*(0x[0-9a-fA-F]+|\d+)", text):
+        names.append((m.group(1), int(m.group(2), 0)))
+    if not names:
+        return None
+    out = []
+    for name, rep in names:
+        if name == "commitment":
+            raise WireError("an inner verifying key cannot be called 'commitment'")
+
+        def numbered(prefix, name=name):
+            found = {int(m.group(1)): m.group(2).lower()
+                     for m in re.finditer(r'pub const %s(\d+)_%s\s*:\s*ByteArray\s*=\s*#"([0-9a-fA-F]{96})"' % (prefix, re.escape(name)), text)}
+            if sorted(found) != list(range(1, len(found) + 1)):
+                raise WireError("%s commitments of inner key %s are not numbered 1..n" % (prefix, name))
+            return [found[i] for i in range(1, len(found) + 1)]
+
+        if rep >= R:
+            raise WireError("transcript_rep_%s is not a canonical scalar" % name)
+        out.append({"name": name, "transcript_repr": rep, "fixed_commitments": numbered("f"), "permutation_commitments": numbered("p")})
+    return out
 
 
 def render_vk_constants_plinth(c: VKConstants) -> str:

@@ -107,3 +107,74 @@ def test_assemble_batch_layout():
     assert inst == wire.instances_to_abi([1, 2, 3]) * 2
     with pytest.raises(wire.WireError):
         verify_files.assemble(vk, proofs, [[1, 2]], [])
+
+
+def test_recursion_constants_roundtrip():
+    """The {{{RECURSION_CONSTANTS}}} block of vk_constants.hbs (emitters/aiken.rs:1089-1134): inner keys of a recursive
+    circuit are rendered as transcript_rep_<name> / f<i>_<name> / p<i>_<name> and read back; with_constants swaps them."""
+    vk, _ = V.ivc_vk()
+    c = vk.constants()
+    assert c.recursion_vks and c.recursion_vks[0]["name"] == "inner"
+    text = wire.render_vk_constants_aiken(c)
+    assert "pub const transcript_rep_inner = 0x%064x" % c.recursion_vks[0]["transcript_repr"] in text
+    assert 'pub const f1_inner: ByteArray = #"%s"' % c.recursion_vks[0]["fixed_commitments"][0] in text
+    back = wire.parse_vk_constants(text)
+    assert back == c
+    back.check(vk.k)
+    # the key's own constants are not mistaken for an inner key, and a plain file has no recursion block
+    plain, _ = V.simple_mul_vk()
+    assert wire.parse_vk_constants(wire.render_vk_constants_aiken(plain.constants())).recursion_vks is None
+    # another instantiation of the inner key travels through with_constants
+    rng = random.Random(8)
+    other = wire.parse_vk_constants(text)
+    other.recursion_vks[0]["transcript_repr"] = rng.randrange(R)
+    vk2 = vk.with_constants(other)
+    assert vk2.recursion_vks[0]["transcript_repr"] == other.recursion_vks[0]["transcript_repr"] and vk2.gates == vk.gates
+    other.recursion_vks[0]["name"] = "elsewhere"
+    with pytest.raises(wire.WireError):
+        vk.with_constants(other)
+
+
+def test_vk_json_schema_and_validator():
+    """docs/vk_schema.json ("h2v-vk/1") is the frozen JSON form of VerifyingKey: same fields, every builder's key fits it
+    (structurally checked here without a JSON-schema library), and vk.validate rejects what the reference itself would
+    panic on or refuse (languages/aiken.rs:134-156, extraction/mod.rs:41-55)."""
+    import json
+    import os
+    schema = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "docs", "vk_schema.json")))
+    fields = set(V.VerifyingKey.__dataclass_fields__)
+    assert set(schema["properties"]) == fields
+    assert set(schema["required"]) <= fields and schema["properties"]["schema_version"]["const"] == V.SCHEMA_VERSION
+    tags = {alt["items"][0]["const"] for alt in schema["definitions"]["expr"]["oneOf"]}
+    assert tags == set(V._EXPR_ARITY)
+    for name, build in V.BUILDERS.items():
+        key, _ = build()
+        d = json.loads(key.to_json())
+        assert set(schema["required"]) <= set(d) <= fields, name
+        assert V.VerifyingKey.from_json(key.to_json()) == key
+    key, _ = V.lookup_table_vk()
+    d = json.loads(key.to_json())
+
+    def broken(**kw):
+        return json.dumps({**d, **kw})
+
+    for bad, why in [
+        (broken(gates=[["selector", 0]]), "Selector"),
+        (broken(gates=[["sum", ["instance", 0], ["const", 1]]]), "Instance"),
+        (broken(gates=[["prod", ["challenge", 0], ["advice", 0]]]), "Challenge"),
+        (broken(gates=[["advice", 99]]), "out of range"),
+        (broken(gates=[["const", R]]), "canonical"),
+        (broken(gates=[["pow", ["advice", 0], 2]]), "unknown expression"),
+        (broken(n_committed_instances=2), "committed instance"),
+        (broken(schema_version=2), "schema_version"),
+        (broken(surprise=1), "unknown field"),
+        (broken(fixed_commitments=d["fixed_commitments"][:-1]), "fixed commitment"),
+        (broken(lookups=[[[["advice", 0]], []]]), "equal length"),
+    ]:
+        with pytest.raises(V.VKError, match=why):
+            V.VerifyingKey.from_json(bad)
+    # rotations the emitted Aiken verifier cannot name are an error only in strict mode (this backend handles them)
+    far = V.VerifyingKey.from_json(broken(advice_queries=d["advice_queries"] + [[0, 7]]))
+    V.validate(far)
+    with pytest.raises(V.VKError, match="rotation"):
+        V.validate(far, strict_rotations=True)
