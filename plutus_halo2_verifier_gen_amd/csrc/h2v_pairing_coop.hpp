@@ -71,6 +71,27 @@ H2V_DI void coop_load28(uint32_t (&l)[14], const uint32_t *p) {
     l[0] = a.x; l[1] = a.y; l[2] = a.z; l[3] = a.w; l[4] = b.x; l[5] = b.y; l[6] = b.z; l[7] = b.w;
     l[8] = c.x; l[9] = c.y; l[10] = c.z; l[11] = c.w; l[12] = d.x; l[13] = d.y;
 }
+// Both operands of one term with 128-bit LDS reads.  Written as one asm block because the optimiser re-cuts uint4 LDS loads
+// whose slot address it cannot see into two-dword reads (24 ds_read2_b32 per term instead of 6 ds_read_b128 + 2 ds_read_b64);
+// slots are 80-byte aligned records (COOP_SLOT_DW = 20), so every 16-byte piece is aligned.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+H2V_DI void coop_load28_pair(uint32_t (&x)[14], uint32_t (&y)[14], const uint32_t *px, const uint32_t *py) {
+    const uint32_t ax = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)px;
+    const uint32_t ay = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)py;
+    u32x4_t x0, x1, x2, y0, y1, y2;
+    u32x2_t x3, y3;
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b64 %3, %8 offset:48\n\t"
+                 "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:16\n\tds_read_b128 %6, %9 offset:32\n\tds_read_b64 %7, %9 offset:48\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
+                 : "v"(ax), "v"(ay)
+                 : "memory");
+    x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
+    x[8] = x2.x; x[9] = x2.y; x[10] = x2.z; x[11] = x2.w; x[12] = x3.x; x[13] = x3.y;
+    y[0] = y0.x; y[1] = y0.y; y[2] = y0.z; y[3] = y0.w; y[4] = y1.x; y[5] = y1.y; y[6] = y1.z; y[7] = y1.w;
+    y[8] = y2.x; y[9] = y2.y; y[10] = y2.z; y[11] = y2.w; y[12] = y3.x; y[13] = y3.y;
+}
 
 // Values between engine calls are lazily reduced F28 elements (h2v_fp28.hpp).  Bounds, in that header's (v, lam)
 // notation:  every Fp12 variable has lam = 1 and v <= 6 (engine outputs 3, conj 6, frob 5, inverse 3; the
@@ -94,8 +115,7 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
     uint64_t acc[28];
     {   // first term initialises the columns (no zero-fill of 56 registers)
         uint32_t x[14], y[14];
-        coop_load28(x, coop_slot(c, tab[2 * c.h]));
-        coop_load28(y, coop_slot(c, tab[2 * c.h + 1]));
+        coop_load28_pair(x, y, coop_slot(c, tab[2 * c.h]), coop_slot(c, tab[2 * c.h + 1]));
 #pragma unroll
         for (int i = 0; i < 14; i++)
 #pragma unroll
@@ -108,8 +128,7 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
 #pragma unroll 1
     for (int t = c.h + 2; t < NT; t += 2) {
         uint32_t x[14], y[14];
-        coop_load28(x, coop_slot(c, tab[2 * t]));
-        coop_load28(y, coop_slot(c, tab[2 * t + 1]));
+        coop_load28_pair(x, y, coop_slot(c, tab[2 * t]), coop_slot(c, tab[2 * t + 1]));
 #pragma unroll
         for (int i = 0; i < 14; i++)
 #pragma unroll
