@@ -116,5 +116,47 @@ inline std::vector<uint8_t> verify_batch(const VerifyingKey &vk, const h2v_batch
     check(h2v_verify_batch(vk.handle(), &batch, accept.data(), ws));
     return accept;
 }
+// The same vector through the batch-accept fast path (one random linear combination of the batch's pairing equations:
+// one bucketed G1 MSM + one pairing; the per-proof kernels only if the batch check fails).  fell_back (optional) tells
+// which of the two produced the vector.  seed: 32 bytes that provers cannot predict, or nullptr = drawn from the OS.
+inline std::vector<uint8_t> verify_batch_rlc(const VerifyingKey &vk, const h2v_batch &batch, h2v_workspace *ws = nullptr,
+                                             bool *fell_back = nullptr, const uint8_t *seed = nullptr) {
+    std::vector<uint8_t> accept(batch.n);
+    h2v_rlc_opts opts{};
+    if (seed) { for (int k = 0; k < 32; k++) opts.seed[k] = seed[k]; opts.flags = H2V_RLC_SEED_GIVEN; }
+    int fb = 0;
+    check(h2v_verify_batch_rlc(vk.handle(), &batch, accept.data(), ws, seed ? &opts : nullptr, &fb));
+    if (fell_back) *fell_back = fb != 0;
+    return accept;
+}
+
+// A reusable workspace, and the streaming form: submit() returns once the batch is copied and everything is enqueued,
+// wait() collects the accept vector.  Alternate two Workspaces to overlap the upload of one batch with the kernels of the
+// previous one.
+class Workspace {
+  public:
+    Workspace(const VerifyingKey &vk, uint64_t max_batch) : vk_(vk) { check(h2v_workspace_create(vk.handle(), max_batch, &w_)); }
+    Workspace(const Workspace &) = delete;
+    Workspace &operator=(const Workspace &) = delete;
+    ~Workspace() { h2v_workspace_free(w_); }
+    h2v_workspace *handle() const { return w_; }
+    void submit(const h2v_batch &batch, bool rlc = false) {
+        check(h2v_verify_batch_submit(vk_.handle(), &batch, w_, rlc ? H2V_SUBMIT_RLC : 0u, nullptr));
+        n_ = batch.n;
+    }
+    std::vector<uint8_t> wait(bool *fell_back = nullptr) {
+        std::vector<uint8_t> accept(n_ ? n_ : 1);
+        int fb = 0;
+        check(h2v_verify_batch_wait(w_, accept.data(), &fb));
+        accept.resize(n_);
+        if (fell_back) *fell_back = fb != 0;
+        return accept;
+    }
+
+  private:
+    const VerifyingKey &vk_;
+    h2v_workspace *w_ = nullptr;
+    uint64_t n_ = 0;
+};
 
 }  // namespace h2v

@@ -59,6 +59,19 @@ int main(int argc, char **argv) {
         std::string bits;
         for (uint8_t a : acc) bits.push_back(a ? '1' : '0');
         std::printf("single %s\nbatch %s\n", single.c_str(), bits.c_str());
+        // the same batch through the batch-accept fast path, and streamed over two workspaces (per proof, then RLC)
+        bool fell_back = false;
+        const std::vector<uint8_t> racc = h2v::verify_batch_rlc(vk, batch, nullptr, &fell_back);
+        std::string rbits;
+        for (uint8_t a : racc) rbits.push_back(a ? '1' : '0');
+        std::printf("rlc %s\nrlc_fell_back %d\n", rbits.c_str(), fell_back ? 1 : 0);
+        h2v::Workspace w0(vk, n), w1(vk, n);
+        w0.submit(batch, false);
+        w1.submit(batch, true);
+        std::string s0, s1;
+        for (uint8_t a : w0.wait()) s0.push_back(a ? '1' : '0');
+        for (uint8_t a : w1.wait()) s1.push_back(a ? '1' : '0');
+        std::printf("stream0 %s\nstream1 %s\n", s0.c_str(), s1.c_str());
         // a consumed guard must refuse a second use; a wrong instance count must be refused by prepare
         bool refused = false;
         try {

@@ -63,4 +63,6 @@ def test_cpp_prepare_verify_on_gpu(driver, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     lines = dict(l.split(" ", 1) for l in r.stdout.strip().splitlines())
     assert lines["single"] == want and lines["batch"] == want
+    assert lines["rlc"] == want and lines["stream0"] == want and lines["stream1"] == want
+    assert lines["rlc_fell_back"] == "1"          # the corrupted proofs are caught only by the pairing
     assert lines["misuse_refused"] == "1"

@@ -448,6 +448,14 @@ def test_baseline_config_sizes(be, circuits, name, n):
     sample = sorted(random.Random(16).sample(range(n), 64))
     sb = _permute(batch, sample, n_pi)
     assert list(ov.verify_batch(sb.proofs, sb.proof_off, sb.instances, sb.committed, threads=16)) == [got[i] for i in sample]
+    # the batch-accept fast path at the same size: the same vector (through the fall-back: the batch holds proofs that only
+    # the pairing rejects); with the pairing-only rejects removed the batch check itself passes and nothing falls back
+    got_rlc, fell_back = dp.verify_batch_rlc(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws)
+    assert list(got_rlc) == list(got)
+    keep = [i for i in range(n) if got[i] == 1 or i % 3 == 0]
+    clean = _permute(batch, [i for i in keep if got[i] == 1], n_pi)
+    acc2, fb2 = dp.verify_batch_rlc(clean.proofs, clean.proof_off, clean.instances, clean.committed, ws=ws)
+    assert list(acc2) == [1] * clean.n and (not fb2 or name == "ivc") and (fell_back or name == "ivc")
 
 
 def test_circuit_without_public_inputs(be):
