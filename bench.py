@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--mode", default="per-proof", choices=["per-proof", "rlc"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--inflight", type=int, default=0, help="steps in flight (workspaces / streams); default: 2 (per-proof, batches above 1024), 4 (per-proof, smaller), 5 (rlc)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product path); gloo = rehearsal of the N > 1 code path on a box with one GPU "
+                         "(every rank on the device H2V_BENCH_DEVICE names, accept bytes gathered through host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rlc-secondary", action="store_true", help="per-proof runs: skip the extra measurement of the RLC mode")
     ap.add_argument("--cpu-sample", type=int, default=1024)
@@ -125,11 +128,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    if os.environ.get("H2V_BENCH_DEVICE") is not None:   # rehearsal on a one-GPU box: all ranks share that device
+        local_rank = int(os.environ["H2V_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)          # one process per GPU; bind before the communicator is created
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL on ROCm
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo")
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -163,9 +171,10 @@ def main():
     d_off = torch.tensor(batch.proof_off, dtype=torch.int64).to(dev)
     d_inst = to_dev(batch.instances)
     d_ci = to_dev(batch.committed) if batch.committed else None
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live
     Bmax = B
     if world > 1:
-        t = torch.tensor([B], device=dev)
+        t = torch.tensor([B], device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         Bmax = int(t.item())
     rlc_seed = bytes((7 * k + 1) & 0xff for k in range(32))   # fixed for the timed steps (reproducible); a service draws it per batch
@@ -177,8 +186,8 @@ def main():
         d_accepts = [torch.zeros(B, dtype=torch.uint8, device=dev) for _ in range(inflight)]
         d_statuses = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(inflight)]
         use_gather = gather and world > 1
-        g_send = [torch.zeros(Bmax, dtype=torch.uint8, device=dev) for _ in range(inflight)] if use_gather else None
-        gathered = [[torch.zeros(Bmax, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(inflight)] if (use_gather and rank == 0) else None
+        g_send = [torch.zeros(Bmax, dtype=torch.uint8, device=cdev) for _ in range(inflight)] if use_gather else None
+        gathered = [[torch.zeros(Bmax, dtype=torch.uint8, device=cdev) for _ in range(world)] for _ in range(inflight)] if (use_gather and rank == 0) else None
         torch.cuda.synchronize()
 
         def step(k):
@@ -216,11 +225,17 @@ def main():
             dist.barrier()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
+        if gathered is not None:   # rank 0: what arrived over the collective is every rank's (all-accepting) vector
+            sizes = [shard.shard_range(B_arg, r, world)[1] - shard.shard_range(B_arg, r, world)[0] if args.scaling == "strong" else B_arg
+                     for r in range(world)]
+            last = gathered[(steps - 1) % inflight]
+            gather_state["ok"] = all(bool(last[r][:sizes[r]].all().item()) for r in range(world))
         return el, wss, d_accepts[(steps - 1) % inflight].cpu().numpy()
 
+    gather_state = {"ok": None}
     elapsed, wss, accept = timed_run(args.mode, inflight, args.steps, args.warmup, True)
 
     # per-kernel device time over the timed steps (HIP events recorded on the kernels' own streams, event rings of the
@@ -277,7 +292,7 @@ def main():
     n_accept = int(accept.sum())
     ok_all = n_accept == B  # the synthetic batch is 100 % accepting
     if world > 1:
-        flag = torch.tensor([1 if ok_all else 0], device=dev)
+        flag = torch.tensor([1 if ok_all else 0], device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok_all = bool(flag.item())
 
@@ -415,6 +430,7 @@ def main():
             "batch_latency_ms": round(batch_latency_ms, 4),
             "pipelines_per_step": launches, "msm_lanes_per_term": msm_lpt,
             "all_accepted": ok_all,
+            "gathered_accept_vectors_all_ones": gather_state["ok"],
             "reject_dataset": reject_check,
             "forge_seconds": round(t_forge, 2),
         }
