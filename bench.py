@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--mode", default="per-proof", choices=["per-proof", "rlc"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--inflight", type=int, default=0, help="steps in flight (workspaces / streams); default: 2 (per-proof, batches above 1024), 4 (per-proof, smaller), 5 (rlc)")
+    ap.add_argument("--msm-tpl", type=int, default=0, choices=[0, 1, 2, 4],
+                    help="per-proof MSM: terms per lane (sets H2V_MSM_TPL; 2 / 4 share the doublings of a lane's terms)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo = rehearsal of the N > 1 code path on a box with one GPU "
                          "(every rank on the device H2V_BENCH_DEVICE names, accept bytes gathered through host memory)")
@@ -120,6 +122,8 @@ def main():
     # 4 -> 2.74 / 3.31; RLC: 1 -> 5.7 ms, 5 -> 2.1 (its tail - bucket reduction, doublings, ONE pairing - is a few waves)
     small = (args.batch or WORKLOADS[args.workload][1]) <= 1024
     inflight = args.inflight or (5 if args.mode == "rlc" else 4 if small else 2)
+    if args.msm_tpl:
+        os.environ["H2V_MSM_TPL"] = str(args.msm_tpl)
     # several steps in flight use 3 streams each: more hardware queues than the runtime's default of 4, or they serialise
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
@@ -359,7 +363,8 @@ def main():
             }
             msm_key = "bucket_accumulate"
         else:
-            kname = {"g1_msm": "k_g1_msm_fixed" if msm_lpt == 3 else "k_g1_msm_merged" if msm_lpt == 1 else "k_g1_msm", "g1_decompress": dec_name,
+            tpl = msm_lpt - 4 if msm_lpt in (6, 8) else 1     # several terms per lane (H2V_MSM_TPL): shared doublings
+            kname = {"g1_msm": "k_g1_msm_multi%d" % tpl if tpl > 1 else "k_g1_msm_fixed" if msm_lpt == 3 else "k_g1_msm_merged" if msm_lpt == 1 else "k_g1_msm", "g1_decompress": dec_name,
                      "transcript_combiner": vm_name, "pairing": "k_pairing_coop" if os.environ.get("H2V_PAIRING") != "legacy" else "k_pairing_check"}
             bytes_per_launch = {
                 "g1_msm": B * (128 * T + 144),
@@ -370,11 +375,12 @@ def main():
             # per MSM lane: 32 windows of 4 doublings + one mixed addition per GLV half the lane carries (tables are built
             # ahead); the launcher reports whether a term ran on two lanes (one half each) or on one (both halves)
             msm_fixed = msm_lpt == 3   # fixed-base mode: VK-base terms cost 65 mixed additions and no doubling
-            lpt = 1 if msm_fixed else msm_lpt
+            lpt = 1 if (msm_fixed or tpl > 1) else msm_lpt
             msm_halves = 2 // lpt
             msm_lane = 128 * MAD_DBL + (32 * msm_halves - 1) * MAD_MADD
             mads = {
                 "g1_msm": (B * (T - n_fix_terms) * msm_lane + B * n_fix_terms * 65 * MAD_MADD + B * (T - 1) * MAD_ADD + B * 3 * MAD_MUL) if msm_fixed
+                          else (B * -(-T // tpl) * 128 * MAD_DBL + B * T * 66 * MAD_MADD + B * (-(-T // tpl) - 1) * MAD_ADD + B * 3 * MAD_MUL) if tpl > 1
                           else B * T * lpt * msm_lane + B * (lpt * T - 1) * MAD_ADD + B * 3 * MAD_MUL,
                 "pairing": B * 32 * pairing_lane,
                 "g1_decompress": B * slots * (377 * MAD_SQR + 86 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD + tab_point),

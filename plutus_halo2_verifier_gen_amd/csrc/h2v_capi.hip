@@ -542,8 +542,22 @@ static uint32_t launch_msm_ladders(const H2vDevPlan &d, const H2vMsmArgs &ma, ui
     else hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
     return sh.lpt;
 }
+// H2V_MSM_TPL = 2 / 4: k_g1_msm_multi2 / 4 (several terms per lane share the doublings: less work, fewer and longer waves;
+// for callers that keep several batches in flight - bench.py sets it then).  Single-group launches with prebuilt tables only.
+static int msm_terms_per_lane() {
+    static const int v = []() { const char *e = getenv("H2V_MSM_TPL"); const int t = e ? atoi(e) : 1; return t == 2 || t == 4 ? t : 1; }();
+    return v;
+}
 static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const uint32_t *scalars, const uint32_t *pts,
                                  uint32_t *tabws, hipStream_t st) {
+    const int tpl = msm_terms_per_lane();
+    if (tpl > 1 && ma.pt_tab && !ma.skip && ma.grp_end[0] == ma.n_terms && ma.n_terms >= (uint32_t)tpl && ma.n_terms <= 256u * tpl) {
+        const uint32_t lpp = (ma.n_terms + tpl - 1) / tpl, bs = 256;
+        const uint32_t per_block = bs / lpp, blocks = (n + per_block - 1) / per_block;
+        if (tpl == 2) hipLaunchKernelGGL(k_g1_msm_multi2, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+        else hipLaunchKernelGGL(k_g1_msm_multi4, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+        return 4 + (uint32_t)tpl;   // reported as msm_lanes_per_term: 6 / 8 = two / four terms per lane
+    }
     return launch_msm_ladders(d, ma, n, msm_ladder_shape(ma.n_terms, n, 0.0), scalars, pts, tabws, st);
 }
 // Fixed-base split of the plan's own MSM (non-recursive plans, tables present): the per-proof terms [0, n_var) as ladders

@@ -884,6 +884,163 @@ k_g1_msm_fixed(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /*
     msm_body<1, true>(plan, ma, n, per_block, scalars, pts, tabws, red);
 }
 
+
+// Several terms per lane (K = 2, 4): the K x 2 GLV halves of a lane's terms share ONE accumulator and therefore the 128
+// doublings - per term 128 / K doublings + 66 mixed additions instead of 128 + 66 (K = 2: 26 % fewer multiply-adds per
+// proof, K = 4: 39 %), on 1 / K of the waves with a chain (128 x 7 + K x 66 x 11) / 1622 as long.  It loses when the launch
+// is alone on the chip (half or a quarter of the SIMDs get a wave) and wins when other kernels fill them: several steps in
+// flight, where the step time is the instruction count.  Non-recursive plans with prebuilt tables.
+// One accumulator over DIFFERENT points has no lattice argument against exceptional additions (crafted proofs can make
+// P_2 = [m] P_1), so the ladder runs unchecked and is judged once at the end: an exceptional addition or doubling leaves
+// Z = 0, which every later Z inherits; such a lane (never an honest one) redoes its ladder with the complete group law.
+template <int K, bool COMPLETE>
+H2V_DN void msm_multi_ladder(G1J28 &out, bool &out_inf, const int8_t (&dg)[2 * K][33], const uint32_t *const (&tab)[2 * K]) {
+    G1J28 lad;
+    bool lad_inf = true;
+#pragma unroll 1
+    for (int q = 32; q >= 0; q--) {
+        if (q != 32 && !lad_inf) {
+#pragma unroll 1
+            for (int rep = 0; rep < 4; rep++) g1j28_dbl_t<true>(lad, lad);
+        }
+#pragma unroll 1
+        for (int h = 0; h < 2 * K; h++) {
+            const int d = dg[h][q];
+            if (d == 0) continue;
+            const uint32_t *ent = tab[h] + ((d < 0 ? -d : d) - 1) * 28;
+            F28 qx, qy;
+#pragma unroll
+            for (int k = 0; k < 14; k++) { qx.l[k] = ent[k]; qy.l[k] = ent[14 + k]; }
+            if (lad_inf) {
+                lad.x = qx;
+                lad.y = qy;
+                if (d < 0) { F28_NEG(lad.y, qy, 3, 1); f28_carry(lad.y); }
+                f28_set_one(lad.z);
+                lad_inf = false;
+            } else if (!COMPLETE) {
+                g1j28_madd_ladder_t<true>(lad, lad, qx, qy, d < 0);
+            } else {
+                G1J28 o;
+                o.x = qx; o.y = qy;
+                f28_set_one(o.z);
+                g1j28_acc_add(lad, lad_inf, o, d < 0);
+            }
+        }
+    }
+    out = lad;
+    out_inf = lad_inf;
+}
+template <int K>
+H2V_DI void msm_multi_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, uint32_t per_block,
+                           const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *red) {
+    const uint32_t tid = threadIdx.x, bs = blockDim.x;
+    const uint32_t lanes_per_proof = (ma.n_terms + K - 1) / K;
+    const uint32_t seg = tid / lanes_per_proof, sub = tid - seg * lanes_per_proof;
+    const uint32_t i = blockIdx.x * per_block + seg;
+    const bool active = seg < per_block && i < n;
+    G1J28 lad;
+    bool lad_inf = true;
+    if (active) {
+        int8_t dg[2 * K][33];
+        const uint32_t *tab[2 * K];
+#pragma unroll 1
+        for (int j = 0; j < K; j++) {
+            const uint32_t term = sub * K + j;
+            bool use = term < ma.n_terms;
+            const uint32_t tt = use ? term : 0u;
+            const uint32_t kind = ma.terms[2 * (ma.term_base + tt)], idx = ma.terms[2 * (ma.term_base + tt) + 1];
+            const bool is_vk = kind == H2V_TERM_VK_BASE;
+            const uint32_t *bp = (is_vk ? plan.vk_bases : pts) + (is_vk ? (size_t)idx : (size_t)i * ma.slots + idx) * 24;
+            uint32_t any_b = 0, s[8], any_s = 0;
+#pragma unroll
+            for (int k = 0; k < 24; k++) any_b |= bp[k];
+            const uint32_t *sp = scalars + ((size_t)i * ma.scal_stride + ma.scal_col_base + tt) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { s[k] = sp[k]; any_s |= s[k]; }
+            use = use && any_b != 0 && any_s != 0;       // the point at infinity / a zero scalar contribute nothing
+            uint32_t k1[4], k2[4];
+            glv_split(k1, k2, s);
+            const uint32_t *t0 = is_vk ? ma.vk_tab + (size_t)idx * 448 : ma.pt_tab + ((size_t)i * ma.slots + idx) * 448;
+            tab[2 * j] = t0;
+            tab[2 * j + 1] = t0 + 224;
+#pragma unroll 1
+            for (int h = 0; h < 2; h++) {
+                uint32_t carry = 0;
+#pragma unroll 1
+                for (int q = 0; q < 32; q++) {
+                    const uint32_t kw = h ? k2[q >> 3] : k1[q >> 3];
+                    uint32_t d = ((kw >> (4 * (q & 7))) & 15u) + carry;
+                    carry = d > 8 ? 1u : 0u;
+                    dg[2 * j + h][q] = use ? (int8_t)(carry ? (int)d - 16 : (int)d) : (int8_t)0;
+                }
+                dg[2 * j + h][32] = use ? (int8_t)carry : (int8_t)0;
+            }
+        }
+        msm_multi_ladder<K, false>(lad, lad_inf, dg, tab);
+        if (!lad_inf) {
+            Fp zc;
+            F28 z = lad.z;
+            f28_carry(z);
+            f28_to_fp(zc, z);
+            if (fp_is_zero(zc)) msm_multi_ladder<K, true>(lad, lad_inf, dg, tab);   // crafted points only
+        }
+    }
+    // reduction over the lanes of each proof (as in msm_body: lazy field, complete additions)
+#define MSMM_RED_STORE()                                                                    \
+    do {                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < 14; k++) {                                    \
+            red[k * bs + tid] = lad.x.l[k]; red[(14 + k) * bs + tid] = lad.y.l[k]; red[(28 + k) * bs + tid] = lad.z.l[k]; \
+        }                                                                                   \
+        red[42 * bs + tid] = lad_inf ? 1u : 0u;                                             \
+    } while (0)
+    MSMM_RED_STORE();
+    __syncthreads();
+    uint32_t top = 1;
+    while (top < lanes_per_proof) top <<= 1;
+    for (uint32_t s = top >> 1; s >= 1; s >>= 1) {
+        if (seg < per_block && sub < s && sub + s < lanes_per_proof) {
+            if (red[42 * bs + tid + s] == 0) {
+                G1J28 other;
+#pragma unroll
+                for (int k = 0; k < 14; k++) {
+                    other.x.l[k] = red[k * bs + tid + s];
+                    other.y.l[k] = red[(14 + k) * bs + tid + s];
+                    other.z.l[k] = red[(28 + k) * bs + tid + s];
+                }
+                g1j28_acc_add(lad, lad_inf, other, false);
+                MSMM_RED_STORE();
+            }
+        }
+        __syncthreads();
+    }
+#undef MSMM_RED_STORE
+    if (sub == 0 && seg < per_block && i < n) {
+        G1J acc;
+        g1j28_to_g1j(acc, lad, lad_inf);
+        uint32_t *out = ma.out[0];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            out[(size_t)i * 36 + k] = acc.x.v[k];
+            out[(size_t)i * 36 + 12 + k] = acc.y.v[k];
+            out[(size_t)i * 36 + 24 + k] = acc.z.v[k];
+        }
+    }
+}
+extern "C" __global__ void __launch_bounds__(256, 2)
+k_g1_msm_multi2(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, const uint32_t *__restrict__ scalars,
+                const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
+    extern __shared__ uint32_t red[];
+    (void)tabws;
+    msm_multi_body<2>(plan, ma, n, per_block, scalars, pts, red);
+}
+extern "C" __global__ void __launch_bounds__(256, 2)
+k_g1_msm_multi4(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, const uint32_t *__restrict__ scalars,
+                const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
+    extern __shared__ uint32_t red[];
+    (void)tabws;
+    msm_multi_body<4>(plan, ma, n, per_block, scalars, pts, red);
+}
+
 // er += er_fix (complete Jacobian addition, one lane per proof): joins the two launches of a split MSM
 extern "C" __global__ void __launch_bounds__(64)
 k_g1_sum_pairs(uint32_t n, uint32_t *__restrict__ er, const uint32_t *__restrict__ er_fix) {

@@ -478,7 +478,7 @@ def test_circuit_without_public_inputs(be):
 @pytest.mark.parametrize("env", [{"H2V_PIPES": "3"}, {"H2V_PAIRING": "legacy"}, {"H2V_DEBUG_SYNC": "1"},
                                  {"H2V_MSM_LPT": "1"}, {"H2V_MSM_LPT": "2", "H2V_MSM_BS": "256"}, {"H2V_SPLIT_DEC": "0"},
                                  {"H2V_MSM_FIX": "1"}, {"H2V_MSM_FIX": "3"}, {"H2V_VM_WIDE": "1"}, {"H2V_VM_WIDE": "0"},
-                                 {"H2V_DEC_QUEUE": "0"}])
+                                 {"H2V_DEC_QUEUE": "0"}, {"H2V_MSM_TPL": "2"}, {"H2V_MSM_TPL": "4"}])
 def test_alternate_pipeline_modes(be, env, tmp_path):
     """The knobs of the pipeline (chunked sub-batches on several streams, the one-lane pairing kernel, the serialised
     debug path, the MSM launch shape - one or two lanes per term, block size, fixed-base lanes for the VK bases - that the
@@ -502,15 +502,17 @@ def test_alternate_pipeline_modes(be, env, tmp_path):
     assert r.returncode == 0 and "modes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("lpt", ["1", "2"])
+@pytest.mark.parametrize("lpt", ["1", "2", "tpl2", "tpl4"])
 def test_g1_msm_forced_shape(be, lpt):
     """test_g1_msm (edge scalars, equal / opposite / infinity bases, T = 1 .. 64) again with the MSM shape forced: the
-    probe's small batches would otherwise always take two lanes per term."""
+    probe's small batches would otherwise always take two lanes per term.  tpl2 / tpl4: several terms per lane on one
+    accumulator (k_g1_msm_multi*), where equal and opposite bases exercise the Z test and the complete redo."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "test_g1_msm and not forced"], env={**os.environ, "H2V_MSM_LPT": lpt}, cwd=root,
+                        "-k", "test_g1_msm and not forced"],
+                       env={**os.environ, **({"H2V_MSM_TPL": lpt[3:]} if lpt.startswith("tpl") else {"H2V_MSM_LPT": lpt})}, cwd=root,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
