@@ -219,3 +219,19 @@ def test_rlc_full_size_batch(be, circuits):
     sample = list(range(0, n, 97))
     for i in sample:
         assert got[i] == int(ov.verify(rej.proof(i), rej.instance_ints(i, 3), None))
+
+
+def test_rlc_api_misuse(be, circuits):
+    """API misuse is an error code, never a launch: the device form without a workspace, a workspace created for a smaller
+    plan, a seed of the wrong length."""
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    with pytest.raises(be.H2VError, match="workspace"):
+        dp.verify_batch_rlc_device(4, 16, 16, 16, None, 16, None, ws=None)        # (pointers are never touched)
+    vk2, td2, pl2, dp2, ov2 = circuits["lookup_table"]
+    b2 = synth.forge_batch(vk2, td2, 2, seed=3, plan=pl2, workers=1)
+    with pytest.raises(be.H2VError, match="workspace"):
+        dp2.verify_batch_rlc(b2.proofs, b2.proof_off, b2.instances, b2.committed, ws=be.Workspace(dp, 8))
+    with pytest.raises(ValueError):
+        dp2.verify_batch_rlc(b2.proofs, b2.proof_off, b2.instances, b2.committed, seed=b"short")
+    assert dp.verify_batch_rlc(b"", [0], b"", None) == (b"", False)              # the empty batch
