@@ -13,6 +13,7 @@ Sources:
   plinth-verifier/plutus-halo2/test/ProofData.hs:33-215 -> test/Halo2MultiOpenMSM.hs:25-43   multi-open scalars
   aiken-verifier/templates/gates_test.hbs:9-79              lookup-identity KAT (inputs -> expected)
   aiken-verifier/templates/verification_h2.hbs:24, transcript.ak:99, vk_constants.hbs:18   constants
+  aiken-verifier/aiken_halo2/lib/bls_utils.ak:119-128       g1_from_coords(x, y') == generator (sign-of-y semantics)
 """
 import json
 import os
@@ -120,6 +121,10 @@ def main():
     kats["field_primes_decimal"] = re.findall(r"(\d{70,})", bt)[:2]
     bu = read("aiken-verifier/aiken_halo2/lib/bls_utils.ak")
     kats["fp_prime"] = re.search(r"fp_prime: Int =\n\s*0x([0-9a-f]+)", bu).group(1)
+    # bls_utils.ak:119-128 coord_generator: g1_from_coords(x, y) == generator although y is NOT the generator's y - the
+    # function takes only the SIGN of y (the recursion fold rebuilds the accumulator points this way)
+    cg = hexes(test_block(bu, "coord_generator"))
+    kats["g1_from_coords_generator"] = {"x": cg[0], "y": cg[1]}
     with open(OUT, "w") as f:
         json.dump(kats, f, indent=1, sort_keys=True)
     print("wrote", OUT, len(json.dumps(kats)), "bytes")

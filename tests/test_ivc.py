@@ -49,6 +49,19 @@ def test_layout_follows_the_emitter():
         ivc.layout(small)                    # "Not enough public inputs to support recursion" (aiken.rs:702)
 
 
+def test_g1_from_coords_reference_vector(kats, orc):
+    """bls_utils.ak:119-128 `coord_generator`: g1_from_coords(x_G, y') is the generator for a y' that is NOT the generator's
+    y but has its sign - the reference-held vector for the function the recursion fold rebuilds accumulator points with."""
+    x, y = int(kats["g1_from_coords_generator"]["x"], 16), int(kats["g1_from_coords_generator"]["y"], 16)
+    assert x == bls.G1_GEN[0] and y != bls.G1_GEN[1]
+    assert ivc.g1_from_coords(x, y) == bls.G1_GEN
+    # the same through the byte encoding the device path builds (x big-endian + the parity flag of y) and the oracle's decompress
+    enc = bytearray(x.to_bytes(48, "big"))
+    enc[0] |= 0x80 | (0x20 if y > (bls.P - 1) // 2 else 0)
+    ok, pt = orc.g1_decompress(bytes(enc))
+    assert ok and pt == bls.G1_GEN
+
+
 def test_g1_from_coords_uses_only_the_sign_of_y():
     pt = bls.g1_mul(bls.G1_GEN, 99)
     assert ivc.g1_from_coords(pt[0], pt[1]) == pt

@@ -235,3 +235,49 @@ def test_rlc_api_misuse(be, circuits):
     with pytest.raises(ValueError):
         dp2.verify_batch_rlc(b2.proofs, b2.proof_off, b2.instances, b2.committed, seed=b"short")
     assert dp.verify_batch_rlc(b"", [0], b"", None) == (b"", False)              # the empty batch
+
+
+@pytest.mark.parametrize("name", ["simple_mul", "lookup_table", "sha256"])
+def test_random_byte_flips_three_way(be, circuits, name):
+    """Differential fuzz: half of the proofs of a batch get ONE random bit flipped at a random position of the proof bytes,
+    of a public input or of the committed instance.  The oracle, the per-proof GPU path and the RLC GPU path must give the
+    same vector (most flips hit a commitment: another curve point, a point off the curve or outside G1, a changed flag; or
+    a scalar: wrong or non-canonical), including the status the device reports for proofs rejected before the pairing."""
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits[name]
+    n, n_pi = 192, vk.n_public_inputs
+    batch = synth.forge_batch(vk, td, n, seed=71, plan=pl, workers=4, ci_identity=False)
+    rng = random.Random(len(name))
+    proofs = [bytearray(batch.proof(i)) for i in range(n)]
+    inst = bytearray(batch.instances)
+    ci = bytearray(batch.committed) if batch.committed else None
+    touched = []
+    for i in range(n):
+        if rng.random() < 0.5:
+            continue
+        touched.append(i)
+        where = rng.random()
+        if where < 0.8 or (n_pi == 0 and ci is None):
+            pos = rng.randrange(len(proofs[i]))
+            proofs[i][pos] ^= 1 << rng.randrange(8)
+        elif where < 0.9 and n_pi:
+            pos = 32 * n_pi * i + rng.randrange(32 * n_pi)
+            inst[pos] ^= 1 << rng.randrange(8)
+        elif ci is not None:
+            pos = 48 * i + rng.randrange(48)
+            ci[pos] ^= 1 << rng.randrange(8)
+        else:
+            pos = rng.randrange(len(proofs[i]))
+            proofs[i][pos] ^= 1 << rng.randrange(8)
+    off = [0]
+    for p in proofs:
+        off.append(off[-1] + len(p))
+    pb, ib, cb = b"".join(bytes(p) for p in proofs), bytes(inst), (bytes(ci) if ci is not None else None)
+    want = ov.verify_batch(pb, off, ib, cb, threads=8)
+    ws = be.Workspace(dp, n)
+    got_pp = dp.verify_batch(pb, off, ib, cb, ws=ws)
+    got_rlc, _fb = dp.verify_batch_rlc(pb, off, ib, cb, ws=ws)
+    assert list(got_pp) == list(want)
+    assert list(got_rlc) == list(want)
+    assert all(want[i] == 1 for i in range(n) if i not in touched)
+    assert sum(want[i] for i in touched) <= 2      # a one-bit change is (almost) always fatal; never silently ignored en masse
