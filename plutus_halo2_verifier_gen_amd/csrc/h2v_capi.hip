@@ -614,7 +614,13 @@ static void launch_ivc_fold(const H2vDevPlan &d, uint32_t n, const uint32_t *pts
 // kernel stays as a cross-check (H2V_PAIRING=legacy, or impl = 0 in the probe).
 static void launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
                                 const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st, const uint32_t *skip = nullptr) {
+    // The WIDE engine (one proof per wave, four lanes per coefficient: 3 / 2 / 1 terms per lane and call instead of 6 / 4 / 2)
+    // when even one wave per proof leaves SIMDs free: n <= #SIMDs.  Above that the two-proofs-per-wave kernel does less
+    // total work.  H2V_PAIRING_WIDE = 0 / 1 forces the choice; the conditional (RLC fall-back) launch is never wide.
+    static const int env_wide = []() { const char *e = getenv("H2V_PAIRING_WIDE"); return e ? atoi(e) : -1; }();
+    const bool wide = !skip && (env_wide >= 0 ? env_wide != 0 : (double)n <= msm_n_simd());
     if (impl == 0) hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
+    else if (wide) hipLaunchKernelGGL(k_pairing_coop_wide, dim3(n), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
     else hipLaunchKernelGGL(k_pairing_coop, dim3((n + 1) / 2), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, skip);
 }
 static void launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,

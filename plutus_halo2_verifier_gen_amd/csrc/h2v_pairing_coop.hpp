@@ -46,7 +46,13 @@ __shared__ __attribute__((aligned(16))) uint32_t coop_lds[COOP_LDS_DW];
 struct Coop {
     int grp_off;  // dword offset of this group's slots in coop_lds
     int g;        // coefficient role 0..15 (lane & 15)
-    int h;        // which half of the terms this lane sums (lane >> 4) & 1
+    int h;        // staging role (lane >> 4) & 1: the h = 0 lanes stage the A-side operands, the h = 1 lanes the B side
+    // Which terms of a coefficient's sum the lane takes: t = q, q + nq, ...  Normal kernel: two lanes per coefficient
+    // (nq = 2, q = h), two proofs per wave.  WIDE kernel (one proof per wave: the single pairing of the RLC batch mode and
+    // batches too small to give every SIMD a wave otherwise): four lanes per coefficient (nq = 4, q = h + 2 * (lane >> 5)),
+    // the upper half-wave mirroring the lower one's staging; the four reduced partial sums meet through
+    // v_permlane16_swap and v_permlane32_swap.  Per engine call a lane then multiplies 3 / 2 / 1 terms instead of 6 / 4 / 2.
+    int q, nq;
 };
 
 H2V_DI uint32_t *coop_slot(const Coop &c, int s) {
@@ -111,11 +117,11 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
     const uint8_t *tab = reinterpret_cast<const uint8_t *>(coop_lds + COOP_TAB_OFF) + tab_row_byte;
     static_assert(NT <= 12, "column accumulators hold at most 12 unreduced products");
     static_assert(!TRIPLE || NT <= 6, "tripling needs a factor 3 of headroom");
-    static_assert((NT & 1) == 0, "terms are split over two lanes");
+    static_assert((NT & 1) == 0 && NT >= 4, "terms are split over two or four lanes, each with at least one");
     uint64_t acc[28];
     {   // first term initialises the columns (no zero-fill of 56 registers)
         uint32_t x[14], y[14];
-        coop_load28_pair(x, y, coop_slot(c, tab[2 * c.h]), coop_slot(c, tab[2 * c.h + 1]));
+        coop_load28_pair(x, y, coop_slot(c, tab[2 * c.q]), coop_slot(c, tab[2 * c.q + 1]));
 #pragma unroll
         for (int i = 0; i < 14; i++)
 #pragma unroll
@@ -126,7 +132,7 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
         acc[27] = 0;
     }
 #pragma unroll 1
-    for (int t = c.h + 2; t < NT; t += 2) {
+    for (int t = c.q + c.nq; t < NT; t += c.nq) {
         uint32_t x[14], y[14];
         coop_load28_pair(x, y, coop_slot(c, tab[2 * t]), coop_slot(c, tab[2 * t + 1]));
 #pragma unroll
@@ -169,7 +175,16 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
         const auto sw = __builtin_amdgcn_permlane16_swap(r.l[i], r.l[i], false, false);
         r.l[i] = sw[0] + sw[1];
     }
-    f28_carry(r);   // value < 2 * 1.44 p, limbs back below 2^28
+    if (c.nq == 4) {   // (wave-uniform) the other half-wave holds the sum of the other two quarters
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(r.l[i], r.l[i], false, false);
+            r.l[i] = sw[0] + sw[1];
+        }
+    }
+    // value: two halves < 2 * 1.44 p; four quarters < 4 * (3 * 7 * 26 / 2520 + 1) p = 4.87 p (every operand bound of the
+    // staging code assumes v <= 6, CONJ and INV v <= 5); limbs back below 2^28
+    f28_carry(r);
     return f28_pack(r);
 }
 template <int NT, bool TRIPLE>
@@ -385,20 +400,20 @@ H2V_DI F28 coop_inv(const Coop &c, const F28 &f, bool &ok) {
 // big-integer pairing by tools/gen_coop_program.py).  Fp12 variables live in a private array, so no vector state is
 // live across the engine call (the first version kept them in VGPRs and spent 65 % of its wave-cycles waiting on
 // the spills around every call).
-extern "C" __global__ void __launch_bounds__(64, 2)
-k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
-               const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac /* folded el (recursion) or NULL */,
-               uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg,
-               const uint32_t *__restrict__ skip /* RLC mode: return at once when *skip != 0; NULL = always run */) {
-    if (skip && skip[0]) return;
-    const int lane = threadIdx.x, grp = lane >> 5;
+template <bool WIDE>
+H2V_DI void pairing_coop_body(const H2vDevPlan &plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
+                              const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac /* folded el (recursion) or NULL */,
+                              uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
+    const int lane = threadIdx.x, grp = WIDE ? 0 : lane >> 5;
     Coop c;
     c.g = lane & 15;
     c.h = (lane >> 4) & 1;
+    c.nq = WIDE ? 4 : 2;
+    c.q = WIDE ? c.h + 2 * (lane >> 5) : c.h;
     c.grp_off = grp * COOP_GROUP_DW;
     const int leader = grp * 32;  // lane (g = 0, h = 0) of the group
     const bool is_leader = lane == leader;
-    const uint32_t i = blockIdx.x * COOP_GROUPS_PER_WAVE + grp;
+    const uint32_t i = WIDE ? blockIdx.x : blockIdx.x * COOP_GROUPS_PER_WAVE + grp;
     const bool live = i < n;
     const uint32_t ii = live ? i : n - 1;  // dead groups shadow the last proof, never write
     const uint32_t slots = H2V_SLOTS(plan);
@@ -535,11 +550,26 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
     if (c.g == 0) { Fp one; fp_set_one(one); mine = fp_eq(res, one); }
     else if (c.g < 12) mine = fp_is_zero(res);
     const unsigned long long bal = __ballot(mine);
-    const bool is_one = ((bal >> leader) & 0xffffffffull) == 0xffffffffull;
+    const bool is_one = WIDE ? bal == ~0ull : ((bal >> leader) & 0xffffffffull) == 0xffffffffull;
     inv_ok = __shfl((int)inv_ok, leader) != 0;
     if (is_leader && live) {
         if (st == 0 && !(is_one && inv_ok)) st |= H2V_ST_PAIRING;
         status[i] = st;
         accept[i] = st == 0 ? 1 : 0;
     }
+}
+extern "C" __global__ void __launch_bounds__(64, 2)
+k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
+               const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac /* folded el (recursion) or NULL */,
+               uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg,
+               const uint32_t *__restrict__ skip /* RLC mode: return at once when *skip != 0; NULL = always run */) {
+    if (skip && skip[0]) return;
+    pairing_coop_body<false>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg);
+}
+// one proof per wave, four lanes per coefficient: for launches that cannot give every SIMD a wave anyway
+extern "C" __global__ void __launch_bounds__(64, 2)
+k_pairing_coop_wide(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
+                    const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac, uint32_t *__restrict__ status,
+                    uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
+    pairing_coop_body<true>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg);
 }
