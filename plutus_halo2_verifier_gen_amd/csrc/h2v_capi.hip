@@ -535,9 +535,10 @@ static uint32_t launch_msm_ladders(const H2vDevPlan &d, const H2vMsmArgs &ma, ui
     const uint32_t lpp = sh.lpt * ma.n_terms;
     const uint32_t per_block = sh.bs / lpp;
     const uint32_t blocks = (n + per_block - 1) / per_block;
-    if (ma.skip) {   // fall-back of the RLC batch mode
-        if (sh.lpt == 1) hipLaunchKernelGGL(k_g1_msm_merged_cond, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
-        else hipLaunchKernelGGL(k_g1_msm_cond, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+    if (ma.skip) {   // fall-back of the RLC batch mode: a grid of at most one block per CU walks the logical blocks
+        const uint32_t cg = (uint32_t)(msm_n_simd() / 4.0), blocks_c = blocks < cg ? blocks : cg;
+        if (sh.lpt == 1) hipLaunchKernelGGL(k_g1_msm_merged_cond, dim3(blocks_c), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+        else hipLaunchKernelGGL(k_g1_msm_cond, dim3(blocks_c), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
     } else if (sh.lpt == 1) hipLaunchKernelGGL(k_g1_msm_merged, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
     else hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
     return sh.lpt;
@@ -1149,17 +1150,24 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     uint8_t *valid1 = (uint8_t *)(r->misc + 26), *acc1 = (uint8_t *)(r->misc + 27);
     HIPCHK(hipMemsetAsync(r->misc + 24, 0, 8, pm));            // status of the batch check, skip flag
     HIPCHK(hipMemsetAsync(valid1, 1, 1, pm));
-    launch_pairing_impl(1, d1, 1, r->misc, valid1, nullptr, r->sums, r->sums + 36, st1, acc1, nullptr, pm);
-    hipLaunchKernelGGL(k_rlc_finalize, dim3((n + 255) / 256), dim3(256), 0, pm, n, r->good, acc1, accept, skip);
+    hipLaunchKernelGGL(k_pairing_rlc, dim3(1), dim3(64), 0, pm, d1, r->misc, valid1, r->sums, r->sums + 36, st1, acc1, n, r->good, accept, skip);
     HIPCHK(hipEventRecord(ev[9], pm));
-    // fall-back, skipped on the device when the batch check passed: window tables, per-proof MSM, per-proof pairing
-    hipLaunchKernelGGL(k_build_tables, dim3((n * slots + 63) / 64), dim3(64), 0, pm, n * slots, w->pts, w->valid, w->pt_tab, skip);
+    // fall-back, skipped on the device when the batch check passed: window tables, per-proof MSM, per-proof pairing - small
+    // grids that walk their logical blocks, so that finding out that they are not needed costs a few microseconds each
+    const uint32_t cond_grid = (uint32_t)(msm_n_simd() / 4.0);
+    {
+        const uint32_t nb = (n * slots + 63) / 64;
+        hipLaunchKernelGGL(k_build_tables, dim3(nb < cond_grid ? nb : cond_grid), dim3(64), 0, pm, n * slots, w->pts, w->valid, w->pt_tab, skip);
+    }
     {
         H2vMsmArgs ma = {d.terms, 0, d.n_main_terms, d.n_terms, 0, slots, {d.n_main_terms, d.n_main_terms, d.n_main_terms}, {w->er, nullptr, nullptr},
                          w->pt_tab, d.vk_tab, nullptr, 0, 0, skip};
         launch_msm_range(d, ma, n, w->scalars, w->pts, nullptr, pm);
     }
-    launch_pairing_impl(1, d, n, w->pts, w->valid, w->valid_sub, w->er, nullptr, w->status, accept, nullptr, pm, skip);
+    {
+        const uint32_t nb = (n + 1) / 2, grid = nb < 4 * cond_grid ? nb : 4 * cond_grid;
+        hipLaunchKernelGGL(k_pairing_coop, dim3(grid), dim3(64), 0, pm, d, n, w->pts, w->valid, w->valid_sub, w->er, (const uint32_t *)nullptr, w->status, accept, (uint32_t *)nullptr, skip);
+    }
     HIPCHK(hipGetLastError());
     if (status_out) HIPCHK(hipMemcpyAsync(status_out, w->status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
     return H2V_OK;

@@ -624,7 +624,8 @@ struct H2vMsmArgs {
 template <int LPT, bool FIX = false, bool MADD_INL = false>
 H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, uint32_t per_block,
                      const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws,
-                     uint32_t *red /* Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t] */) {
+                     uint32_t *red /* Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t] */,
+                     const uint32_t bid /* logical block: blockIdx.x, or the loop index of a conditional launch */) {
     static_assert(!FIX || LPT == 1, "fixed-base mode runs merged ladders");
     constexpr int NH = 2 / LPT;   // GLV halves per lane
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
@@ -633,7 +634,7 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
     const uint32_t sub = tid - seg * lanes_per_proof; // position inside the proof's segment
     const bool fix_lane = FIX;   // a fixed-base launch has no ladder lanes (a wave mixing the two kinds would run them one after the other)
     const uint32_t term = FIX ? 0u : (LPT == 2 ? sub >> 1 : sub), half = LPT == 2 ? sub & 1 : 0;
-    const uint32_t i = blockIdx.x * per_block + seg;
+    const uint32_t i = bid * per_block + seg;
     const bool active = seg < per_block && i < n;
     // this lane's group: position and length of its reduction segment inside the proof's lanes
     const uint32_t grp = FIX ? 0u : (term < ma.grp_end[0] ? 0u : (term < ma.grp_end[1] ? 1u : 2u));
@@ -851,37 +852,47 @@ extern "C" __global__ void __launch_bounds__(512, 2)
 k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
          const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];
-    msm_body<2, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red);
+    msm_body<2, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red, blockIdx.x);
 }
 extern "C" __global__ void __launch_bounds__(512, 2)
 k_g1_msm_merged(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
                 const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];
-    msm_body<1, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red);
+    msm_body<1, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red, blockIdx.x);
 }
 
 // the same two ladders as the fall-back of the RLC batch mode: they return at once when the batch check passed.  (Separate
-// entry points: the check costs the parity path's kernels nothing, not even a different register allocation.)
+// entry points: the check costs the parity path's kernels nothing, not even a different register allocation.)  The grid
+// is small and walks the logical blocks in a loop: a launch that only has to find out that it is not needed should not
+// cost a thousand workgroup dispatches (40-50 us per skipped kernel on the RLC mode's critical path before).
 extern "C" __global__ void __launch_bounds__(512, 2)
 k_g1_msm_cond(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, const uint32_t *__restrict__ scalars,
               const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];
     if (ma.skip[0]) return;   // (uniform over the launch: before any barrier)
-    msm_body<2, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red);
+    const uint32_t n_blocks = (n + per_block - 1) / per_block;
+    for (uint32_t bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
+        msm_body<2, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red, bid);
+        __syncthreads();
+    }
 }
 extern "C" __global__ void __launch_bounds__(512, 2)
 k_g1_msm_merged_cond(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, const uint32_t *__restrict__ scalars,
                      const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];
     if (ma.skip[0]) return;
-    msm_body<1, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red);
+    const uint32_t n_blocks = (n + per_block - 1) / per_block;
+    for (uint32_t bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
+        msm_body<1, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red, bid);
+        __syncthreads();
+    }
 }
 
 extern "C" __global__ void __launch_bounds__(512, 2)
 k_g1_msm_fixed(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
                const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];
-    msm_body<1, true>(plan, ma, n, per_block, scalars, pts, tabws, red);
+    msm_body<1, true>(plan, ma, n, per_block, scalars, pts, tabws, red, blockIdx.x);
 }
 
 

@@ -403,7 +403,8 @@ H2V_DI F28 coop_inv(const Coop &c, const F28 &f, bool &ok) {
 template <bool WIDE>
 H2V_DI void pairing_coop_body(const H2vDevPlan &plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
                               const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac /* folded el (recursion) or NULL */,
-                              uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
+                              uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg, const uint32_t bid,
+                              bool *verdict_out = nullptr /* WIDE: the verdict, in every lane */) {
     const int lane = threadIdx.x, grp = WIDE ? 0 : lane >> 5;
     Coop c;
     c.g = lane & 15;
@@ -413,7 +414,7 @@ H2V_DI void pairing_coop_body(const H2vDevPlan &plan, uint32_t n, const uint32_t
     c.grp_off = grp * COOP_GROUP_DW;
     const int leader = grp * 32;  // lane (g = 0, h = 0) of the group
     const bool is_leader = lane == leader;
-    const uint32_t i = WIDE ? blockIdx.x : blockIdx.x * COOP_GROUPS_PER_WAVE + grp;
+    const uint32_t i = WIDE ? bid : bid * COOP_GROUPS_PER_WAVE + grp;
     const bool live = i < n;
     const uint32_t ii = live ? i : n - 1;  // dead groups shadow the last proof, never write
     const uint32_t slots = H2V_SLOTS(plan);
@@ -557,6 +558,7 @@ H2V_DI void pairing_coop_body(const H2vDevPlan &plan, uint32_t n, const uint32_t
         status[i] = st;
         accept[i] = st == 0 ? 1 : 0;
     }
+    if (verdict_out) *verdict_out = st == 0 && is_one && inv_ok;   // (st, is_one, inv_ok are the leader's in every lane)
 }
 extern "C" __global__ void __launch_bounds__(64, 2)
 k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
@@ -564,12 +566,30 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
                uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg,
                const uint32_t *__restrict__ skip /* RLC mode: return at once when *skip != 0; NULL = always run */) {
     if (skip && skip[0]) return;
-    pairing_coop_body<false>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg);
+    if (!skip) { pairing_coop_body<false>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg, blockIdx.x); return; }
+    // conditional launch (fall-back of the RLC batch mode): a small grid walks the logical blocks
+    const uint32_t n_blocks = (n + COOP_GROUPS_PER_WAVE - 1) / COOP_GROUPS_PER_WAVE;
+    for (uint32_t bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
+        pairing_coop_body<false>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg, bid);
+        __syncthreads();
+    }
 }
 // one proof per wave, four lanes per coefficient: for launches that cannot give every SIMD a wave anyway
 extern "C" __global__ void __launch_bounds__(64, 2)
 k_pairing_coop_wide(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
                     const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac, uint32_t *__restrict__ status,
                     uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
-    pairing_coop_body<true>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg);
+    pairing_coop_body<true>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg, blockIdx.x);
+}
+// The single pairing of the RLC batch mode with its epilogue fused in: batch check passed -> accept[i] = good_i for the whole
+// batch and *skip = 1 (the per-proof kernels queued behind return at once); failed -> *skip = 0 and accept[] is left to them.
+extern "C" __global__ void __launch_bounds__(64, 2)
+k_pairing_rlc(H2vDevPlan plan, const uint32_t *__restrict__ pts1, const uint8_t *__restrict__ valid1, const uint32_t *__restrict__ er_jac,
+              const uint32_t *__restrict__ el_jac, uint32_t *__restrict__ status1, uint8_t *__restrict__ accept1,
+              uint32_t n_batch, const uint8_t *__restrict__ good, uint8_t *__restrict__ accept, uint32_t *__restrict__ skip) {
+    bool ok = false;
+    pairing_coop_body<true>(plan, 1u, pts1, valid1, nullptr, er_jac, el_jac, status1, accept1, nullptr, 0u, &ok);
+    if (threadIdx.x == 0) skip[0] = ok ? 1u : 0u;
+    if (ok)
+        for (uint32_t i = threadIdx.x; i < n_batch; i += 64) accept[i] = good[i];
 }

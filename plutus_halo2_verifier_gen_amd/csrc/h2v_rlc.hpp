@@ -8,8 +8,8 @@
 //                   r_i s_{i,t} mod r of its per-proof terms, its share of the VK-base sums, and (r_i, pi_i) for the left side
 //   k_rlc_vk_sum    sum_i r_i s_{i,f} per VK base f (the bases are the same for every proof: one term each)
 //   bucket MSMs     R = sum_i r_i er_i (255-bit scalars, GLV)  and  L = sum_i r_i pi_i (128-bit scalars)
-//   k_pairing_coop  ONE check e(L, s_g2) == e(R, G2)
-//   k_rlc_finalize  accepted: accept[i] = good_i.  Rejected (some good-looking proof fails its own pairing equation, caught
+//   k_pairing_rlc   ONE check e(L, s_g2) == e(R, G2) (wide engine) with the epilogue fused in:
+//                   accepted: accept[i] = good_i.  Rejected (some good-looking proof fails its own pairing equation, caught
 //                   with probability >= 1 - 2^-128 over the seed): the per-proof MSM + pairing kernels that follow on the
 //                   stream are NOT skipped and produce accept[] exactly as the per-proof mode does.
 #pragma once
@@ -119,26 +119,17 @@ k_rlc_vk_sum(RlcArgs a, uint32_t n_blocks) {
     a.r_idx[e] = a.n * a.slots + a.terms[2 * (a.n_var + f) + 1];   // pool 1 (the plan's VK bases) starts at n * slots
 }
 
-// rlc_accept: the one-group pairing kernel's verdict.  *skip = 1 tells the per-proof kernels queued behind to return at once.
-extern "C" __global__ void __launch_bounds__(256)
-k_rlc_finalize(uint32_t n, const uint8_t *__restrict__ good, const uint8_t *__restrict__ rlc_accept, uint8_t *__restrict__ accept,
-               uint32_t *__restrict__ skip) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = rlc_accept[0] != 0;
-    if (i == 0) skip[0] = ok ? 1u : 0u;
-    if (i < n && ok) accept[i] = good[i];
-}
-
 // fall-back path only: the MSM window tables of every per-proof point, which the RLC mode's decompression launch skips
 extern "C" __global__ void __launch_bounds__(64)
 k_build_tables(uint32_t n_points, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, uint32_t *__restrict__ pt_tab,
                const uint32_t *__restrict__ skip) {
     if (skip && skip[0]) return;
-    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= n_points || !valid[g]) return;
-    G1A p;
+    for (uint32_t g = blockIdx.x * 64 + threadIdx.x; g < n_points; g += gridDim.x * 64) {   // (small grid: see k_g1_msm_cond)
+        if (!valid[g]) continue;
+        G1A p;
 #pragma unroll
-    for (int k = 0; k < 12; k++) { p.x.v[k] = pts[(size_t)g * 24 + k]; p.y.v[k] = pts[(size_t)g * 24 + 12 + k]; }
-    if (g1a_is_inf(p)) return;
-    g1_build_window_tables_glv(pt_tab + (size_t)g * 448, p);
+        for (int k = 0; k < 12; k++) { p.x.v[k] = pts[(size_t)g * 24 + k]; p.y.v[k] = pts[(size_t)g * 24 + 12 + k]; }
+        if (g1a_is_inf(p)) continue;
+        g1_build_window_tables_glv(pt_tab + (size_t)g * 448, p);
+    }
 }
