@@ -51,6 +51,14 @@ def main() -> int:
         print("ERROR: the invalid proof verified")
         return 1
 
+    # many proofs at once (the form the hardware wants), per proof and through the batch-accept fast path
+    v = api.verifier_for(vk)
+    many = [proof, bytes(invalid_proof)] * 8
+    per_proof = v.verify_batch(many, [instance] * len(many))
+    rlc = v.verify_batch(many, [instance] * len(many), mode="rlc")
+    assert per_proof == rlc == [True, False] * 8
+    print("batch of %d verified in both modes: %d accepted" % (len(many), sum(per_proof)))
+
     out = sys.argv[1] if len(sys.argv) > 1 else None
     if out:
         os.makedirs(out, exist_ok=True)
