@@ -396,7 +396,8 @@ H2V_DI F28 coop_inv(const Coop &c, const F28 &f, bool &ok) {
 
 // dbg (optional): per proof 2 x 12 Fp (canonical, 12 dwords each): f after the Miller loop, f after the final
 // exponentiation; flat order (k, part).
-// The kernel interprets COOP_PROGRAM (coop_program.h: 577 Fp12-level operations, generated and simulated against the
+// The kernel interprets COOP_PROGRAM (coop_program.h: 34 steps since the Miller loop and the exponentiations by x are single
+// steps; generated and simulated against the
 // big-integer pairing by tools/gen_coop_program.py).  Fp12 variables live in a private array, so no vector state is
 // live across the engine call (the first version kept them in VGPRs and spent 65 % of its wave-cycles waiting on
 // the spills around every call).
@@ -511,6 +512,42 @@ H2V_DI void pairing_coop_body(const H2vDevPlan &plan, uint32_t n, const uint32_t
                 if (!skip2 && c.g < 12) f = r2;
             }
             vars[COOP_VAR_F] = f;
+        } break;
+        case COOP_OP_MILLER: {
+            // The whole Miller loop as one step: F never leaves the registers (as 63 MSTEPs it went through the variable
+            // file - scratch - 126 times).  Per bit of |x| below the leading one: F = F^2, then one (doubling) or two
+            // (doubling + addition) rounds of { line of loop 1, line of loop 2 }; invariants as for MSTEP.
+            F28 f = vars[COOP_VAR_F];
+            int ln = 0;
+#pragma unroll 1
+            for (int bit = 62; bit >= 0; bit--) {
+                f = coop_sqr(c, f);
+                const int steps = ((BLS_X_ABS >> bit) & 1) ? 2 : 1;
+#pragma unroll 1
+                for (int s2 = 0; s2 < steps; s2++, ln++) {
+                    if (ln > 0) coop_stage_line(c, COOP_SLOT_LN2, plan.lines28_g2, ln, lane);
+                    __syncthreads();
+                    const F28 r1 = coop_line<1>(c, f);
+                    if (!skip1 && c.g < 12) f = r1;
+                    if (ln + 1 < H2V_MILLER_LINES) coop_stage_line(c, COOP_SLOT_LN1, plan.lines28_sg2, ln + 1, lane);
+                    __syncthreads();
+                    const F28 r2 = coop_line<2>(c, f);
+                    if (!skip2 && c.g < 12) f = r2;
+                }
+            }
+            vars[COOP_VAR_F] = f;
+        } break;
+        case COOP_OP_EXPX: {   // d = a^x (x < 0: conjugate of a^|x|), the running power in registers throughout
+            F28 x = vars[a];
+#pragma unroll 1
+            for (int bit = 62; bit >= 0; bit--) {
+                x = coop_csqr(c, x);
+                if ((BLS_X_ABS >> bit) & 1) {
+                    const F28 y = vars[a];
+                    x = coop_mul(c, x, y);
+                }
+            }
+            vars[d] = coop_conj(c, x);
         } break;
         case COOP_OP_WARMUP: {
             coop_stage_line(c, COOP_SLOT_LN1, plan.lines28_sg2, 0, lane);

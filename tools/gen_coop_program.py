@@ -16,8 +16,12 @@ sys.path.insert(0, ROOT)
 from plutus_halo2_verifier_gen_amd import bls12_381 as bls  # noqa: E402
 
 # opcodes (4 bytes per instruction: op, dst, a, b)
-OP_END, OP_MUL, OP_MSTEP, OP_CONJ, OP_FROB, OP_INV, OP_MOV, OP_SETONE, OP_DUMP, OP_WARMUP, OP_CSQR = range(11)
-OP_NAMES = ["END", "MUL", "MSTEP", "CONJ", "FROB", "INV", "MOV", "SETONE", "DUMP", "WARMUP", "CSQR"]
+OP_END, OP_MUL, OP_MSTEP, OP_CONJ, OP_FROB, OP_INV, OP_MOV, OP_SETONE, OP_DUMP, OP_WARMUP, OP_CSQR, OP_MILLER, OP_EXPX = range(13)
+OP_NAMES = ["END", "MUL", "MSTEP", "CONJ", "FROB", "INV", "MOV", "SETONE", "DUMP", "WARMUP", "CSQR", "MILLER", "EXPX"]
+# MILLER: the whole Miller loop on F as ONE interpreter step (63 x MSTEP with the line counts read off the bits of |x|): F
+# stays in registers from the first squaring to the last line instead of going through the variable file 63 times.
+# EXPX d, a: d = conj(a^|x|) = a^x for a in the cyclotomic subgroup, as one step: the running power stays in registers
+# through the runs of cyclotomic squarings and the five multiplications by a (re-read from the variable file each time).
 # MSTEP n, line: one step of the Miller loop on F: F = F^2 (general squaring), then n in {1, 2} times { F *= line of
 # loop 1, F *= line of loop 2 } starting at line index `line` (doubling step; plus the addition step where the bit of
 # |x| is set).  F stays in registers for the whole step.
@@ -33,12 +37,8 @@ def build_program():
     e = lambda *ins: prog.append(tuple(list(ins) + [0] * (4 - len(ins))))
     e(OP_SETONE, F)
     e(OP_WARMUP)
-    line = 0
-    for bit in bls.miller_bits():
-        n = 2 if bit else 1
-        e(OP_MSTEP, n, line)
-        line += n
-    assert line == 68
+    e(OP_MILLER)
+    assert sum(2 if bit else 1 for bit in bls.miller_bits()) == 68
     # x < 0: the Miller value is m = conj(F).  Easy part m^(p^6-1) = conj(m) * m^-1 = F * conj(F^-1); written so that
     # every CONJ / INV operand is an engine output (the lazily reduced field bounds of h2v_pairing_coop.hpp).
     e(OP_CONJ, U, F)
@@ -51,17 +51,7 @@ def build_program():
     e(OP_MUL, T, A, T)        # ^(p^2+1)
 
     def exp_x(dst, src):      # dst = src^x, x = -|x|  (cyclotomic subgroup: inverse = conjugate)
-        bits = bls.miller_bits()          # the bits of |x| below the leading one
-        cur, run = src, 0
-        for bit in bits:
-            run += 1                      # Granger-Scott squaring: X is in the cyclotomic subgroup after the easy part
-            if bit:
-                e(OP_CSQR, X, cur, run)
-                e(OP_MUL, X, X, src)
-                cur, run = X, 0
-        if run:
-            e(OP_CSQR, X, cur, run)
-        e(OP_CONJ, dst, X)
+        e(OP_EXPX, dst, src)
 
     exp_x(A, T); e(OP_CONJ, U, T); e(OP_MUL, T0, A, U)       # t^(x-1)
     exp_x(A, T0); e(OP_CONJ, U, T0); e(OP_MUL, T1, A, U)     # ^(x-1)
@@ -96,6 +86,12 @@ def check_bounds(prog):
         elif op == OP_MSTEP:
             assert v[F] <= 6 and d in (1, 2)
             v[F] = 3
+        elif op == OP_MILLER:
+            assert v[F] <= 6
+            v[F] = 3
+        elif op == OP_EXPX:
+            assert v[a] <= 6          # staged as an operand of the squarings and of the multiplications
+            v[d] = 6                  # conj of an engine result
         elif op == OP_CONJ:
             assert v[a] <= 5, "CONJ of a value that is not an engine / FROB result"
             v[d] = 6
@@ -139,6 +135,22 @@ def simulate(prog, p1, q1, p2, q2):
                 for loop in (1, 2):
                     if pts[loop] is not None:
                         v[F] = bls.f12_mul(v[F], bls._line_eval(lines[loop][idx], pts[loop]))
+        elif op == OP_MILLER:
+            idx = 0
+            for bit in bls.miller_bits():
+                v[F] = bls.f12_sqr(v[F])
+                for _ in range(2 if bit else 1):
+                    for loop in (1, 2):
+                        if pts[loop] is not None:
+                            v[F] = bls.f12_mul(v[F], bls._line_eval(lines[loop][idx], pts[loop]))
+                    idx += 1
+        elif op == OP_EXPX:
+            t = v[a]
+            for bit in bls.miller_bits():
+                t = bls.f12_sqr(t)
+                if bit:
+                    t = bls.f12_mul(t, v[a])
+            v[d] = bls.f12_conj(t)
         elif op == OP_CONJ:
             v[d] = bls.f12_conj(v[a])
         elif op == OP_FROB:
@@ -194,10 +206,13 @@ def emit():
     if row:
         o.append("    " + ", ".join(row) + ",")
     o.append("};")
-    n_mul = sum(1 for p in prog if p[0] == OP_MUL)
-    n_line = sum(2 * p[1] for p in prog if p[0] == OP_MSTEP)
-    n_csqr = sum(p[3] for p in prog if p[0] == OP_CSQR)
-    n_sqr = sum(1 for p in prog if p[0] == OP_MSTEP)
+    bits = bls.miller_bits()
+    n_expx = sum(1 for p in prog if p[0] == OP_EXPX)
+    n_mil = sum(1 for p in prog if p[0] == OP_MILLER)
+    n_mul = sum(1 for p in prog if p[0] == OP_MUL) + n_expx * sum(1 for b in bits if b)
+    n_line = sum(2 * p[1] for p in prog if p[0] == OP_MSTEP) + n_mil * 2 * sum(2 if b else 1 for b in bits)
+    n_csqr = sum(p[3] for p in prog if p[0] == OP_CSQR) + n_expx * len(bits)
+    n_sqr = sum(1 for p in prog if p[0] == OP_MSTEP) + n_mil * len(bits)
     o.append("// %d instructions: %d MUL, %d SQR, %d CSQR, %d LINE" % (len(prog), n_mul, n_sqr, n_csqr, n_line))
     path = os.path.join(ROOT, "plutus_halo2_verifier_gen_amd", "csrc", "coop_program.h")
     with open(path, "w") as f:
