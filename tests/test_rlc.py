@@ -281,3 +281,30 @@ def test_random_byte_flips_three_way(be, circuits, name):
     assert list(got_rlc) == list(want)
     assert all(want[i] == 1 for i in range(n) if i not in touched)
     assert sum(want[i] for i in touched) <= 2      # a one-bit change is (almost) always fatal; never silently ignored en masse
+
+
+def test_rlc_infinity_points(be, circuits):
+    """The point at infinity is a valid G1 encoding: as pi (the left-hand side of one proof vanishes), as a commitment,
+    as every commitment of a proof.  Same verdicts as the oracle in both modes; such proofs take part in the batch check
+    (their terms are skipped by the bucket MSM) and make it fail when their own equation fails."""
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    n = 24
+    good = synth.forge_batch(vk, td, n, seed=81, plan=pl, workers=1)
+    inf = bls.g1_compress(None)
+    proofs = [bytearray(good.proof(i)) for i in range(n)]
+    o_pi = pl.points[pl.pi_point]
+    proofs[3][o_pi:o_pi + 48] = inf                                  # pi = O
+    proofs[7][pl.points[1]:pl.points[1] + 48] = inf                  # one commitment = O
+    for o in pl.points:                                              # every G1 element = O
+        proofs[11][o:o + 48] = inf
+    off = [0]
+    for p in proofs:
+        off.append(off[-1] + len(p))
+    pb = b"".join(bytes(p) for p in proofs)
+    want = ov.verify_batch(pb, off, good.instances, None, threads=4)
+    ws = be.Workspace(dp, n)
+    assert list(dp.verify_batch(pb, off, good.instances, None, ws=ws)) == list(want)
+    got, fb = dp.verify_batch_rlc(pb, off, good.instances, None, ws=ws)
+    assert list(got) == list(want) and fb
+    assert want[3] == 0 and want[7] == 0 and sum(want) >= n - 3
