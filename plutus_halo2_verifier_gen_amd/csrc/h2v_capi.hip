@@ -471,11 +471,16 @@ static int launch_vm(const H2vDevPlan &d0, uint32_t n, uint32_t stride, const ui
     const bool wide_ok = d.wide_lanes && !trace;
     const bool wide = wide_ok && (env_wide >= 0 ? env_wide != 0 : ((uint64_t)n * d.wide_lanes + 63) / 64 <= 256);
     if (wide) { d.vm_lanes = d.wide_lanes; d.n_regs = d.wide_n_regs; d.n_instr = d.wide_n_instr; d.instr = d.wide_instr; }
-    const uint32_t P = vm_lds_slots(d);
+    uint32_t P = vm_lds_slots(d);
     if (P == 0) {
         hipLaunchKernelGGL(k_transcript_combiner, dim3((n + 63) / 64), dim3(64), 0, st, d, n, stride, proofs, off, inst, ci, regs, scalars, status, trace);
         return H2V_OK;
     }
+    // Fewer proofs per block than the wave could serve (the spare lanes shadow): the register file of P proofs is what
+    // decides how many blocks a CU holds (simple_mul, P = 32: 79 + 8 KB = ONE block per CU = one wave on one of its four
+    // SIMDs), and a wave's chain is as long with 16 proofs as with 32.  H2V_VM_P forces P (power of two).
+    static const int env_p = []() { const char *e = getenv("H2V_VM_P"); return e ? atoi(e) : 0; }();
+    if (env_p >= 1 && (env_p & (env_p - 1)) == 0 && (uint32_t)env_p <= P) P = (uint32_t)env_p;
     const size_t lds = (size_t)d.n_regs * 32 * P;
     HIPCHK(hipFuncSetAttribute((const void *)k_transcript_combiner_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_transcript_combiner_lds, dim3((n + P - 1) / P), dim3(64), lds, st, d, n, P, proofs, off, inst, ci, scalars, status, trace);

@@ -182,6 +182,7 @@ H2V_DI void tr_absorb_scalar(Transcript &s, uint32_t *sbuf, int lane, const Fr &
 template <class RF>
 H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const int lane, const uint32_t i, const uint32_t ii,
                    const bool live, const uint32_t L, const uint32_t sub, uint32_t *st_red /* 64 dwords of LDS */,
+                   const uint32_t P /* proof slots of the block: lane l serves slot l & (P - 1) */,
                    const uint8_t *__restrict__ proofs, const uint64_t *__restrict__ proof_off,
                    const uint8_t *__restrict__ instances, const uint8_t *__restrict__ committed,
                    uint32_t *__restrict__ scalars, uint32_t *__restrict__ status, uint32_t *__restrict__ trace) {
@@ -340,7 +341,6 @@ H2V_DI void vm_run(const H2vDevPlan &plan, const RF rf, uint32_t *sbuf, const in
     if (L > 1) {   // status bits of the proof's other lanes (inverse of zero, recursion check)
         st_red[lane] = st;
         __syncthreads();
-        const uint32_t P = 64 / L;
         for (uint32_t k = 1; k < L; k++) st |= st_red[((uint32_t)lane & (P - 1)) + k * P];
     }
     if (live && sub == 0) {
@@ -368,7 +368,7 @@ k_transcript_combiner(H2vDevPlan plan, uint32_t n, uint32_t stride, const uint8_
     const bool live = i < n;
     const uint32_t ii = live ? i : n - 1;  // dead lanes shadow the last proof (keeps control flow uniform), never write
     const RegsGlobal rf = {regs, stride, ii, i};
-    vm_run(plan, rf, sbuf, lane, i, ii, live, 1u, 0u, nullptr, proofs, proof_off, instances, committed, scalars, status, trace);
+    vm_run(plan, rf, sbuf, lane, i, ii, live, 1u, 0u, nullptr, 64u, proofs, proof_off, instances, committed, scalars, status, trace);
 }
 // P proofs per block (power of two, <= 64), register file in dynamic LDS: P * n_regs * 32 bytes
 extern "C" __global__ void __launch_bounds__(64)
@@ -381,14 +381,15 @@ k_transcript_combiner_lds(H2vDevPlan plan, uint32_t n, uint32_t P, const uint8_t
     const int lane = threadIdx.x;
     const uint32_t L = plan.vm_lanes;
     const uint32_t q = (uint32_t)lane & (P - 1);            // proof slot of the block
-    const uint32_t sub = L > 1 ? (uint32_t)lane / P : 0u;   // which of the proof's lanes (L > 1: P * L = 64)
+    const uint32_t sub = L > 1 ? ((uint32_t)lane / P) % L : 0u;   // which of the proof's lanes
     const uint32_t i = blockIdx.x * P + q;
-    // single-lane plans with P < 64: lanes >= P shadow slot q (same proof, same work) and never write
-    const bool live = (L > 1 || (uint32_t)lane < P) && i < n;
+    // P * L may be below 64 (fewer proofs per block = less LDS per block = more blocks resident per CU, chosen by the
+    // launcher): lanes >= P * L shadow a lane of the same proof (same work, same values) and never write
+    const bool live = (uint32_t)lane < P * L && i < n;
     const uint32_t ii = i < n ? i : n - 1;
     // a dead slot of the last block shadows proof n-1 but must not touch a live slot's registers: it owns slot q anyway
     const RegsLds rf = {P, q};
-    vm_run(plan, rf, sbuf, lane, i, ii, live, L, sub, st_red, proofs, proof_off, instances, committed, scalars, status, trace);
+    vm_run(plan, rf, sbuf, lane, i, ii, live, L, sub, st_red, P, proofs, proof_off, instances, committed, scalars, status, trace);
 }
 
 // ============================================================================ K2: G1 decompression
