@@ -493,3 +493,31 @@ def test_plan_loader_rejects_broken_bundles():
         m = bytearray(blob)
         struct.pack_into("<I", m, 8 + 4 * 35, bad)
         assert load(m)[0] == -2
+
+
+def test_bucket_msm_recoding_model():
+    """The scalar recoding of the bucket MSM (csrc/h2v_pippenger.hpp: k_pip_digits) restated on integers: GLV split into two
+    halves below 2^128, then signed c-bit digits in [-2^(c-1), 2^(c-1)] over W = 128 // c + 1 windows.  For every window
+    width the launcher can pick (7..10) the digits reconstruct the half exactly, stay in range, and no carry leaves the top
+    window - the property that lets the kernel address 2^(c-1) buckets per window without an overflow bucket."""
+    rng = random.Random(77)
+    lam = bls.GLV_LAMBDA
+    edge = [0, 1, bls.R - 1, lam, lam - 1, lam + 1, (1 << 128) - 1, 1 << 128, (1 << 255) % bls.R, bls.R - lam, bls.R // 2]
+    scalars = edge + [rng.randrange(bls.R) for _ in range(300)]
+    for k in scalars:
+        k1, k2 = bls.glv_split(k)
+        assert 0 <= k1 < (1 << 128) and 0 <= k2 < (1 << 128) and (k1 + k2 * lam - k) % bls.R == 0
+        for c in (7, 8, 9, 10):
+            W, NB = 128 // c + 1, 1 << (c - 1)
+            for half in (k1, k2, (1 << 128) - 1):          # (any value below 2^128 must recode: the left-hand scalars r_i)
+                carry, digits = 0, []
+                for w in range(W):
+                    raw = ((half >> (w * c)) & ((1 << c) - 1)) + carry
+                    if raw > NB:
+                        d, carry = raw - (1 << c), 1
+                    else:
+                        d, carry = raw, 0
+                    digits.append(d)
+                assert carry == 0
+                assert all(-NB <= d <= NB for d in digits)
+                assert sum(d << (w * c) for w, d in enumerate(digits)) == half
