@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="proofs per GPU (weak) / in total (strong); default: the workload's BASELINE size")
     ap.add_argument("--mode", default="per-proof", choices=["per-proof", "rlc"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--inflight", type=int, default=0, help="steps in flight (workspaces / streams); default: 2 (per-proof, batches above 1024), 4 (per-proof, smaller), 5 (rlc)")
+    ap.add_argument("--inflight", type=int, default=0, help="steps in flight (workspaces / streams); default: 2 (per-proof, batches above 1024), 4 (per-proof, smaller), 7 (rlc)")
     ap.add_argument("--msm-tpl", type=int, default=0, choices=[0, 1, 2, 4],
                     help="per-proof MSM: terms per lane (sets H2V_MSM_TPL; 2 / 4 share the doublings of a lane's terms)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -123,7 +123,7 @@ def main():
     # with twelve streams the runtime sometimes maps two busy ones onto one hardware queue), 7 -> 2.0 (the tail of a batch -
     # bucket reduction, doublings, ONE pairing - is a few waves)
     small = (args.batch or WORKLOADS[args.workload][1]) <= 1024
-    inflight = args.inflight or (5 if args.mode == "rlc" else 4 if small else 2)
+    inflight = args.inflight or (7 if args.mode == "rlc" else 4 if small else 2)
     if args.msm_tpl:
         os.environ["H2V_MSM_TPL"] = str(args.msm_tpl)
     # several steps in flight use 3 streams each: more hardware queues than the runtime's default of 4, or they serialise
@@ -207,7 +207,7 @@ def main():
                 ptrs = (B, d_proofs.data_ptr(), d_off.data_ptr(), d_inst.data_ptr(), d_ci.data_ptr() if d_ci is not None else None,
                         d_accepts[slot].data_ptr(), d_statuses[slot].data_ptr())
                 if mode == "rlc":
-                    dp.verify_batch_rlc_device(*ptrs, ws=wss[slot], stream=stream, seed=rlc_seed)
+                    dp.verify_batch_rlc_device(*ptrs, ws=wss[slot], stream=stream, seed=rlc_seed, one_stream=inflight >= 3)
                 else:
                     dp.verify_batch_device(*ptrs, ws=wss[slot], stream=stream)
                 if use_gather:
@@ -310,7 +310,7 @@ def main():
     # config ("G1 MSM + one pairing per proof") names.
     rlc_secondary = None
     if args.mode == "per-proof" and not args.no_rlc_secondary and vk.recursion_vks is None:
-        inflight2 = 5
+        inflight2 = 7
         el2, wss2, acc2 = timed_run("rlc", inflight2, args.steps, args.warmup, False)
         ok2, tm2 = wss2[0].rlc_result()
         rlc_secondary = {"value": round(B_total * args.steps / el2, 2), "unit": "proofs/s", "ms_per_step": round(el2 / args.steps * 1e3, 4),

@@ -42,16 +42,20 @@ class RlcTimings(C.Structure):
 
 
 RLC_SEED_GIVEN = 1
+RLC_ONE_STREAM = 2
 SUBMIT_RLC = 1
 
 
-def _rlc_opts(seed):
-    if seed is None:
+def _rlc_opts(seed, one_stream: bool = False):
+    if seed is None and not one_stream:
         return None
+    flags = RLC_ONE_STREAM if one_stream else 0
+    if seed is None:
+        return RlcOpts((C.c_uint8 * 32)(), flags)
     seed = bytes(seed)
     if len(seed) != 32:
         raise ValueError("the RLC seed is 32 bytes")
-    return RlcOpts((C.c_uint8 * 32)(*seed), RLC_SEED_GIVEN)
+    return RlcOpts((C.c_uint8 * 32)(*seed), flags | RLC_SEED_GIVEN)
 
 
 EXPORTS = [
@@ -178,9 +182,9 @@ class DevicePlan:
         n, b, keep = self._host_batch(proofs, proof_off, instances, committed)
         return b, keep
 
-    def submit(self, batch: "Batch", ws, rlc: bool = False, seed: Optional[bytes] = None):
+    def submit(self, batch: "Batch", ws, rlc: bool = False, seed: Optional[bytes] = None, one_stream: bool = False):
         """h2v_verify_batch_submit: copy + upload + verification + download enqueued on the workspace's stream."""
-        opts = _rlc_opts(seed)
+        opts = _rlc_opts(seed, one_stream)
         check(lib().h2v_verify_batch_submit(self._h, C.byref(batch), ws.handle, SUBMIT_RLC if rlc else 0,
                                             C.byref(opts) if opts is not None else None))
 
@@ -196,9 +200,9 @@ class DevicePlan:
         return bytes(acc[:n]), bool(fb.value)
 
     def verify_batch_rlc_device(self, n, d_proofs, d_off, d_inst, d_ci, d_accept, d_status=None, ws=None, stream=None,
-                                seed: Optional[bytes] = None):
+                                seed: Optional[bytes] = None, one_stream: bool = False):
         b = Batch(n, d_proofs, d_off, d_inst, d_ci)
-        opts = _rlc_opts(seed)
+        opts = _rlc_opts(seed, one_stream)
         check(lib().h2v_verify_batch_rlc_device(self._h, C.byref(b), d_accept, d_status, ws.handle if ws else None, stream,
                                                 C.byref(opts) if opts is not None else None))
 

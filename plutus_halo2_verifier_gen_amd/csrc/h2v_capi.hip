@@ -901,7 +901,7 @@ static int stage_inputs(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws
     return H2V_OK;
 }
 static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
-                   uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, const uint32_t seed[8]);
+                   uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, const uint32_t seed[8], bool one_stream_opt);
 static bool rlc_supported(const h2v_plan *p);
 static int rlc_seed(const h2v_rlc_opts *o, uint32_t seed[8]);
 
@@ -927,7 +927,8 @@ extern "C" int h2v_verify_batch_submit(const h2v_plan *p, const h2v_batch *b, h2
         if (rlc) {
             uint32_t seed[8];
             if ((rc = rlc_seed(opts, seed))) return rc;
-            rc = run_rlc(p, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, ws->hs, seed);
+            rc = run_rlc(p, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, ws->hs, seed,
+                         opts && (opts->flags & H2V_RLC_ONE_STREAM));
             ws->pending_rlc = true;
         } else {
             rc = run_pipeline(p->d, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, ws->hs, nullptr, false);
@@ -1101,7 +1102,7 @@ static bool rlc_supported(const h2v_plan *p) { return !p->d.ivc && p->n_var > 0 
 // One batch in RLC mode.  Phase 1 as in run_pipeline (the decompression launch builds no window tables), then the batch
 // check; the per-proof MSM + pairing kernels are queued behind it and return at once unless the batch check failed.
 static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
-                   uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, const uint32_t seed[8]) {
+                   uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, const uint32_t seed[8], bool one_stream_opt) {
     const H2vDevPlan &d = p->d;
     int rc = rlc_ensure(w, p);
     if (rc) return rc;
@@ -1110,10 +1111,16 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     hipEvent_t *ev = r->ring[r->calls % h2v_workspace::RING];
     r->calls++;
     // two streams per batch: the caller's (transcript + combiner, then everything else) and one for the decompression
-    if ((rc = ws_streams(w, 0, false, true, false))) return rc;
-    hipStream_t pm = st, ps = w->pside[0];
-    HIPCHK(hipEventRecord(w->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(ps, w->ev_fork, 0));
+    // one_stream (h2v_rlc_opts.flags & H2V_RLC_ONE_STREAM, or the environment variable of that name = 1 / 0): everything on
+    // the caller's stream, decompression before the combiner - one stream per batch in flight instead of two
+    static const int env_one = []() { const char *e = getenv("H2V_RLC_ONE_STREAM"); return e ? atoi(e) : -1; }();
+    const bool one_stream = env_one >= 0 ? env_one != 0 : one_stream_opt;
+    if (!one_stream && (rc = ws_streams(w, 0, false, true, false))) return rc;
+    hipStream_t pm = st, ps = one_stream ? st : w->pside[0];
+    if (!one_stream) {
+        HIPCHK(hipEventRecord(w->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(ps, w->ev_fork, 0));
+    }
     // phase 1
     HIPCHK(hipEventRecord(ev[0], ps));
     {
@@ -1130,7 +1137,7 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     rc = launch_vm(d, n, w->stride, proofs, off, inst, ci, w->regs, w->scalars, w->status, nullptr, pm);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ev[3], pm));
-    HIPCHK(hipStreamWaitEvent(pm, w->ev_join[0], 0));
+    if (!one_stream) HIPCHK(hipStreamWaitEvent(pm, w->ev_join[0], 0));
     HIPCHK(hipEventRecord(ev[10], pm));
     // the batch check
     RlcArgs ra = {n, p->n_var, p->n_fix, slots, d.pi_point, d.n_terms, d.terms, w->scalars, w->status, w->valid, w->valid_sub, {},
@@ -1205,7 +1212,8 @@ extern "C" int h2v_verify_batch_rlc_device(const h2v_plan *p, const h2v_batch *b
         return run_pipeline(p->d, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, nullptr, false);
     uint32_t seed[8];
     if ((rc = rlc_seed(opts, seed))) return rc;
-    return run_rlc(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, seed);
+    return run_rlc(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, seed,
+                   opts && (opts->flags & H2V_RLC_ONE_STREAM));
 }
 extern "C" int h2v_verify_batch_rlc(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, h2v_workspace *ws, const h2v_rlc_opts *opts,
                                     int *fell_back) {

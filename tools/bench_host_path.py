@@ -40,7 +40,7 @@ def run(steps):
         ws = wss[k % W]
         if k >= W:
             acc, _ = ws.wait(args.batch)          # batch k - W ran on this workspace
-        dp.submit(hb, ws, rlc=rlc, seed=seed)
+        dp.submit(hb, ws, rlc=rlc, seed=seed, one_stream=rlc and W >= 3)
     for k in range(max(0, steps - W), steps):
         acc, _ = wss[k % W].wait(args.batch)
     return acc
