@@ -308,3 +308,16 @@ def test_rlc_infinity_points(be, circuits):
     got, fb = dp.verify_batch_rlc(pb, off, good.instances, None, ws=ws)
     assert list(got) == list(want) and fb
     assert want[3] == 0 and want[7] == 0 and sum(want) >= n - 3
+
+
+def test_rlc_one_stream_form(be):
+    """H2V_RLC_ONE_STREAM (the form for callers with many batches in flight: decompression ahead of the combiner on the
+    caller's stream) is read once per process: the corruption and mixed-batch tests again in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_rlc.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "single_corruptions or mixed_batch or duplicate"],
+                       env={**os.environ, "H2V_RLC_ONE_STREAM": "1"}, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
