@@ -122,8 +122,12 @@ def main():
     # 4 -> 2.74 / 3.31; RLC: 1 -> 5.0 ms, 4 -> 2.04, 5 -> 1.84 (stable over boxes and runs), 6 -> 1.80 OR 3.4-3.9 (bimodal:
     # with twelve streams the runtime sometimes maps two busy ones onto one hardware queue), 7 -> 2.0 (the tail of a batch -
     # bucket reduction, doublings, ONE pairing - is a few waves)
+    # Not every box overlaps streams equally well (one measured 2.2 ms -> 6.5 ms per RLC step with seven in flight where the
+    # others gain 3x), so without --inflight the count is PROBED: a few untimed steps with each candidate, the best one is used
+    # for the timed region and reported (config.steps_in_flight, inflight_probe_ms_per_step).
     small = (args.batch or WORKLOADS[args.workload][1]) <= 1024
-    inflight = args.inflight or (7 if args.mode == "rlc" else 4 if small else 2)
+    inflight_candidates = [args.inflight] if args.inflight else ([7, 5, 3, 1] if args.mode == "rlc" else [4, 2, 1] if small else [2, 1])
+    inflight = inflight_candidates[0]
     if args.msm_tpl:
         os.environ["H2V_MSM_TPL"] = str(args.msm_tpl)
     # several steps in flight use 3 streams each: more hardware queues than the runtime's default of 4, or they serialise
@@ -185,10 +189,16 @@ def main():
         Bmax = int(t.item())
     rlc_seed = bytes((7 * k + 1) & 0xff for k in range(32))   # fixed for the timed steps (reproducible); a service draws it per batch
 
+    stream_pool = []
+
     def timed_run(mode, inflight, steps, warmup, gather):
         """warmup + `steps` timed passes in `mode` with `inflight` steps in flight; returns (elapsed s, workspaces, accept)"""
         wss = [backend.Workspace(dp, B) for _ in range(inflight)]
-        streams = [torch.cuda.Stream(device=dev) for _ in range(inflight)] if inflight > 1 else [None]
+        # (the same few torch streams in every measurement of this process: every stream that was ever created keeps a
+        #  hardware queue busy in the runtime's round-robin, and later measurements would collide with the earlier ones')
+        while len(stream_pool) < inflight:
+            stream_pool.append(torch.cuda.Stream(device=dev))
+        streams = stream_pool[:inflight] if inflight > 1 else [None]
         d_accepts = [torch.zeros(B, dtype=torch.uint8, device=dev) for _ in range(inflight)]
         d_statuses = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(inflight)]
         use_gather = gather and world > 1
@@ -241,7 +251,26 @@ def main():
             gather_state["ok"] = all(bool(last[r][:sizes[r]].all().item()) for r in range(world))
         return el, wss, d_accepts[(steps - 1) % inflight].cpu().numpy()
 
+    def pick_inflight(mode, candidates):
+        """a few untimed steps with each candidate number of steps in flight; returns (best, {candidate: ms per step})"""
+        if len(candidates) == 1:
+            return candidates[0], None
+        seen = {}
+        for cand in candidates:
+            k = args.steps            # as many steps as the timed region: filling and draining the pipeline count the same
+            el_, w_, _a = timed_run(mode, cand, k, min(args.warmup, 3), False)
+            for x in w_:
+                x.close()
+            seen[cand] = round(el_ / k * 1e3, 4)
+        best = min(seen, key=seen.get)
+        if world > 1:   # every rank the same count (the slowest rank's view decides nothing: take rank 0's)
+            t = torch.tensor([best], device=cdev)
+            dist.broadcast(t, src=0)
+            best = int(t.item())
+        return best, seen
+
     gather_state = {"ok": None}
+    inflight, inflight_probe = pick_inflight(args.mode, inflight_candidates)
     elapsed, wss, accept = timed_run(args.mode, inflight, args.steps, args.warmup, True)
 
     # per-kernel device time over the timed steps (HIP events recorded on the kernels' own streams, event rings of the
@@ -310,11 +339,13 @@ def main():
     # config ("G1 MSM + one pairing per proof") names.
     rlc_secondary = None
     if args.mode == "per-proof" and not args.no_rlc_secondary and vk.recursion_vks is None:
-        inflight2 = 7
+        for w_ in wss[1:]:
+            w_.close()
+        inflight2, probe2 = pick_inflight("rlc", [7, 5, 3, 1])
         el2, wss2, acc2 = timed_run("rlc", inflight2, args.steps, args.warmup, False)
         ok2, tm2 = wss2[0].rlc_result()
         rlc_secondary = {"value": round(B_total * args.steps / el2, 2), "unit": "proofs/s", "ms_per_step": round(el2 / args.steps * 1e3, 4),
-                         "steps_in_flight": inflight2, "all_accepted": bool(int(acc2.sum()) == B), "batch_check_passed": ok2,
+                         "steps_in_flight": inflight2, "inflight_probe_ms_per_step": probe2, "all_accepted": bool(int(acc2.sum()) == B), "batch_check_passed": ok2,
                          "bucket_msm_terms": tm2.msm_terms, "k_pip_accumulate_ms": round(tm2.bucket_accumulate_ms, 4),
                          "msm_GBps_algorithmic": round((128 * tm2.msm_terms + 144) / (tm2.bucket_accumulate_ms * 1e-3) / 1e9, 3) if tm2.bucket_accumulate_ms > 0 else None,
                          "note": "python bench.py --mode rlc prints the full line (roofline of the bucket kernel, kernel times)"}
@@ -428,7 +459,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": label, "mode": args.mode, "proofs_per_gpu": B, "proofs_per_step_all_gpus": B_total, "proof_bytes": pl.proof_len,
                        "msm_terms_per_proof": T, "g1_points_per_proof": slots, "public_inputs": pl.n_pi, "plan_instructions": len(pl.instrs),
-                       "steps_in_flight": inflight,
+                       "steps_in_flight": inflight, "inflight_probe_ms_per_step": inflight_probe,
                        "parallelism": ("independent proofs sharded per GPU (%s); accept gather over RCCL" % args.scaling) if world > 1 else "1 GPU"},
             "roofline": roof(dominant),
             "msm_roofline": roof(msm_key),
