@@ -1,4 +1,6 @@
 // Micro-benchmark: issue cost of the integer instructions the field arithmetic is made of (gfx950).
+// build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/ubench/imad.hip -o /tmp/imad && /tmp/imad > profiles/rNN_imad_ubench.txt
+// (bench.py reads the v_mad_u64_u32 line of the 4-waves-per-SIMD section from the newest such file as the integer-issue peak)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
