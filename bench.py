@@ -382,7 +382,7 @@ def main():
             n_terms_r = rlc_shape["msm_terms"]
             W = rlc_shape["windows_per_glv_half"]
             kname = {"transcript_combiner": vm_name, "g1_decompress": dec_name, "rlc_prepare": "k_rlc_prepare", "bucket_sort": "k_pip_digits",
-                     "bucket_accumulate": "k_pip_accumulate", "bucket_reduce": "k_pip_reduce", "pairing": "k_pairing_coop"}
+                     "bucket_accumulate": "k_pip_accumulate", "bucket_reduce": "k_pip_reduce", "pairing": "k_pairing_rlc"}
             bytes_per_launch = {
                 "bucket_accumulate": 128 * n_terms_r + 144,                   # the G1 MSM the metric names: 32 B scalar + 96 B base per term
                 "g1_decompress": B * slots * (48 + 96 + 1),
