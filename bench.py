@@ -112,6 +112,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rlc-secondary", action="store_true", help="per-proof runs: skip the extra measurement of the RLC mode")
     ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--timed-only", action="store_true",
+                    help="launch nothing but warm-up + the timed steps (no in-flight probe, no one-step pass, no RLC secondary, no reject "
+                         "dataset, no CPU baseline): the form profiled under rocprofv3, whose per-kernel averages then cover the same "
+                         "launches as the line's kernel_ms")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -270,6 +274,9 @@ def main():
         return best, seen
 
     gather_state = {"ok": None}
+    if args.timed_only:
+        args.no_cpu_baseline = args.no_rlc_secondary = True
+        inflight_candidates = inflight_candidates[:1]
     inflight, inflight_probe = pick_inflight(args.mode, inflight_candidates)
     elapsed, wss, accept = timed_run(args.mode, inflight, args.steps, args.warmup, True)
 
@@ -315,7 +322,7 @@ def main():
     # with several steps in flight the event-timed kernel durations include what the kernels lose to each other; a short
     # pass with ONE step in flight gives the kernels' own durations beside them
     kernel_ms_alone = None
-    if inflight > 1 and args.mode == "per-proof":
+    if inflight > 1 and args.mode == "per-proof" and not args.timed_only:
         for w_ in wss[1:]:
             w_.close()            # (their event rings have been read; their streams give their hardware queues back)
         _el1, wss1, _acc1 = timed_run("per-proof", 1, 5, 3, False)
@@ -356,7 +363,7 @@ def main():
     # second dataset (untimed): 1 % of the proofs get the reference example's byte flip (examples/simple_mul.rs:87-95,
     # first scalar of the proof) - exactly those proofs must be rejected (rlc: through the per-proof fall-back)
     reject_check = None
-    if rank == 0:
+    if rank == 0 and not args.timed_only:
         rej = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.01, seed=77, kinds=["flip_first_scalar"])
         if args.mode == "rlc":
             got, fell_back = dp.verify_batch_rlc(rej.proofs, rej.proof_off, rej.instances, rej.committed, ws=wss[0])

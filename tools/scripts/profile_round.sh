@@ -4,7 +4,7 @@
 # e.g. tools/scripts/profile_round.sh r02_v24 simple_mul 4096 per-proof
 # writes, under gpurun_out/ (copy the ones to keep into profiles/):
 #   TAG_bench.json                the bench line of the default-length run (CPU baseline included)
-#   TAG_bench_under_rocprof.json  the line of the profiled (shorter) run
+#   TAG_bench_under_rocprof.json  the line of the profiled run (--timed-only: the same launches rocprofv3 averages over)
 #   TAG_kernel_stats.csv          rocprofv3 --kernel-trace --stats of that command
 #   TAG_pmc_summary.txt           mean counters per launch, from separate --pmc passes (tools/pmc_summary.py); the first
 #                                 line records what was profiled - bench.py only attaches traffic from a matching file
@@ -14,7 +14,10 @@ O=gpurun_out
 mkdir -p $O
 timeout -k 10 400 python bench.py $ARGS > $O/b_$TAG.log 2>&1; grep "^{" $O/b_$TAG.log | tail -1 > $O/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py $ARGS --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_$TAG.log 2>&1
+# the profiled command: the steps-in-flight count the run above settled on, and nothing but warm-up + timed steps, so
+# that rocprofv3's per-kernel averages and the line's event-timed kernel_ms cover the same launches
+INF=$(python -c "import json,sys; print(json.load(open('$O/${TAG}_bench.json'))['config']['steps_in_flight'])")
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py $ARGS --steps 20 --warmup 5 --inflight $INF --timed-only > $O/prof_$TAG.log 2>&1
 grep "^{" $O/prof_$TAG.log | tail -1 > $O/${TAG}_bench_under_rocprof.json
 for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
   n=$(echo $c | cut -d" " -f1)
