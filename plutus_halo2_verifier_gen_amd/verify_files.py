@@ -2,7 +2,7 @@
 `serialized_proof.{hex,json}`, `serialized_public_input.hex` and `serialized_committed_input.hex`
 (examples/shared_utils/mod.rs:9-65) and calls the verifier.
 
-  python -m plutus_halo2_verifier_gen_amd.verify_files --vk vk.json [--vk-constants verifier_key.ak]
+  python -m plutus_halo2_verifier_gen_amd.verify_files --vk vk.json [--vk-constants verifier_key.ak] [--kzg-params kzg_params_K]
          --proof serialized_proof.hex [--proof more.hex ...] --public-inputs serialized_public_input.hex
          [--committed serialized_committed_input.hex]
 
@@ -56,6 +56,8 @@ def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--vk", required=True, help="VerifyingKey JSON (vk.py) or a built-in circuit name")
     ap.add_argument("--vk-constants", help="generated verifier_key.ak / VKConstants.hs to take the constants from")
+    ap.add_argument("--kzg-params", help="kzg_params/kzg_params_{k} (src/kzg_params.rs): s_g2 is taken from its tail (wire.parse_kzg_params: "
+                                         "self-validating, layout unpinned) and must agree with the VK constants' when both are given")
     ap.add_argument("--proof", action="append", required=True)
     ap.add_argument("--public-inputs", action="append", required=True)
     ap.add_argument("--committed", action="append", default=[])
@@ -64,6 +66,12 @@ def main(argv=None) -> int:
     vk = load_vk(a.vk)
     if a.vk_constants:
         vk = vk.with_constants(wire.load_vk_constants(a.vk_constants))
+    if a.kzg_params:
+        kp = wire.load_kzg_params(a.kzg_params)
+        if a.vk_constants and kp.s_g2 != vk.s_g2.lower():
+            raise wire.WireError("s_g2 of %s differs from the VK constants'" % a.kzg_params)
+        import dataclasses
+        vk = dataclasses.replace(vk, s_g2=kp.s_g2)
     proofs = [wire.load_proof(p) for p in a.proof]
     pis = [wire.load_public_inputs(p) for p in a.public_inputs]
     cis = [wire.load_committed_inputs(p) for p in a.committed]

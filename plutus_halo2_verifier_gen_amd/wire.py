@@ -14,9 +14,16 @@ Formats (each restated from the reference lines cited; nothing here is on the pe
                       omega^-1, barycentric weight, transcript representation, blinding factors.
 
 The C-ABI takes scalars as 32-byte little-endian and G1 as 48-byte zcash-compressed (include/h2v.h); the loaders
-return those.  The KZG parameter file (`SerdeFormat::RawBytesUnchecked`, src/kzg_params.rs:50-57) is NOT read here:
-its layout is defined inside the un-vendored `midnight-proofs` crate and the reference holds no sample of it, so a
-reader could not be pinned; `s_g2` comes from the VK constants files instead, which carry it in compressed form.
+return those.
+
+* KZG parameters      `kzg_params/kzg_params_{k}` (src/kzg_params.rs:15-18, written with `SerdeFormat::RawBytesUnchecked`,
+                      :50-57 / :61-81).  UNPINNED: the byte layout is defined inside the un-vendored `midnight-proofs`
+                      crate and the reference holds no sample file.  `read_kzg_params` therefore trusts no layout: it
+                      takes the verifier's two elements (g2, s_g2 - `ParamsKZG::verifier_params()`) from the END of the
+                      file, tries the encodings a BLS12-381 G2 element can have there, and accepts one only if the
+                      element before last decodes to the standard G2 generator and the last one to a point of the G2
+                      subgroup.  A file in a layout it does not know is refused, never mis-read.  `s_g2` normally comes
+                      from the VK constants files, which carry it compressed; the two are compared when both are given.
 """
 from __future__ import annotations
 
@@ -331,3 +338,105 @@ def parse_vk_constants(text: str) -> VKConstants:
 def load_vk_constants(path: str) -> VKConstants:
     with open(path) as f:
         return parse_vk_constants(f.read())
+
+
+# ----------------------------------------------------------------------------- KZG parameters (verifier part)
+@dataclass
+class KZGVerifierParams:
+    """What `ParamsKZG::verifier_params()` hands to `Guard::verify` (examples/simple_mul.rs:101-104): s_g2 (and g2)."""
+    k: int                      # the u32 the file starts with (log2 of the number of G1 powers)
+    s_g2: str                   # hex of the 96-byte compressed point - the form vk.py / the VK constants use
+    encoding: str               # which G2 encoding the file's tail was in
+    g1_element_bytes: Optional[int]  # (file length - 4 - the two G2 elements) / (2 * 2^k) if that is a whole number, else None
+
+
+_R384 = 1 << 384
+
+
+def _g2_from_fp_quad(vals):
+    x, y = (vals[0], vals[1]), (vals[2], vals[3])
+    return (x, y)
+
+
+def _g2_tail_decoders():
+    """(name, element size, bytes -> affine point or None).  Every decoder raises ValueError on a malformed element."""
+    def fp_le(b, mont):
+        v = int.from_bytes(b, "little")
+        if v >= P:
+            raise ValueError("coordinate not below p")
+        return v * pow(_R384, -1, P) % P if mont else v
+
+    def raw_affine(mont):
+        def dec(b):
+            return _g2_from_fp_quad([fp_le(b[48 * i:48 * i + 48], mont) for i in range(4)])     # x.c0 x.c1 y.c0 y.c1
+        return dec
+
+    def raw_projective(mont):
+        def dec(b):
+            c = [fp_le(b[48 * i:48 * i + 48], mont) for i in range(6)]                          # X Y Z, each c0 c1
+            z = (c[4], c[5])
+            if z == (0, 0):
+                return None
+            zi = bls.f2_inv(z)
+            return (bls.f2_mul((c[0], c[1]), zi), bls.f2_mul((c[2], c[3]), zi))
+        return dec
+
+    def zcash_uncompressed(b):
+        if b[0] & 0xE0:
+            raise ValueError("flag bits set in an uncompressed element")
+        v = [int.from_bytes(b[48 * i:48 * i + 48], "big") for i in range(4)]                   # x.c1 x.c0 y.c1 y.c0
+        if any(t >= P for t in v):
+            raise ValueError("coordinate not below p")
+        return ((v[1], v[0]), (v[3], v[2]))
+
+    return [("raw affine, Montgomery limbs, little-endian", 192, raw_affine(True)),
+            ("raw affine, canonical, little-endian", 192, raw_affine(False)),
+            ("zcash uncompressed", 192, zcash_uncompressed),
+            ("zcash compressed", 96, lambda b: bls.g2_decompress(bytes(b), check_subgroup=False)),
+            ("raw projective, Montgomery limbs, little-endian", 288, raw_projective(True)),
+            ("raw projective, canonical, little-endian", 288, raw_projective(False))]
+
+
+def parse_kzg_params(blob: bytes) -> KZGVerifierParams:
+    """The verifier's part of a KZG parameter file (see the module docstring: self-validating, layout unpinned)."""
+    blob = bytes(blob)
+    if len(blob) < 4 + 2 * 96:
+        raise WireError("KZG params: file too short")
+    k = int.from_bytes(blob[:4], "little")
+    if not 1 <= k <= 30:
+        raise WireError("KZG params: implausible k = %d in the header" % k)
+    for name, size, dec in _g2_tail_decoders():
+        if len(blob) < 4 + 2 * size:
+            continue
+        try:
+            g2 = dec(blob[-2 * size:-size])
+            if g2 != bls.G2_GEN:
+                continue
+            s_g2 = dec(blob[-size:])
+        except ValueError:
+            continue
+        if s_g2 is None or not bls.g2_is_on_curve(s_g2) or not bls.g2_in_subgroup(s_g2):
+            raise WireError("KZG params (%s): g2 is the generator but s_g2 is not a point of the G2 subgroup" % name)
+        body = len(blob) - 4 - 2 * size
+        per = body // (2 << k) if body % (2 << k) == 0 else None
+        return KZGVerifierParams(k=k, s_g2=bls.g2_compress(s_g2).hex(), encoding=name, g1_element_bytes=per)
+    raise WireError("KZG params: the element before last is not the G2 generator in any known encoding "
+                    "(layout of this file is not one this reader knows; nothing was assumed)")
+
+
+def load_kzg_params(path: str) -> KZGVerifierParams:
+    """Reads only the header and the tail (the G1 powers - 2 x 2^k elements - are the prover's)."""
+    import os
+    size = os.path.getsize(path)
+    with open(path, "rb") as f:
+        head = f.read(4)
+        tail_len = min(size - 4, 2 * 288)
+        f.seek(size - tail_len)
+        tail = f.read(tail_len)
+    # the length-derived field needs the true file length: pad the middle virtually
+    params = parse_kzg_params(head + tail)
+    for _name, sz, _d in _g2_tail_decoders():
+        if _name == params.encoding:
+            body = size - 4 - 2 * sz
+            params.g1_element_bytes = body // (2 << params.k) if body >= 0 and body % (2 << params.k) == 0 else None
+    return params

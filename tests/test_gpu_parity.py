@@ -425,6 +425,21 @@ def test_exported_artefact_files_verify_on_gpu(be, circuits, tmp_path, capsys):
     swapped = [a.replace("pi0", "piX").replace("pi1", "pi0").replace("piX", "pi1") for a in args]
     assert verify_files.main(swapped) == 1
     assert capsys.readouterr().out.count("reject") == 2
+    # s_g2 from a KZG parameter file (src/kzg_params.rs:15-57; wire.parse_kzg_params: self-validating, layout unpinned):
+    # alone it replaces the key's, next to the VK constants it must agree with them
+    def params_file(name, s_pt):
+        enc = lambda pt: b"".join(v.to_bytes(48, "big") for v in (pt[0][1], pt[0][0], pt[1][1], pt[1][0]))
+        (tmp_path / name).write_bytes((4).to_bytes(4, "little") + bytes(2 * 16 * 96) + enc(bls.G2_GEN) + enc(s_pt))
+        return str(tmp_path / name)
+    s_pt = bls.g2_decompress(bytes.fromhex(vk.s_g2))
+    assert verify_files.main(args + ["--kzg-params", params_file("kzg_params_4", s_pt)]) == 0
+    capsys.readouterr()
+    other = params_file("kzg_params_other", bls.g2_mul(bls.G2_GEN, 5))
+    with pytest.raises(wire.WireError, match="differs"):
+        verify_files.main(args + ["--kzg-params", other])
+    no_constants = [a for i, a in enumerate(args) if i not in (2, 3)]
+    assert verify_files.main(no_constants + ["--kzg-params", other]) == 1      # another trapdoor: nothing verifies
+    assert capsys.readouterr().out.count("reject") == 2
 
 
 @pytest.mark.parametrize("name,n", [("lookup_table", 2048), ("atms_with_lookups", 2048), ("sha256", 1024), ("secp256k1", 512),

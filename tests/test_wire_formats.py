@@ -178,3 +178,64 @@ def test_vk_json_schema_and_validator():
     V.validate(far)
     with pytest.raises(V.VKError, match="rotation"):
         V.validate(far, strict_rotations=True)
+
+
+def _kzg_params_file(k, s, encoding, g1_bytes=96):
+    """A parameter file as `ParamsKZG::write_custom` is understood to lay it out (k, 2^k G1 powers, 2^k Lagrange-basis
+    G1 elements, g2, s_g2 - src/kzg_params.rs:61-81 calls it; the layout itself is in the un-vendored crate): the G1 part
+    is filler here (the verifier never reads it), the two G2 elements are real."""
+    R384 = 1 << 384
+
+    def fp_le(v, mont):
+        return ((v * R384) % bls.P if mont else v).to_bytes(48, "little")
+
+    def enc(pt):
+        (x0, x1), (y0, y1) = pt
+        if encoding == "mont":
+            return b"".join(fp_le(v, True) for v in (x0, x1, y0, y1))
+        if encoding == "canon":
+            return b"".join(fp_le(v, False) for v in (x0, x1, y0, y1))
+        if encoding == "zcash":
+            return b"".join(v.to_bytes(48, "big") for v in (x1, x0, y1, y0))
+        if encoding == "compressed":
+            return bls.g2_compress(pt)
+        if encoding == "proj":
+            z = (7, 11)
+            X, Y = bls.f2_mul(pt[0], z), bls.f2_mul(pt[1], z)
+            return b"".join(fp_le(v, True) for v in (X[0], X[1], Y[0], Y[1], z[0], z[1]))
+        raise AssertionError(encoding)
+
+    rng = random.Random(k)
+    body = bytes(rng.getrandbits(8) for _ in range(2 * (1 << k) * g1_bytes))
+    return k.to_bytes(4, "little") + body + enc(bls.G2_GEN) + enc(bls.g2_mul(bls.G2_GEN, s))
+
+
+@pytest.mark.parametrize("encoding", ["mont", "canon", "zcash", "compressed", "proj"])
+def test_kzg_params_reader_is_self_validating(encoding, tmp_path):
+    """src/kzg_params.rs:50-57 reads `kzg_params_{k}` with RawBytesUnchecked; no sample of that layout exists in the
+    reference, so the reader accepts a file only when the element before last IS the G2 generator (UNPINNED format)."""
+    s = 0x1234567890ABCDEF1234567
+    blob = _kzg_params_file(4, s, encoding)
+    want = bls.g2_compress(bls.g2_mul(bls.G2_GEN, s)).hex()
+    got = wire.parse_kzg_params(blob)
+    assert (got.k, got.s_g2) == (4, want)
+    assert got.g1_element_bytes == 96
+    path = tmp_path / "kzg_params_4"
+    path.write_bytes(blob)
+    from_file = wire.load_kzg_params(str(path))
+    assert (from_file.k, from_file.s_g2, from_file.encoding, from_file.g1_element_bytes) == (4, want, got.encoding, 96)
+    # a damaged generator: refused, not mis-read
+    size = {"compressed": 96, "proj": 288}.get(encoding, 192)
+    bad = bytearray(blob)
+    bad[-2 * size + 20] ^= 1
+    with pytest.raises(wire.WireError, match="generator"):
+        wire.parse_kzg_params(bytes(bad))
+    # g2 fine, s_g2 off the curve / out of the subgroup
+    bad = bytearray(blob)
+    bad[-size + 60] ^= 1
+    with pytest.raises(wire.WireError):
+        wire.parse_kzg_params(bytes(bad))
+    with pytest.raises(wire.WireError, match="short"):
+        wire.parse_kzg_params(blob[:100])
+    with pytest.raises(wire.WireError, match="implausible"):
+        wire.parse_kzg_params(b"\xff\xff\xff\xff" + blob[4:])
