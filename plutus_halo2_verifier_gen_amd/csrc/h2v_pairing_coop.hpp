@@ -104,10 +104,10 @@ H2V_DI void coop_load28_pair(uint32_t (&x)[14], uint32_t (&y)[14], const uint32_
 // generated program is checked for this by tools/gen_coop_program.py).  Accumulator headroom: a lane's column sums
 // (terms per lane) x 14 products of (lam_x lam_y) 2^56, tripled for the cyclotomic squaring, plus 14 reduction products:
 // the weighted product count must stay below 2^8.  MUL: 6 x 14 = 84 with carried operands (lam = 1); the doubled operand
-// D = 2a of the squarings is stored UNCARRIED (lam = 2): SQR 4 x 14 x 2 = 112, CSQR 2 x 14 x 2 x 3 = 168.  Staged operands:
+// D = 2a of the squarings is stored UNCARRIED (lam = 2): SQR 4 x 14 x 2 = 112, CSQR 2 x 14 x 2 x 3 = 168 (no CSQR term has two uncarried operands: D and ND2 only meet carried ones).  Staged operands:
 //   A = a (6)   NA = 7p - a_im (7)   B = b (6)   XB = (b0 - b1 + 7p, b0 + b1) (13)   D = 2a (12)   (squarings: see coop_csqr / coop_sqr)
 // Each of the two lanes sharing a coefficient reduces its half of the terms on its own: a half is below
-// (6 * 7 * 13 / 2520 + 1) p = 1.22 p for MUL and (3 * 2 * 7 * 26 / 2520 + 1) p = 1.44 p for the tripled cyclotomic
+// (6 * 7 * 13 / 2520 + 1) p = 1.22 p for MUL and (3 * 2 * 168 / 2520 + 1) p = 1.4 p for the tripled cyclotomic
 // squaring (p / R < 1/2520), so the engine's result (the sum of the two halves) is below 3p.
 
 // out = sum_t X[tab[2t]] * Y[tab[2t+1]]  (mod p), one Montgomery reduction.  NT <= 12 (accumulator headroom).
@@ -182,7 +182,7 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
             r.l[i] = sw[0] + sw[1];
         }
     }
-    // value: two halves < 2 * 1.44 p; four quarters < 4 * (3 * 7 * 26 / 2520 + 1) p = 4.87 p (every operand bound of the
+    // value: two halves < 2 * 1.4 p; four quarters < 4 * (3 * 168 / 2520 + 1) p = 4.8 p (every operand bound of the
     // staging code assumes v <= 6, CONJ and INV v <= 5); limbs back below 2^28
     f28_carry(r);
     return f28_pack(r);
@@ -196,7 +196,8 @@ H2V_DI F28 coop_engine(const Coop &c, const int tab_row_byte) {
 H2V_DI F28 coop_shfl_xor1(const F28 &a) {
     F28 r;
 #pragma unroll
-    for (int i = 0; i < 14; i++) r.l[i] = __shfl_xor(a.l[i], 1);
+    for (int i = 0; i < 14; i++)   // quad_perm [1, 0, 3, 2]: a DPP move at VALU rate (the generic shuffle is an LDS round trip per limb)
+        r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], 0xB1, 0xf, 0xf, false);
     return r;
 }
 // stage a distributed value (v <= 6) as the A operand (a_{k,part}, and -a_{k,1})
@@ -234,28 +235,34 @@ H2V_DI F28 coop_mul(const Coop &c, const F28 &a, const F28 &b) {
     return r;
 }
 // a^2 for a in the cyclotomic subgroup (Granger-Scott; formulas and table: tools/gen_coop_tables.py: csqr_table).
-// Operands: A = a (6), NA = 7p - a_im (7) from the half-0 lanes; from the half-1 lanes D = 2a (12) and, per Fp2
-// coefficient, the sum S = a_re + a_im (12) and the difference M = a_re - a_im + 7p (13) (Re(x^2) = S M is one product
-// instead of two), plus 2 S, 2 M (26) of the last coefficient; and the shared constants +-2/3: the engine returns
+// Operands: A = a (6), NA = 7p - a_im (7), ND2 = 2 NA_2 (14, uncarried) from the half-0 lanes; from the half-1 lanes
+// D = 2a (12, uncarried) and, per Fp2 coefficient, the sum S = a_re + a_im (12) and the difference M = a_re - a_im + 7p
+// (13) (Re(x^2) = S M is one product instead of two); and the shared constants +-2/3: the engine returns
 // 3 (Q_k -/+ (2/3) a_k) = 3 Q_k -/+ 2 a_k already reduced.  Four terms per coefficient, two per lane; a half-sum is
-// below (3 * 2 * 7 * 26 / 2520 + 1) p = 1.44 p.
+// below (3 * 2 * 168 / 2520 + 1) p = 1.4 p (largest product of operand bounds: ND2 x S = 14 x 12).
+// Staging is ONE instruction stream for both half-waves (lanes of a wave that take different branches run them one
+// after the other): both halves hold a and its Fp2 partner, every lane forms 7p - a, the half-0 lanes carry and store
+// that (NA; odd g), the half-1 lanes carry and store partner + (a or 7p - a) (S / M), and the uncarried first store is
+// a << h (A or D).
 H2V_DI F28 coop_csqr(const Coop &c, const F28 &a) {
-    coop_stage_a(c, a);
     const F28 pa = coop_shfl_xor1(a);          // the other part of the same Fp2 coefficient
-    if (c.g < 12 && c.h == 1) {
-        F28 d2, sm, t;
-        f28_mul_small<2>(d2, a);               // (12, 2): stored with limbs below 2^29 - see the headroom note at the engine
-        coop_store28(coop_slot(c, COOP_SLOT_D + c.g), d2);
-        if (c.g & 1) { F28_NEG(t, a, 7, 1); }  // imaginary-part lane: M = re - im = pa + (7p - a)
-        else t = a;                            // real-part lane:      S = re + im = a + pa
-        f28_add(sm, pa, t);
-        f28_carry(sm);                         // S (12, 1) / M (13, 1)
-        coop_store28(coop_slot(c, COOP_SLOT_SM + c.g), sm);
-        if (c.g >= 10) {                       // 2 S_5 -> DS5, 2 M_5 -> DM5
-            F28 ds;
-            f28_mul_small<2>(ds, sm);
-            f28_carry(ds);
-            coop_store28(coop_slot(c, COOP_SLOT_DS5 + (c.g - 10)), ds);
+    const bool odd = (c.g & 1) != 0, hi = c.h != 0;
+    F28 neg, v, u;
+    F28_NEG(neg, a, 7, 1);                     // 7p - a                                   (7, 3)
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint32_t t = odd ? neg.l[i] : a.l[i];      // imaginary-part lane: M = re - im = pa + (7p - a); real: S = a + pa
+        v.l[i] = hi ? pa.l[i] + t : neg.l[i];
+        u.l[i] = a.l[i] << c.h;                // A = a (6, 1) | D = 2a (12, 2): limbs below 2^29 - see the headroom note at the engine
+    }
+    f28_carry(v);                              // NA (7, 1) | S (12, 1) / M (13, 1)
+    if (c.g < 12) {
+        coop_store28(coop_slot(c, hi ? COOP_SLOT_D + c.g : COOP_SLOT_A + c.g), u);
+        if (hi || odd) coop_store28(coop_slot(c, hi ? COOP_SLOT_SM + c.g : COOP_SLOT_NA + (c.g >> 1)), v);
+        if (!hi && c.g == 5) {                 // ND2 = 2 NA_2 = -2 a_21                    (14, 2)
+            F28 nd;
+            f28_mul_small<2>(nd, v);
+            coop_store28(coop_slot(c, COOP_SLOT_ND2), nd);
         }
     }
     __syncthreads();

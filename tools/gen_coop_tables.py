@@ -49,11 +49,10 @@ N_SQR_TERMS = 8
 SLOT_XD = SLOT_XB
 # cyclotomic squaring reuses the B area for the doubled operand D = 2*g (12 slots; products with -2*g_k1 are taken as
 # (-g_k1) * (2*g)), the XB area for the sums / differences S_k = g_k0 + g_k1, M_k = g_k0 - g_k1 (S_k at SM + 2k, M_k at
-# SM + 2k + 1) and two slots of the XA area for 2 S_5, 2 M_5
+# SM + 2k + 1) and one slot of the XA area for ND2 = -2 g_21 (the one doubled NEGATIVE the xi-odd coefficient needs)
 SLOT_D = SLOT_B
 SLOT_SM = SLOT_XB
-SLOT_DS5 = SLOT_XA
-SLOT_DM5 = SLOT_XA + 1
+SLOT_ND2 = SLOT_XA
 
 
 def mul_table():
@@ -189,7 +188,7 @@ def csqr_table():
     two) and D = 2g every Fp coefficient is at most THREE products (xi = 1 + u: xi z = (z0 - z1, z0 + z1)):
          even, real:  S_a M_a + S_b M_b - g_b1 D_b0          imaginary:  g_a0 D_a1 + S_b M_b + g_b0 D_b1
          odd,  real:  g_a0 D_b0 - g_a1 D_b1                  imaginary:  g_a0 D_b1 + g_a1 D_b0
-         xi-odd, real: g_a0 (2 M_b) - g_a1 (2 S_b)           imaginary:  g_a0 (2 S_b) + g_a1 (2 M_b)
+         xi-odd, real: D_a0 M_b + (-2 g_a1) S_b              imaginary:  D_a0 S_b + D_a1 M_b
     The engine computes Q'_k = Q_k -/+ (2/3) g_k (minus for even k; the last term of every lane, against the shared
     constants +-2/3) with its column accumulators tripled before the Montgomery reduction, so h_k = 3 Q'_k leaves the
     engine reduced and no additive post-processing is left to the lane: 4 terms per coefficient, 2 per lane."""
@@ -215,12 +214,12 @@ def csqr_table():
                     terms = [(A(a, 0), D(b, 0)), (NA(a), D(b, 1))]
                 else:
                     terms = [(A(a, 0), D(b, 1)), (A(a, 1), D(b, 0))]
-            else:               # 2 xi a b, b = g5: the doubled sum / difference of g5 sit in DS5 / DM5
-                assert b == 5
+            else:               # 2 xi a b = (2a) (xi b), a = g2: the doubling rides on a (D, and ND2 = -2 g_21 = 2 NA_2)
+                assert a == 2
                 if part == 0:
-                    terms = [(A(a, 0), SLOT_DM5), (NA(a), SLOT_DS5)]
+                    terms = [(D(a, 0), M(b)), (SLOT_ND2, S(b))]
                 else:
-                    terms = [(A(a, 0), SLOT_DS5), (A(a, 1), SLOT_DM5)]
+                    terms = [(D(a, 0), S(b)), (D(a, 1), M(b))]
         if g < 12:
             assert len(terms) <= N_CSQR_TERMS - 1
             terms.append((A(g >> 1, g & 1), SLOT_C23N if (g >> 1) % 2 == 0 else SLOT_C23P))
@@ -237,7 +236,7 @@ def stage_csqr(g):
         s[SLOT_NA + k] = (-g[k][1]) % P
         s[SLOT_D + 2 * k], s[SLOT_D + 2 * k + 1] = 2 * g[k][0] % P, 2 * g[k][1] % P
         s[SLOT_SM + 2 * k], s[SLOT_SM + 2 * k + 1] = (g[k][0] + g[k][1]) % P, (g[k][0] - g[k][1]) % P
-    s[SLOT_DS5], s[SLOT_DM5] = 2 * (g[5][0] + g[5][1]) % P, 2 * (g[5][0] - g[5][1]) % P
+    s[SLOT_ND2] = (-2 * g[2][1]) % P
     return s
 
 
@@ -337,7 +336,7 @@ def emit():
          "#pragma once", "#include <stdint.h>"]
     for name in ("SLOT_A", "SLOT_NA", "SLOT_B", "SLOT_XB", "SLOT_T1", "SLOT_T2", "SLOT_PX1", "SLOT_PY1", "SLOT_PX2",
                  "SLOT_PY2", "SLOT_ZERO", "N_GROUP_SLOTS", "SLOT_LN1", "SLOT_LN2", "N_SHARED_SLOTS", "N_MUL_TERMS",
-                 "N_LINE_TERMS", "N_CSQR_TERMS", "SLOT_D", "SLOT_SM", "SLOT_DS5", "SLOT_DM5", "SLOT_C23P", "SLOT_C23N", "SLOT_XA", "SLOT_XD",
+                 "N_LINE_TERMS", "N_CSQR_TERMS", "SLOT_D", "SLOT_SM", "SLOT_ND2", "SLOT_C23P", "SLOT_C23N", "SLOT_XA", "SLOT_XD",
                  "N_SQR_TERMS"):
         o.append("#define COOP_%s %d" % (name, globals()[name]))
     o.append("#define COOP_SHARED_BASE %d" % SH)
