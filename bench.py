@@ -232,7 +232,7 @@ def main():
                 if ctx is not None:
                     ctx.__exit__(None, None, None)
 
-        for k in range(warmup):
+        for k in range(max(warmup, inflight)):   # untimed; at least one step on every workspace (their first use allocates)
             step(k)
         if world > 1:
             dist.barrier()
