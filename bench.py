@@ -130,7 +130,7 @@ def main():
     # others gain 3x), so without --inflight the count is PROBED: a few untimed steps with each candidate, the best one is used
     # for the timed region and reported (config.steps_in_flight, inflight_probe_ms_per_step).
     small = (args.batch or WORKLOADS[args.workload][1]) <= 1024
-    inflight_candidates = [args.inflight] if args.inflight else ([7, 5, 3, 1] if args.mode == "rlc" else [4, 2, 1] if small else [2, 1])
+    inflight_candidates = [args.inflight] if args.inflight else ([11, 7, 5, 3, 1] if args.mode == "rlc" else [4, 2, 1] if small else [3, 2, 1])
     inflight = inflight_candidates[0]
     if args.msm_tpl:
         os.environ["H2V_MSM_TPL"] = str(args.msm_tpl)
@@ -348,7 +348,7 @@ def main():
     if args.mode == "per-proof" and not args.no_rlc_secondary and vk.recursion_vks is None:
         for w_ in wss[1:]:
             w_.close()
-        inflight2, probe2 = pick_inflight("rlc", [7, 5, 3, 1])
+        inflight2, probe2 = pick_inflight("rlc", [11, 7, 5, 3, 1])
         el2, wss2, acc2 = timed_run("rlc", inflight2, args.steps, args.warmup, False)
         ok2, tm2 = wss2[0].rlc_result()
         rlc_secondary = {"value": round(B_total * args.steps / el2, 2), "unit": "proofs/s", "ms_per_step": round(el2 / args.steps * 1e3, 4),
