@@ -408,8 +408,10 @@ def main():
             }
             msm_key = "bucket_accumulate"
         else:
-            tpl = msm_lpt - 4 if msm_lpt in (6, 8) else 1     # several terms per lane (H2V_MSM_TPL): shared doublings
-            kname = {"g1_msm": "k_g1_msm_multi%d" % tpl if tpl > 1 else "k_g1_msm_fixed" if msm_lpt == 3 else "k_g1_msm_merged" if msm_lpt == 1 else "k_g1_msm", "g1_decompress": dec_name,
+            tpl = msm_lpt - 16 if msm_lpt in (18, 20) else 1     # several terms per lane (H2V_MSM_TPL): shared doublings
+            quad = msm_lpt if msm_lpt == 8 else 0                # a quad per GLV half (small launches of few terms)
+            kname = {"g1_msm": "k_g1_msm_multi%d" % tpl if tpl > 1 else "k_g1_msm_fixed" if msm_lpt == 3 else "k_g1_msm_merged" if msm_lpt == 1
+                               else "k_g1_msm_quad" if quad == 8 else "k_g1_msm", "g1_decompress": dec_name,
                      "transcript_combiner": vm_name, "pairing": "k_pairing_coop" if os.environ.get("H2V_PAIRING") != "legacy" else "k_pairing_check"}
             bytes_per_launch = {
                 "g1_msm": B * (128 * T + 144),
@@ -420,12 +422,13 @@ def main():
             # per MSM lane: 32 windows of 4 doublings + one mixed addition per GLV half the lane carries (tables are built
             # ahead); the launcher reports whether a term ran on two lanes (one half each) or on one (both halves)
             msm_fixed = msm_lpt == 3   # fixed-base mode: VK-base terms cost 65 mixed additions and no doubling
-            lpt = 1 if (msm_fixed or tpl > 1) else msm_lpt
+            lpt = 1 if (msm_fixed or tpl > 1) else 2 if quad == 8 else msm_lpt
             msm_halves = 2 // lpt
             msm_lane = 128 * MAD_DBL + (32 * msm_halves - 1) * MAD_MADD
             mads = {
                 "g1_msm": (B * (T - n_fix_terms) * msm_lane + B * n_fix_terms * 65 * MAD_MADD + B * (T - 1) * MAD_ADD + B * 3 * MAD_MUL) if msm_fixed
                           else (B * -(-T // tpl) * 128 * MAD_DBL + B * T * 66 * MAD_MADD + B * (-(-T // tpl) - 1) * MAD_ADD + B * 3 * MAD_MUL) if tpl > 1
+                          else (B * T * 8 * 33 * 18 * MAD_MUL + B * (lpt * T - 1) * MAD_ADD + B * 3 * MAD_MUL) if quad  # every lane of a quad runs each level's multiplication
                           else B * T * lpt * msm_lane + B * (lpt * T - 1) * MAD_ADD + B * 3 * MAD_MUL,
                 "pairing": B * 32 * pairing_lane,
                 "g1_decompress": B * slots * (377 * MAD_SQR + 86 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD + tab_point),

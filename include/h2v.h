@@ -63,7 +63,8 @@ typedef struct {
  * g1_decompress_ms is the longer of the decompression kernel's two concurrent launches (square roots + window tables
  * on one stream, subgroup tests on another).  msm_lanes_per_term is the shape the MSM launcher chose for the call:
  * 2 = one lane per GLV half, 1 = both halves on one lane (shared doublings), 3 = ladders for the per-proof terms beside a
- * fixed-base launch for the VK bases. */
+ * fixed-base launch for the VK bases, 8 = a quad of lanes per GLV half (small launches of few terms: the four lanes share
+ * the multiplications of every doubling and addition), 18 / 20 = two / four terms per lane (H2V_MSM_TPL). */
 typedef struct {
     float transcript_combiner_ms, g1_decompress_ms, g1_msm_ms, pairing_ms, total_ms;
     uint32_t launches;
@@ -164,6 +165,11 @@ int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_t *scalars,
  * (encodings that do not decompress count as infinity); out 96 B affine BE (all-zero = infinity) */
 int h2v_probe_g1_msm_pippenger(int device, uint32_t n, const uint8_t *scalars, const uint8_t *bases_compressed,
                                uint8_t *out_xy_be);
+/* 2P + (neg ? -Q : Q) by the one-lane mixed addition and by the quad-cooperative one (the forced MSM shape H2V_MSM_LPT=8):
+ * pq = x_P, y_P, x_Q, y_Q as 12 canonical LE dwords each; out = 5 x 42 dwords of lazily reduced limbs (X, Y, Z; 14 limbs of
+ * 28 bits each, Montgomery form R = 2^392): the one-lane result, then lanes 0..3 of a quad.  Guards a compiler issue
+ * (csrc/h2v_curve28.hpp: g1j28_madd_quad). */
+int h2v_probe_quad_madd(int device, const uint32_t *pq, int neg, uint32_t *out);
 /* e(p1, s_g2 of plan) == e(p2, G2) for n pairs of compressed G1 points; out[i] = 1/0 */
 int h2v_probe_pairing(const h2v_plan *plan, uint32_t n, const uint8_t *p1_compressed, const uint8_t *p2_compressed,
                       uint8_t *out);

@@ -63,7 +63,7 @@ EXPORTS = [
     "h2v_workspace_timings",
     "h2v_verify_batch", "h2v_verify_batch_submit", "h2v_verify_batch_wait", "h2v_verify_batch_device", "h2v_verify_batch_rlc", "h2v_verify_batch_rlc_device",
     "h2v_workspace_rlc_result", "h2v_probe_g1_msm_pippenger", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
-    "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_pairing", "h2v_probe_pairing_ex",
+    "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_quad_madd", "h2v_probe_pairing", "h2v_probe_pairing_ex",
     "h2v_last_error", "h2v_build_id",
     "h2v_device_count",
 ]
@@ -320,6 +320,21 @@ def probe_g1_msm(scalar_groups, base_groups, device: int = 0):
     out = C.create_string_buffer(96 * n)
     check(lib().h2v_probe_g1_msm(device, n, T, sc, bs, out))
     return [_unxy(out.raw[96 * i:96 * i + 96]) for i in range(n)]
+
+
+def probe_quad_madd(p_xy, q_xy, neg: bool, device: int = 0):
+    """2P + (-)Q as Jacobian (X, Y, Z) integers: [one-lane result, quad lane 0, 1, 2, 3] (h2v_probe_quad_madd)."""
+    def limbs(v):
+        return [(v >> (32 * i)) & 0xffffffff for i in range(12)]
+    pq = (C.c_uint32 * 48)(*(limbs(p_xy[0]) + limbs(p_xy[1]) + limbs(q_xy[0]) + limbs(q_xy[1])))
+    out = (C.c_uint32 * 210)()
+    check(lib().h2v_probe_quad_madd(device, pq, 1 if neg else 0, out))
+    from . import bls12_381 as bls
+    rinv = pow(1 << 392, -1, bls.P)
+
+    def val(o):
+        return sum(out[o + k] << (28 * k) for k in range(14)) * rinv % bls.P
+    return [(val(42 * j), val(42 * j + 14), val(42 * j + 28)) for j in range(5)]
 
 
 def probe_g1_msm_pippenger(scalars, bases_compressed, device: int = 0):

@@ -521,13 +521,22 @@ static void msm_try_shape(MsmShape &best, uint32_t lpt, uint32_t lpp, double cha
         if (cost < best.cost) { best.cost = cost; best.lpt = lpt; best.bs = cand; best.waves = waves; }
     }
 }
-static MsmShape msm_ladder_shape(uint32_t n_terms, uint32_t n, double other_waves) {
+static MsmShape msm_ladder_shape(uint32_t n_terms, uint32_t n, double other_waves, bool quad_ok = false) {
     static const int env_lpt = []() { const char *e = getenv("H2V_MSM_LPT"); return e ? atoi(e) : 0; }();
     static const uint32_t env_bs = []() { const char *e = getenv("H2V_MSM_BS"); return e ? (uint32_t)atoi(e) : 0u; }();
     MsmShape best = {2, 512, 1e300, 0};
     for (uint32_t cl = 2; cl >= 1; cl--) {
         if (env_lpt && (uint32_t)env_lpt != cl) continue;
         msm_try_shape(best, cl, cl * n_terms, cl == 2 ? 1250.0 : 1600.0, n, other_waves, env_bs);
+    }
+    // a quad per GLV half (h2v_kernels.hip: msm_body, LPT = 8)
+    // Only on request (H2V_MSM_LPT=8): alone it shortens a T = 16 launch of 64-512 proofs from 1.35 to 1.17-1.27 ms, but it issues
+    // four times the instructions, and with four steps in flight - how small batches are run for throughput - the step got
+    // slower at 64 and 512 proofs (1.30 -> 1.40, 1.66 -> 1.90 ms) and faster only at 256 (1.57 -> 1.47).
+    if (quad_ok && 8 * n_terms <= 512 && env_lpt == 8) {
+        MsmShape q = {8, 512, 1e300, 0};
+        msm_try_shape(q, 8, 8 * n_terms, 1080.0, n, other_waves, env_bs);
+        if (q.cost < 1e300) best = q;
     }
     if (best.cost == 1e300) {   // forced shape that does not fit: fall back to the widest block
         const uint32_t pb = 512 / (2 * n_terms) ? 512 / (2 * n_terms) : 1;
@@ -544,7 +553,8 @@ static uint32_t launch_msm_ladders(const H2vDevPlan &d, const H2vMsmArgs &ma, ui
         const uint32_t cg = (uint32_t)(msm_n_simd() / 4.0), blocks_c = blocks < cg ? blocks : cg;
         if (sh.lpt == 1) hipLaunchKernelGGL(k_g1_msm_merged_cond, dim3(blocks_c), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
         else hipLaunchKernelGGL(k_g1_msm_cond, dim3(blocks_c), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
-    } else if (sh.lpt == 1) hipLaunchKernelGGL(k_g1_msm_merged, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+    } else if (sh.lpt == 8) hipLaunchKernelGGL(k_g1_msm_quad, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+    else if (sh.lpt == 1) hipLaunchKernelGGL(k_g1_msm_merged, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
     else hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
     return sh.lpt;
 }
@@ -562,9 +572,9 @@ static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint
         const uint32_t per_block = bs / lpp, blocks = (n + per_block - 1) / per_block;
         if (tpl == 2) hipLaunchKernelGGL(k_g1_msm_multi2, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
         else hipLaunchKernelGGL(k_g1_msm_multi4, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
-        return 4 + (uint32_t)tpl;   // reported as msm_lanes_per_term: 6 / 8 = two / four terms per lane
+        return 16 + (uint32_t)tpl;   // reported as msm_lanes_per_term: 18 / 20 = two / four terms per lane
     }
-    return launch_msm_ladders(d, ma, n, msm_ladder_shape(ma.n_terms, n, 0.0), scalars, pts, tabws, st);
+    return launch_msm_ladders(d, ma, n, msm_ladder_shape(ma.n_terms, n, 0.0, ma.pt_tab != nullptr && !ma.skip), scalars, pts, tabws, st);
 }
 // Fixed-base split of the plan's own MSM (non-recursive plans, tables present): the per-proof terms [0, n_var) as ladders
 // and, beside them on another stream, the VK-base terms as one lane per term that walks the all-window table of its base
@@ -749,7 +759,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         const IvcBufs ib = {d.ivc ? w->accl + (size_t)lo * 36 : nullptr, d.ivc ? w->accr + (size_t)lo * 36 : nullptr,
                             d.ivc ? w->fold_pts + (size_t)lo * 96 : nullptr, d.ivc ? w->fold_scal + (size_t)lo * 32 : nullptr,
                             d.ivc ? w->el2 + (size_t)lo * 36 : nullptr, d.ivc ? w->er2 + (size_t)lo * 36 : nullptr};
-        const MsmShape single = msm_ladder_shape(d.ivc ? d.n_terms : d.n_main_terms, m, 0.0);
+        const MsmShape single = msm_ladder_shape(d.ivc ? d.n_terms : d.n_main_terms, m, 0.0, true);
         const MsmSplit split = w->er_fix ? msm_split_shape(d, m, single) : MsmSplit{false, {}, {}, 0};
         if (split.on) {
             // per-proof terms as ladders on the main stream; the VK-base terms beside them on the side stream (free since
@@ -1313,6 +1323,18 @@ extern "C" int h2v_probe_field(int device, int op, uint32_t n, const uint32_t *a
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return H2V_OK;
+}
+extern "C" int h2v_probe_quad_madd(int device, const uint32_t *pq /* 48 dwords */, int neg, uint32_t *out /* 210 dwords */) {
+    int rc = pick_device(device);
+    if (rc) return rc;
+    DevBuf din, dout;
+    if (din.alloc(48 * 4) || dout.alloc(210 * 4)) return fail(H2V_E_DEVICE, "hipMalloc failed");
+    HIPCHK(hipMemcpy(din.p, pq, 48 * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_quad_madd, dim3(1), dim3(64), 0, nullptr, din.as<uint32_t>(), neg, dout.as<uint32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dout.p, 210 * 4, hipMemcpyDeviceToHost));
     return H2V_OK;
 }
 extern "C" int h2v_probe_blake2b(int device, uint32_t n, uint32_t len, const uint8_t *msgs, uint8_t *digests) {

@@ -136,6 +136,108 @@ H2V_DI void g1j28_madd_ladder_t(G1J28 &r, const G1J28 &p, const F28 &qx, const F
 H2V_DI void g1j28_madd_ladder(G1J28 &r, const G1J28 &p, const F28 &qx, const F28 &qy_in, const bool neg_q) {
     g1j28_madd_ladder_t<false>(r, p, qx, qy_in, neg_q);
 }
+template <int LANE>
+H2V_DI F28 f28_bcast(const F28 &a) {   // lane LANE (0..3) of every quad in all four lanes of the quad: one DPP move per limb
+    F28 r;
+    constexpr int ctrl = LANE | (LANE << 2) | (LANE << 4) | (LANE << 6);   // quad_perm: [LANE, LANE, LANE, LANE]
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], ctrl, 0xf, 0xf, false);
+        asm volatile("" : "+v"(r.l[i]));   // keep the move a move: see the note at g1j28_madd_quad
+    }
+    return r;
+}
+// QUAD-COOPERATIVE POINT ARITHMETIC.  The four lanes of a hardware quad (lane & 3) hold the same point and run the
+// independent field multiplications of a formula side by side, one each; values cross lanes with quad-broadcast DPP
+// moves (VALU rate).  Every lane of a quad must take the same path (the callers' control flow is uniform per quad).
+//
+// n doublings of the point lane 0 of each quad holds, spread over its lanes 0..2 (the result is valid in all four).  dbl-2009-l has 7 multiplications but depth 3:
+//     level 1   lane 0: A = X^2        lane 1: B = Y^2        lane 2: Y Z
+//     level 2   lane 0: (3A)^2         lane 1: C = B^2        lane 2: (X + B)^2
+//     level 3   E (D - X3)             (operands are wave-uniform by then: every lane computes it)
+// Users: the window weights 2^(c w) of k_pip_reduce (a chain of up to 120 doublings on an otherwise idle wave: 0.9 ms on
+// one lane) and the four-lanes-per-half shape of the per-proof MSM (msm_body<8>).  Values cross lanes with quad-broadcast DPP moves.  Bounds: those of g1j28_dbl_t, line by line.
+H2V_DN void g1j28_dbl_n_coop3(G1J28 &p, const uint32_t n) {
+    const int l = threadIdx.x & 3;
+    F28 X = f28_bcast<0>(p.x), Y = f28_bcast<0>(p.y), Z = f28_bcast<0>(p.z);
+#pragma unroll 1
+    for (uint32_t k = 0; k < n; k++) {
+        F28 a, b, r1, r2, e3, xb, o2;
+#pragma unroll
+        for (int i = 0; i < 14; i++) { a.l[i] = l == 0 ? X.l[i] : Y.l[i]; b.l[i] = l == 0 ? X.l[i] : (l == 1 ? Y.l[i] : Z.l[i]); }
+        f28_mul_inl(r1, a, b);                            // A | B | Y Z                       (2, 1)
+        const F28 B = f28_bcast<1>(r1);
+        f28_mul_small<3>(e3, r1);                         // lane 0: E = 3A                    (6, 3)
+        f28_add(xb, X, B);                                // X + B                             (v_X + 2, 2)
+#pragma unroll
+        for (int i = 0; i < 14; i++) o2.l[i] = l == 0 ? e3.l[i] : (l == 1 ? B.l[i] : xb.l[i]);
+        f28_mul_inl(r2, o2, o2);                          // E^2 | C = B^2 | (X + B)^2         (2, 1)
+        const F28 A = f28_bcast<0>(r1), YZ = f28_bcast<2>(r1), E2 = f28_bcast<0>(r2), T = f28_bcast<2>(r2);
+        F28 C = f28_bcast<1>(r2), D, t, E, X3, Y3;
+        f28_add(D, A, C);                                 //                                   (4, 2)
+        F28_SUB(t, T, D, 5, 2);                           // (X+B)^2 - A - C                   (7, 5)
+        f28_mul_small<2>(D, t); f28_carry(D);             // D                                 (14, 1)
+        f28_mul_small<3>(E, A);                           // E = 3A                            (6, 3)
+        f28_mul_small<2>(t, D);                           // 2D                                (28, 2)
+        F28_SUB(X3, E2, t, 29, 2); f28_carry(X3);         // X3 = E^2 - 2D                     (31, 1)
+        F28_SUB(t, D, X3, 32, 1);                         // D - X3                            (46, 4)
+        f28_mul_inl(Y3, E, t);                            // E (D - X3)                        (2, 1)
+        f28_mul_small<8>(C, C);                           // 8C                                (16, 8)
+        F28_SUB(Y3, Y3, C, 17, 8); f28_carry(Y3);         // Y3                                (19, 1)
+        f28_mul_small<2>(Z, YZ);                          // Z3 = 2 Y Z                        (4, 2)
+        X = X3; Y = Y3;
+    }
+    p.x = X; p.y = Y; p.z = Z;
+}
+
+// Mixed addition p += (neg_q ? -q : q), q affine, for the quad: the 11 multiplications of g1j28_madd_ladder_t in 6 levels
+//     level 1   Z1^2                                       (every lane)
+//     level 2   lane 0: U2 = x2 Z1^2        lane 1: Z1^3
+//     level 3   lane 0: S2 = y2 Z1^3        lane 1: Z3 = Z1 H        lane 2: HH = H^2
+//     level 4   lane 0: HHH = H HH          lane 1: V = X1 HH        lane 2: R^2
+//     level 5   lane 0: R (V - X3)          lane 1: Y1 HHH
+// Same caller guarantee (p != +-q, both finite), same bounds line by line: in: stored-point bounds, out: X (10,1) Y (5,1) Z (2,1).
+// (Compiler note, ROCm 7.2: with the broadcasts left to the optimiser it folds them into the consuming subtraction -
+// `v_subrev_u32_dpp vN, vN, vM quad_perm:[1,1,1,1]`, destination = permuted source - and Y3 came out wrong in lane 0 of
+// every quad, right in lanes 1..3 (h2v_probe_quad_madd; tests/test_gpu_parity.py); f28_bcast therefore pins its result with an empty asm.)
+H2V_DN void g1j28_madd_quad(G1J28 &p, const F28 &qx, const F28 &qy_in, const bool neg_q) {
+    const int l = threadIdx.x & 3;
+    const F28 X1 = p.x, Y1 = p.y, Z1 = p.z;
+    F28 a, x, y, r, qy = qy_in;
+    {
+        F28 nq;
+        F28_NEG(nq, qy, 3, 1);                            // -Y2                              (3, 3)
+        if (neg_q) qy = nq;
+    }
+    f28_sqr_inl(a, Z1);                                   // Z1^2                             (2, 1)
+#pragma unroll
+    for (int i = 0; i < 14; i++) x.l[i] = l == 1 ? Z1.l[i] : qx.l[i];
+    f28_mul_inl(r, x, a);                                 // U2 | Z1^3                        (2, 1)
+    const F28 U2 = f28_bcast<0>(r), Z1c = f28_bcast<1>(r);
+    F28 H, R, t;
+    F28_SUB(H, U2, X1, 32, 1);                            // H = U2 - X1                      (34, 4)
+#pragma unroll
+    for (int i = 0; i < 14; i++) { x.l[i] = l == 0 ? qy.l[i] : (l == 1 ? Z1.l[i] : H.l[i]); y.l[i] = l == 0 ? Z1c.l[i] : H.l[i]; }
+    f28_mul_inl(r, x, y);                                 // S2 | Z3 | HH                     (2, 1)
+    const F28 S2 = f28_bcast<0>(r), Z3 = f28_bcast<1>(r), HH = f28_bcast<2>(r);
+    F28_SUB(R, S2, Y1, 21, 1);                            // R = S2 - Y1                      (23, 4)
+#pragma unroll
+    for (int i = 0; i < 14; i++) { x.l[i] = l == 0 ? H.l[i] : (l == 1 ? X1.l[i] : R.l[i]); y.l[i] = l == 2 ? R.l[i] : HH.l[i]; }
+    f28_mul_inl(r, x, y);                                 // HHH | V | R^2                    (2, 1)
+    const F28 HHH = f28_bcast<0>(r), V = f28_bcast<1>(r), RR = f28_bcast<2>(r);
+    F28 X3, Y3;
+    F28_SUB(X3, RR, HHH, 3, 1);                           // R^2 - HHH                        (5, 4)
+    f28_mul_small<2>(t, V);                               // 2V                               (4, 2)
+    F28_SUB(X3, X3, t, 5, 2); f28_carry(X3);              // X3                               (10, 1)
+    F28_SUB(t, V, X3, 11, 1);                             // V - X3                           (13, 4)
+#pragma unroll
+    for (int i = 0; i < 14; i++) { x.l[i] = l == 0 ? R.l[i] : Y1.l[i]; y.l[i] = l == 0 ? t.l[i] : HHH.l[i]; }
+    f28_mul_inl(r, x, y);                                 // R (V - X3) | Y1 HHH              (2, 1)
+    const F28 c = f28_bcast<0>(r), yh = f28_bcast<1>(r);
+    F28_SUB(Y3, c, yh, 3, 1); f28_carry(Y3);              // Y3                               (5, 1)
+    p.x = X3; p.y = Y3; p.z = Z3;
+}
+
 // Brings n <= 8 finite Jacobian points to affine with ONE inversion (Montgomery's trick); x and y come out carried
 // with v <= 2.  ax / ay may alias nothing in `pts`.
 // (inlined: the arrays stay the caller's own stack objects, addressed with scratch instructions)

@@ -611,7 +611,16 @@ struct H2vMsmArgs {
 // A proof owns exactly LPT * n_terms consecutive lanes of a block (no power-of-two padding: 34 terms used to occupy
 // 128 lanes); the block holds as many whole proofs as fit, the rest of its lanes idle.
 //
-// LPT = lanes per term.  2: one lane per GLV half (shortest chain: 128 doublings + 33 additions per lane).
+// LPT = lanes per term.  2: one lane per GLV half (128 doublings + 33 additions per lane).
+// 8: a QUAD per GLV half (h2v_curve28.hpp: quad-cooperative arithmetic): the four lanes hold the same accumulator and
+// share the multiplications of every doubling (depth 3 instead of 7) and addition (6 instead of 11): 33 x (4 x 3 + 6) =
+// 594 multiplications deep instead of 1287, on four times the lanes - for launches that leave most SIMDs idle anyway.
+// Measured, it buys far less than the depth suggests: T = 16 x 64 proofs 1.35 -> 1.17 ms; T = 58 (464 lanes per proof: a
+// 512-thread block, two waves per SIMD) 1.35 -> 1.69 ms; a quad per TERM (both halves, 780 deep, 256-thread blocks) 1.45-1.51
+// ms, slower than two plain lanes per term.  A lone wave is bound by the latency of its dependent multiply-adds, and the one-lane
+// formulas already overlap their independent multiplications (A = X^2, B = Y^2, ...) inside the lane; a level of the quad
+// schedule is exactly one multiplication between two barriers (select, multiply, broadcast).  Kept as a forced shape
+// (H2V_MSM_LPT=8, parity-tested), never chosen by the launcher: see msm_ladder_shape.
 // 1: one lane runs both halves of its term on ONE accumulator, so the 128 doublings are shared (128 doublings + 66
 // additions per lane, 36 % less work per proof, half the waves).  Measured on MI355X one wave per SIMD of this code
 // already reaches 85 % of what two deliver (2048 proofs: 1.54 ms, 4096: 2.60 ms with LPT = 2), so whenever the batch
@@ -628,13 +637,16 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
                      uint32_t *red /* Jacobian partial sums, dword d of thread t at red[d*blockDim.x + t] */,
                      const uint32_t bid /* logical block: blockIdx.x, or the loop index of a conditional launch */) {
     static_assert(!FIX || LPT == 1, "fixed-base mode runs merged ladders");
-    constexpr int NH = 2 / LPT;   // GLV halves per lane
+    static_assert(LPT == 1 || LPT == 2 || LPT == 8, "one lane per term, one per GLV half, or a quad per GLV half");
+    constexpr bool QUAD = LPT >= 4;                 // four lanes share one accumulator
+    constexpr bool SPLIT = LPT == 2 || LPT == 8;    // one GLV half per lane (or quad); otherwise both halves on one accumulator
+    constexpr int NH = SPLIT ? 1 : 2;               // GLV halves per accumulator
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
     const uint32_t lanes_per_proof = FIX ? ma.n_fixl : LPT * ma.n_terms;
     const uint32_t seg = tid / lanes_per_proof;       // which of the block's proofs
     const uint32_t sub = tid - seg * lanes_per_proof; // position inside the proof's segment
     const bool fix_lane = FIX;   // a fixed-base launch has no ladder lanes (a wave mixing the two kinds would run them one after the other)
-    const uint32_t term = FIX ? 0u : (LPT == 2 ? sub >> 1 : sub), half = LPT == 2 ? sub & 1 : 0;
+    const uint32_t term = FIX ? 0u : (LPT == 8 ? sub >> 3 : LPT == 2 ? sub >> 1 : sub), half = LPT == 8 ? (sub >> 2) & 1 : LPT == 2 ? sub & 1 : 0;
     const uint32_t i = bid * per_block + seg;
     const bool active = seg < per_block && i < n;
     // this lane's group: position and length of its reduction segment inside the proof's lanes
@@ -717,7 +729,7 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
         for (int k = 0; k < 8; k++) s[k] = sp[k];
         glv_split(k1, k2, s);
         uint32_t any = 0;
-        if (LPT == 2) {
+        if (SPLIT) {
 #pragma unroll
             for (int k = 0; k < 4; k++) any |= half ? k2[k] : k1[k];
         } else {
@@ -731,7 +743,7 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
             for (int h = 0; h < NH; h++) {
                 uint32_t kk[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) kk[k] = (LPT == 2 ? half != 0 : h != 0) ? k2[k] : k1[k];
+                for (int k = 0; k < 4; k++) kk[k] = (SPLIT ? half != 0 : h != 0) ? k2[k] : k1[k];
                 uint32_t carry = 0;
 #pragma unroll 1
                 for (int q = 0; q < 32; q++) {
@@ -750,7 +762,7 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
             const uint32_t *tab;   // of this lane's first half
             if (ma.pt_tab) {
                 tab = (is_vk ? ma.vk_tab + (size_t)idx * 448 : ma.pt_tab + ((size_t)i * slots + idx) * 448) + half * 224;
-            } else if (LPT == 2) {
+            } else if (SPLIT) {   // (the quad shapes are only launched with prebuilt tables)
                 uint32_t *mine = tabws + (((size_t)i * ma.n_terms + term) * 2 + half) * 224;
                 if (half) {  // phi(P)
                     Fp beta;
@@ -778,8 +790,11 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
 #pragma unroll 1
             for (int q = 32; q >= 0; q--) {
                 if (q != 32 && !lad_inf) {
+                    if (QUAD) g1j28_dbl_n_coop3(lad, 4);   // the quad's lanes share the multiplications of a doubling: depth 3 instead of 7
+                    else {
 #pragma unroll 1
-                    for (int rep = 0; rep < 4; rep++) g1j28_dbl_t<true>(lad, lad);   // multiplier inlined: no argument marshalling
+                        for (int rep = 0; rep < 4; rep++) g1j28_dbl_t<true>(lad, lad);   // multiplier inlined: no argument marshalling
+                    }
                 }
 #pragma unroll 1
                 for (int h = 0; h < NH; h++) {
@@ -795,7 +810,9 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
                         if (d < 0) { F28_NEG(lad.y, qy, 3, 1); f28_carry(lad.y); }
                         f28_set_one(lad.z);
                         lad_inf = false;
-                    } else if (LPT == 2 || q >= 2) {
+                    } else if (QUAD && (SPLIT || q >= 2)) {
+                        g1j28_madd_quad(lad, qx, qy, d < 0);                     // never exceptional (above); depth 6 instead of 11
+                    } else if (SPLIT || q >= 2) {
                         g1j28_madd_ladder_t<MADD_INL>(lad, lad, qx, qy, d < 0);   // never an exceptional case (above)
                     } else {
                         G1J28 o;
@@ -807,6 +824,7 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
             }
         }
     }
+    if (QUAD && (sub & 3) != 0) lad_inf = true;   // the quad's four lanes hold the same sum: its first lane carries it
     // segmented reduction over the lanes of each (proof, group), still on the lazy field: 42 limbs + the flag per lane
     // in LDS (dword d of thread t at red[d*bs + t]); only the lane that ends up with a group's sum converts it back
 #define MSM_RED_STORE()                                                                     \
@@ -854,6 +872,12 @@ k_g1_msm(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proof
          const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];
     msm_body<2, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red, blockIdx.x);
+}
+extern "C" __global__ void __launch_bounds__(512, 2)
+k_g1_msm_quad(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
+              const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
+    extern __shared__ uint32_t red[];
+    msm_body<8, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red, blockIdx.x);
 }
 extern "C" __global__ void __launch_bounds__(512, 2)
 k_g1_msm_merged(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /* proofs per block */,
@@ -1334,6 +1358,29 @@ extern "C" __global__ void k_probe_field(int op, uint32_t n, const uint32_t *__r
 #pragma unroll
         for (int k = 0; k < 8; k++) out[(size_t)i * 8 + k] = r.v[k];
     }
+}
+// dev probe: 2P + (neg ? -Q : Q) by the one-lane mixed addition and by the quad-cooperative one (P, Q affine canonical limbs);
+// out: 5 x 42 dwords of raw lazily reduced limbs: the one-lane result, then the quad's lanes 0..3
+extern "C" __global__ void __launch_bounds__(64)
+k_probe_quad_madd(const uint32_t *__restrict__ pq, int neg, uint32_t *__restrict__ out) {
+    G1A P, Q;
+#pragma unroll
+    for (int k = 0; k < 12; k++) { P.x.v[k] = pq[k]; P.y.v[k] = pq[12 + k]; Q.x.v[k] = pq[24 + k]; Q.y.v[k] = pq[36 + k]; }
+    fp_to_mont(P.x, P.x); fp_to_mont(P.y, P.y); fp_to_mont(Q.x, Q.x); fp_to_mont(Q.y, Q.y);
+    G1J28 p1, p2, a, b;
+    g1j28_from_affine(p1, P);
+    g1j28_dbl(p2, p1);
+    F28 qx, qy;
+    f28_from_fp(qx, Q.x);
+    f28_from_fp(qy, Q.y);
+    g1j28_madd_ladder(a, p2, qx, qy, neg != 0);
+    b = p2;
+    g1j28_madd_quad(b, qx, qy, neg != 0);
+    const int l = threadIdx.x;
+    if (l == 0)
+        for (int k = 0; k < 14; k++) { out[k] = a.x.l[k]; out[14 + k] = a.y.l[k]; out[28 + k] = a.z.l[k]; }
+    if (l < 4)
+        for (int k = 0; k < 14; k++) { out[42 * (1 + l) + k] = b.x.l[k]; out[42 * (1 + l) + 14 + k] = b.y.l[k]; out[42 * (1 + l) + 28 + k] = b.z.l[k]; }
 }
 // blake2b-256 of n messages of `len` bytes each through the LDS transcript path (one message per lane)
 extern "C" __global__ void __launch_bounds__(64)

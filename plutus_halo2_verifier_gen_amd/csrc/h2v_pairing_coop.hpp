@@ -197,7 +197,10 @@ H2V_DI F28 coop_shfl_xor1(const F28 &a) {
     F28 r;
 #pragma unroll
     for (int i = 0; i < 14; i++)   // quad_perm [1, 0, 3, 2]: a DPP move at VALU rate (the generic shuffle is an LDS round trip per limb)
+    {
         r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], 0xB1, 0xf, 0xf, false);
+        asm volatile("" : "+v"(r.l[i]));   // keep the move a move: folded into the consuming add / sub (v_subrev_u32_dpp vN, vN, vM) the
+    }                                      // quad-cooperative mixed addition of h2v_curve28.hpp came out wrong in lane 0 (ROCm 7.2)
     return r;
 }
 // stage a distributed value (v <= 6) as the A operand (a_{k,part}, and -a_{k,1})

@@ -311,53 +311,7 @@ k_pip_accumulate(PipArgs2 a2) {
     }
 }
 
-template <int LANE>
-H2V_DI F28 f28_bcast(const F28 &a) {   // lane LANE (0..3) of every quad in all four lanes of the quad: one DPP move per limb
-    F28 r;
-    constexpr int ctrl = LANE | (LANE << 2) | (LANE << 4) | (LANE << 6);   // quad_perm: [LANE, LANE, LANE, LANE]
-#pragma unroll
-    for (int i = 0; i < 14; i++) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], ctrl, 0xf, 0xf, false);
-    return r;
-}
-// n doublings of the point lane 0 of the calling wave holds, spread over lanes 0..2 (every lane of the wave must call;
-// the result is valid in lanes 0..3).  dbl-2009-l has 7 multiplications but depth 3:
-//     level 1   lane 0: A = X^2        lane 1: B = Y^2        lane 2: Y Z
-//     level 2   lane 0: (3A)^2         lane 1: C = B^2        lane 2: (X + B)^2
-//     level 3   E (D - X3)             (operands are wave-uniform by then: every lane computes it)
-// and the window weights 2^(c w) of k_pip_reduce are a chain of up to 120 doublings on an otherwise idle wave: 0.9 ms on
-// one lane.  Values cross lanes with quad-broadcast DPP moves.  Bounds: those of g1j28_dbl_t, line by line.
-H2V_DN void g1j28_dbl_n_coop3(G1J28 &p, const uint32_t n) {
-    const int l = threadIdx.x & 63;
-    F28 X = f28_bcast<0>(p.x), Y = f28_bcast<0>(p.y), Z = f28_bcast<0>(p.z);
-#pragma unroll 1
-    for (uint32_t k = 0; k < n; k++) {
-        F28 a, b, r1, r2, e3, xb, o2;
-#pragma unroll
-        for (int i = 0; i < 14; i++) { a.l[i] = l == 0 ? X.l[i] : Y.l[i]; b.l[i] = l == 0 ? X.l[i] : (l == 1 ? Y.l[i] : Z.l[i]); }
-        f28_mul_inl(r1, a, b);                            // A | B | Y Z                       (2, 1)
-        const F28 B = f28_bcast<1>(r1);
-        f28_mul_small<3>(e3, r1);                         // lane 0: E = 3A                    (6, 3)
-        f28_add(xb, X, B);                                // X + B                             (v_X + 2, 2)
-#pragma unroll
-        for (int i = 0; i < 14; i++) o2.l[i] = l == 0 ? e3.l[i] : (l == 1 ? B.l[i] : xb.l[i]);
-        f28_mul_inl(r2, o2, o2);                          // E^2 | C = B^2 | (X + B)^2         (2, 1)
-        const F28 A = f28_bcast<0>(r1), YZ = f28_bcast<2>(r1), E2 = f28_bcast<0>(r2), T = f28_bcast<2>(r2);
-        F28 C = f28_bcast<1>(r2), D, t, E, X3, Y3;
-        f28_add(D, A, C);                                 //                                   (4, 2)
-        F28_SUB(t, T, D, 5, 2);                           // (X+B)^2 - A - C                   (7, 5)
-        f28_mul_small<2>(D, t); f28_carry(D);             // D                                 (14, 1)
-        f28_mul_small<3>(E, A);                           // E = 3A                            (6, 3)
-        f28_mul_small<2>(t, D);                           // 2D                                (28, 2)
-        F28_SUB(X3, E2, t, 29, 2); f28_carry(X3);         // X3 = E^2 - 2D                     (31, 1)
-        F28_SUB(t, D, X3, 32, 1);                         // D - X3                            (46, 4)
-        f28_mul_inl(Y3, E, t);                            // E (D - X3)                        (2, 1)
-        f28_mul_small<8>(C, C);                           // 8C                                (16, 8)
-        F28_SUB(Y3, Y3, C, 17, 8); f28_carry(Y3);         // Y3                                (19, 1)
-        f28_mul_small<2>(Z, YZ);                          // Z3 = 2 Y Z                        (4, 2)
-        X = X3; Y = Y3;
-    }
-    p.x = X; p.y = Y; p.z = Z;
-}
+// (f28_bcast, g1j28_dbl_n_coop3: h2v_curve28.hpp - the per-proof MSM's small-launch shape uses them too)
 
 // One block per window w, NB of its threads at work.  Thread t owns bucket j = t + 1 and computes
 //   suffix scan  S_t = sum_{u >= t} B_u   (Hillis-Steele, log2 NB rounds)      and      T = sum_t S_t = sum_j j B_j

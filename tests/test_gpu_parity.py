@@ -127,6 +127,21 @@ def test_g1_msm(be, orc):
             assert r == orc.g1_msm(ss, ps)
 
 
+def test_quad_cooperative_addition_in_every_lane(be):
+    """The quad-cooperative mixed addition (forced MSM shape H2V_MSM_LPT=8) against the one-lane one and the big-integer
+    model, in EVERY lane of the quad: with its DPP broadcasts left to the optimiser, lane 0 alone came out wrong
+    (csrc/h2v_curve28.hpp: g1j28_madd_quad) - a result only lanes 1..3 would have hidden."""
+    rng = random.Random(23)
+    for neg in (False, True):
+        P = bls.g1_mul(bls.G1_GEN, rng.randrange(1, R))
+        Q = bls.g1_mul(bls.G1_GEN, rng.randrange(1, R))
+        res = be.probe_quad_madd(P, Q, neg)
+        want = bls.g1_add(bls.g1_mul(P, 2), bls.g1_neg(Q) if neg else Q)
+        for X, Y, Z in res:
+            zi = pow(Z, -1, bls.P)
+            assert (X * zi * zi % bls.P, Y * zi * zi * zi % bls.P) == want
+
+
 def test_pairing(be, orc, circuits):
     vk, td, pl, dp, ov = circuits["simple_mul"]
     rng = random.Random(5)
@@ -518,7 +533,7 @@ def test_alternate_pipeline_modes(be, env, tmp_path):
     assert r.returncode == 0 and "modes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("lpt", ["1", "2", "tpl2", "tpl4"])
+@pytest.mark.parametrize("lpt", ["1", "2", "8", "tpl2", "tpl4"])
 def test_g1_msm_forced_shape(be, lpt):
     """test_g1_msm (edge scalars, equal / opposite / infinity bases, T = 1 .. 64) again with the MSM shape forced: the
     probe's small batches would otherwise always take two lanes per term.  tpl2 / tpl4: several terms per lane on one
