@@ -130,7 +130,7 @@ def main():
     # others gain 3x), so without --inflight the count is PROBED: a few untimed steps with each candidate, the best one is used
     # for the timed region and reported (config.steps_in_flight, inflight_probe_ms_per_step).
     small = (args.batch or WORKLOADS[args.workload][1]) <= 1024
-    inflight_candidates = [args.inflight] if args.inflight else ([11, 7, 5, 3, 1] if args.mode == "rlc" else [4, 2, 1] if small else [3, 2, 1])
+    inflight_candidates = [args.inflight] if args.inflight else ([11, 7, 5, 3, 1] if args.mode == "rlc" else [4, 2, 1] if small else [5, 3, 2, 1])
     inflight = inflight_candidates[0]
     if args.msm_tpl:
         os.environ["H2V_MSM_TPL"] = str(args.msm_tpl)
@@ -198,6 +198,8 @@ def main():
     def timed_run(mode, inflight, steps, warmup, gather):
         """warmup + `steps` timed passes in `mode` with `inflight` steps in flight; returns (elapsed s, workspaces, accept)"""
         wss = [backend.Workspace(dp, B) for _ in range(inflight)]
+        for w_ in wss:
+            w_.hint_in_flight(inflight)     # (from 4 up the library prefers launch shapes that issue fewer instructions)
         # (the same few torch streams in every measurement of this process: every stream that was ever created keeps a
         #  hardware queue busy in the runtime's round-robin, and later measurements would collide with the earlier ones')
         while len(stream_pool) < inflight:

@@ -85,6 +85,10 @@ int h2v_plan_info(const h2v_plan *plan, uint32_t *proof_len, uint32_t *n_public_
  * (they never write past a buffer).  One workspace serves one call at a time. */
 int h2v_workspace_create(const h2v_plan *plan, uint64_t max_batch, h2v_workspace **out);
 void h2v_workspace_free(h2v_workspace *ws);
+/* (new) Tuning hint: the caller keeps n_in_flight batches in flight on this device (each on its own workspace).  From 4 up
+ * the launcher prefers shapes that issue fewer instructions over shapes with shorter dependent chains (per-proof MSM: two
+ * terms per lane on one accumulator).  Results do not depend on it.  Default 1. */
+int h2v_workspace_hint_in_flight(h2v_workspace *ws, uint32_t n_in_flight);
 /* Per-kernel device times of a past call that used `ws` (calls_back = 0: the most recent; up to 63 back), from HIP
  * events recorded on the streams the kernels ran on.  Synchronise the launch stream before asking. */
 int h2v_workspace_timings(h2v_workspace *ws, uint32_t calls_back, h2v_timings *out);

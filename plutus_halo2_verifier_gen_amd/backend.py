@@ -60,7 +60,7 @@ def _rlc_opts(seed, one_stream: bool = False):
 
 EXPORTS = [
     "h2v_plan_load", "h2v_plan_free", "h2v_plan_info", "h2v_workspace_create", "h2v_workspace_free",
-    "h2v_workspace_timings",
+    "h2v_workspace_timings", "h2v_workspace_hint_in_flight",
     "h2v_verify_batch", "h2v_verify_batch_submit", "h2v_verify_batch_wait", "h2v_verify_batch_device", "h2v_verify_batch_rlc", "h2v_verify_batch_rlc_device",
     "h2v_workspace_rlc_result", "h2v_probe_g1_msm_pippenger", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
     "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_quad_madd", "h2v_probe_pairing", "h2v_probe_pairing_ex",
@@ -248,6 +248,10 @@ class Workspace:
         tm = Timings()
         check(lib().h2v_workspace_timings(self._h, calls_back, C.byref(tm)))
         return tm
+
+    def hint_in_flight(self, n: int) -> None:
+        """h2v_workspace_hint_in_flight: the caller keeps n batches in flight (a tuning hint; results do not depend on it)."""
+        check(lib().h2v_workspace_hint_in_flight(self._h, C.c_uint32(n)))
 
     def wait(self, n: int):
         """h2v_verify_batch_wait for the batch submitted on this workspace: (accept bytes, fell_back)."""

@@ -127,6 +127,25 @@ def test_g1_msm(be, orc):
             assert r == orc.g1_msm(ss, ps)
 
 
+def test_in_flight_hint_changes_the_shape_not_the_verdicts(be, circuits):
+    """h2v_workspace_hint_in_flight(>= 4): the per-proof MSM runs two terms per lane (k_g1_msm_multi2, reported as 18) -
+    the accept vector and the statuses stay those of the default shape."""
+    from plutus_halo2_verifier_gen_amd import synth
+    for name in ("simple_mul", "lookup_table"):
+        vk, td, pl, dp, ov = circuits[name]
+        batch = synth.forge_batch(vk, td, 96, seed=61, plan=pl, workers=2)
+        batch = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.3, seed=62, kinds=list(synth.CORRUPTIONS))
+        ws1, ws5 = be.Workspace(dp, 96), be.Workspace(dp, 96)
+        ws5.hint_in_flight(5)
+        a1 = dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws1)
+        a5 = dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws5)
+        assert list(a1) == list(a5) == batch.expected
+        assert ws1.timings().msm_lanes_per_term in (1, 2, 3) and ws5.timings().msm_lanes_per_term in (18, 3)
+        with pytest.raises(be.H2VError):
+            ws5.hint_in_flight(0)
+        ws1.close(); ws5.close()
+
+
 def test_quad_cooperative_addition_in_every_lane(be):
     """The quad-cooperative mixed addition (forced MSM shape H2V_MSM_LPT=8) against the one-lane one and the big-integer
     model, in EVERY lane of the quad: with its DPP broadcasts left to the optimiser, lane 0 alone came out wrong
