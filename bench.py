@@ -303,15 +303,16 @@ def main():
                          "max_entries_per_lane": tm.max_chain}
         kernel_ms = {k: v / k_steps for k, v in acc.items()}
         batch_latency_ms = span / k_steps
-        launches, msm_lpt = 1, 0
+        launches, msm_lpt, pair_lanes = 1, 0, 64
     else:
         acc = {"transcript_combiner": 0.0, "g1_decompress": 0.0, "g1_msm": 0.0, "pairing": 0.0}
-        launches, msm_lpt, span = 1, 2, 0.0
+        launches, msm_lpt, span, pair_lanes = 1, 2, 0.0, 32
         for j in range(k_steps):
             slot = (args.steps - 1 - j) % inflight
             tm = wss[slot].timings(j // inflight)
             launches = max(1, tm.launches)
             msm_lpt = tm.msm_lanes_per_term or 2
+            pair_lanes = tm.pairing_lanes_per_proof or 32
             acc["transcript_combiner"] += tm.transcript_combiner_ms
             acc["g1_decompress"] += tm.g1_decompress_ms
             acc["g1_msm"] += tm.g1_msm_ms
@@ -414,7 +415,11 @@ def main():
             quad = msm_lpt if msm_lpt == 8 else 0                # a quad per GLV half (small launches of few terms)
             kname = {"g1_msm": "k_g1_msm_multi%d" % tpl if tpl > 1 else "k_g1_msm_fixed" if msm_lpt == 3 else "k_g1_msm_merged" if msm_lpt == 1
                                else "k_g1_msm_quad" if quad == 8 else "k_g1_msm", "g1_decompress": dec_name,
-                     "transcript_combiner": vm_name, "pairing": "k_pairing_coop" if os.environ.get("H2V_PAIRING") != "legacy" else "k_pairing_check"}
+                     "transcript_combiner": vm_name,
+                     "pairing": {16: "k_pairing_coop_narrow", 64: "k_pairing_coop_wide", 1: "k_pairing_check"}.get(pair_lanes, "k_pairing_coop")}
+            # lanes per coefficient 1 / 2 / 4 (narrow / normal / wide engine): a lane multiplies 1/nq of a coefficient's terms and reduces once
+            nq = {16: 1, 64: 4}.get(pair_lanes, 2)
+            pairing_lane = sum(calls * ((terms // nq) * 196 + 196) for calls, terms in ((35, 12), (63, 8), (315, 4), (136, 6)))
             bytes_per_launch = {
                 "g1_msm": B * (128 * T + 144),
                 "g1_decompress": B * slots * (48 + 96 + 1),
@@ -432,7 +437,7 @@ def main():
                           else (B * -(-T // tpl) * 128 * MAD_DBL + B * T * 66 * MAD_MADD + B * (-(-T // tpl) - 1) * MAD_ADD + B * 3 * MAD_MUL) if tpl > 1
                           else (B * T * 8 * 33 * 18 * MAD_MUL + B * (lpt * T - 1) * MAD_ADD + B * 3 * MAD_MUL) if quad  # every lane of a quad runs each level's multiplication
                           else B * T * lpt * msm_lane + B * (lpt * T - 1) * MAD_ADD + B * 3 * MAD_MUL,
-                "pairing": B * 32 * pairing_lane,
+                "pairing": B * (1 if pair_lanes == 1 else pair_lanes) * pairing_lane,
                 "g1_decompress": B * slots * (377 * MAD_SQR + 86 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD + tab_point),
                 "transcript_combiner": B * sum(128 for ins in pl.instrs if ins[0] == PL.OP_MUL),
             }
@@ -484,7 +489,7 @@ def main():
                                   "achieved": round(sum(mads.values()) / (elapsed / args.steps) / 1e12, 3), "peak": round(IMAD_PEAK_TOPS, 2) if IMAD_PEAK_TOPS else None,
                                   "unit": "T lane-mad/s", "frac": round(sum(mads.values()) / (elapsed / args.steps) / 1e12 / IMAD_PEAK_TOPS, 4) if IMAD_PEAK_TOPS else None},
             "batch_latency_ms": round(batch_latency_ms, 4),
-            "pipelines_per_step": launches, "msm_lanes_per_term": msm_lpt,
+            "pipelines_per_step": launches, "msm_lanes_per_term": msm_lpt, "pairing_lanes_per_proof": pair_lanes if args.mode == "per-proof" else None,
             "all_accepted": ok_all,
             "gathered_accept_vectors_all_ones": gather_state["ok"],
             "reject_dataset": reject_check,

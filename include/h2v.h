@@ -69,6 +69,8 @@ typedef struct {
     float transcript_combiner_ms, g1_decompress_ms, g1_msm_ms, pairing_ms, total_ms;
     uint32_t launches;
     uint32_t msm_lanes_per_term;
+    uint32_t pairing_lanes_per_proof;   /* 32: two proofs per wave; 64: the wide engine (small launches); 16: the narrow one (four
+                                         * proofs per wave: fewest instructions, for full chips); 1: the one-lane cross-check kernel */
 } h2v_timings;
 
 /* ---- plan (VerifyingKey) lifecycle -------------------------------------------------------------------------
@@ -177,7 +179,8 @@ int h2v_probe_quad_madd(int device, const uint32_t *pq, int neg, uint32_t *out);
 /* e(p1, s_g2 of plan) == e(p2, G2) for n pairs of compressed G1 points; out[i] = 1/0 */
 int h2v_probe_pairing(const h2v_plan *plan, uint32_t n, const uint8_t *p1_compressed, const uint8_t *p2_compressed,
                       uint8_t *out);
-/* same with an explicit kernel (impl 0: one lane per proof, 1: cooperative, 32 lanes per proof, -1: default) and an
+/* same with an explicit kernel (impl 0: one lane per proof, 1: cooperative - 32 lanes per proof, or the wide engine for small n,
+ * as the launcher picks -, 2 / 3: its narrow (16 lanes per proof) / wide (64) engine whatever n, -1: default) and an
  * optional dump (n * 24 * 48 bytes): the 12 Fp coefficients (flat order w^k, re/im; canonical LE) of f after the
  * Miller loop and, for the cooperative kernel, after the final exponentiation */
 int h2v_probe_pairing_ex(const h2v_plan *plan, uint32_t n, const uint8_t *p1_compressed, const uint8_t *p2_compressed,

@@ -27,7 +27,7 @@ class Batch(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("transcript_combiner_ms", C.c_float), ("g1_decompress_ms", C.c_float), ("g1_msm_ms", C.c_float),
                 ("pairing_ms", C.c_float), ("total_ms", C.c_float), ("launches", C.c_uint32),
-                ("msm_lanes_per_term", C.c_uint32)]
+                ("msm_lanes_per_term", C.c_uint32), ("pairing_lanes_per_proof", C.c_uint32)]
 
 
 class RlcOpts(C.Structure):

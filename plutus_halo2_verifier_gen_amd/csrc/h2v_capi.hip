@@ -89,7 +89,7 @@ struct h2v_workspace {
     // [7]/[8] around the decompression kernel's subgroup half (third stream)
     static constexpr int RING = 64, NEV = 9;
     hipEvent_t ring[RING][MAXP][NEV] = {};
-    uint8_t ring_pipes[RING] = {}, ring_split[RING] = {}, ring_lpt[RING] = {};
+    uint8_t ring_pipes[RING] = {}, ring_split[RING] = {}, ring_lpt[RING] = {}, ring_pair[RING] = {};
     uint64_t calls = 0;
     struct RlcWs *rlc = nullptr;   // buffers of the RLC batch mode, created by its first call
 };
@@ -637,21 +637,36 @@ static void launch_ivc_fold(const H2vDevPlan &d, uint32_t n, const uint32_t *pts
 }
 // Pairing kernel selection: the cooperative 16-lanes-per-proof kernel is the product path; the one-lane-per-proof
 // kernel stays as a cross-check (H2V_PAIRING=legacy, or impl = 0 in the probe).
-static void launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
-                                const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st, const uint32_t *skip = nullptr) {
+static uint32_t launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
+                                const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st, const uint32_t *skip = nullptr,
+                                bool prefer_narrow = false) {
     // The WIDE engine (one proof per wave, four lanes per coefficient: 3 / 2 / 1 terms per lane and call instead of 6 / 4 / 2)
     // when even one wave per proof leaves SIMDs free: n <= #SIMDs.  Above that the two-proofs-per-wave kernel does less
     // total work.  H2V_PAIRING_WIDE = 0 / 1 forces the choice; the conditional (RLC fall-back) launch is never wide.
     static const int env_wide = []() { const char *e = getenv("H2V_PAIRING_WIDE"); return e ? atoi(e) : -1; }();
-    const bool wide = !skip && (env_wide >= 0 ? env_wide != 0 : (double)n <= msm_n_simd());
-    if (impl == 0) hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
-    else if (wide) hipLaunchKernelGGL(k_pairing_coop_wide, dim3(n), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
-    else hipLaunchKernelGGL(k_pairing_coop, dim3((n + 1) / 2), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, skip);
+    static const int env_narrow = []() { const char *e = getenv("H2V_PAIRING_NARROW"); return e ? atoi(e) : -1; }();
+    // impl 2 / 3 (probe): the narrow / the wide kernel whatever n
+    const bool wide = !skip && impl != 2 && (impl == 3 || (env_wide >= 0 ? env_wide != 0 : (double)n <= msm_n_simd()));
+    const bool narrow = !skip && !wide && (impl == 2 || env_narrow > 0 || (env_narrow < 0 && prefer_narrow));
+    if (impl == 0) { hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg); return 1; }
+    else if (wide) hipLaunchKernelGGL(k_pairing_coop_wide, dim3(n), dim3(64), COOP_LDS_BYTES(1), st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
+    else if (narrow) hipLaunchKernelGGL(k_pairing_coop_narrow, dim3((n + 3) / 4), dim3(64), COOP_LDS_BYTES(COOP_GROUPS_NARROW), st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
+    else hipLaunchKernelGGL(k_pairing_coop, dim3((n + 1) / 2), dim3(64), COOP_LDS_BYTES(COOP_GROUPS_PER_WAVE), st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, skip);
+    return wide ? 64u : narrow ? 16u : 32u;
 }
-static void launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
-                           const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st) {
+// The NARROW engine (four proofs per wave, one lane per coefficient: 21 % fewer instructions per pairing, twice the chain).
+// Measured (simple_mul, pairing kernel alone / step with five batches in flight):
+//   n = 1536: normal 1.94 ms / 2.32 ms, narrow 2.60 / 2.40      n = 2048: 1.96 / 2.71, 2.61 / 2.64
+//   n = 3072: 2.99 / 3.71, 2.63 / 3.46     n = 4096: 3.00 / 4.81, 2.66 / 4.50     n = 8192: 5.65 / 9.59, 6.59 / 8.91
+// (a narrow block needs 22.5 KB of LDS: seven per CU, so its second wave per SIMD does not fit everywhere).  Rule: a caller
+// that keeps the chip full (hint >= 4) takes it from 2 * #SIMDs proofs up; one step at a time takes it exactly where the
+// normal kernel needs a second wave per SIMD and the narrow one does not.  H2V_PAIRING_NARROW = 0 / 1 forces the choice.
+static uint32_t launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
+                           const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st, uint32_t in_flight_hint = 1) {
     static const int impl = []() { const char *e = getenv("H2V_PAIRING"); return (e && strcmp(e, "legacy") == 0) ? 0 : 1; }();
-    launch_pairing_impl(impl, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, st);
+    const double S = msm_n_simd();
+    const bool prefer_narrow = in_flight_hint >= 4 ? (double)n >= 2.0 * S : ((double)n > 2.0 * S && (double)n <= 4.0 * S);
+    return launch_pairing_impl(impl, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, st, nullptr, prefer_narrow);
 }
 
 // ---------------------------------------------------------------------------------------------- pipeline
@@ -795,7 +810,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
             er_in = ib.er2; el_in = ib.el2;
         }
         HIPCHK(hipEventRecord(ev[5], pm));
-        launch_pairing(d, m, pts_k, valid_k, vsub_k, er_in, el_in, status_k, accept_k, nullptr, pm);
+        w->ring_pair[slot] = (uint8_t)launch_pairing(d, m, pts_k, valid_k, vsub_k, er_in, el_in, status_k, accept_k, nullptr, pm, w->in_flight_hint);
         HIPCHK(hipEventRecord(ev[6], pm));
         HIPCHK(hipEventRecord(w->ev_done[k], pm));
         HIPCHK(hipStreamWaitEvent(st, w->ev_done[k], 0));
@@ -845,6 +860,7 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
     memset(tm, 0, sizeof *tm);
     tm->launches = (uint32_t)pipes;
     tm->msm_lanes_per_term = w->ring_lpt[slot];
+    tm->pairing_lanes_per_proof = w->ring_pair[slot];
     float first_start = 0, last_end = 0;
     for (int k = 0; k < pipes; k++) {
         hipEvent_t *ev = w->ring[slot][k];
@@ -1181,7 +1197,7 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     uint8_t *valid1 = (uint8_t *)(r->misc + 26), *acc1 = (uint8_t *)(r->misc + 27);
     HIPCHK(hipMemsetAsync(r->misc + 24, 0, 8, pm));            // status of the batch check, skip flag
     HIPCHK(hipMemsetAsync(valid1, 1, 1, pm));
-    hipLaunchKernelGGL(k_pairing_rlc, dim3(1), dim3(64), 0, pm, d1, r->misc, valid1, r->sums, r->sums + 36, st1, acc1, n, r->good, accept, skip);
+    hipLaunchKernelGGL(k_pairing_rlc, dim3(1), dim3(64), COOP_LDS_BYTES(1), pm, d1, r->misc, valid1, r->sums, r->sums + 36, st1, acc1, n, r->good, accept, skip);
     HIPCHK(hipEventRecord(ev[9], pm));
     // fall-back, skipped on the device when the batch check passed: window tables, per-proof MSM, per-proof pairing - small
     // grids that walk their logical blocks, so that finding out that they are not needed costs a few microseconds each
@@ -1197,7 +1213,7 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     }
     {
         const uint32_t nb = (n + 1) / 2, grid = nb < 4 * cond_grid ? nb : 4 * cond_grid;
-        hipLaunchKernelGGL(k_pairing_coop, dim3(grid), dim3(64), 0, pm, d, n, w->pts, w->valid, w->valid_sub, w->er, (const uint32_t *)nullptr, w->status, accept, (uint32_t *)nullptr, skip);
+        hipLaunchKernelGGL(k_pairing_coop, dim3(grid), dim3(64), COOP_LDS_BYTES(COOP_GROUPS_PER_WAVE), pm, d, n, w->pts, w->valid, w->valid_sub, w->er, (const uint32_t *)nullptr, w->status, accept, (uint32_t *)nullptr, skip);
     }
     HIPCHK(hipGetLastError());
     if (status_out) HIPCHK(hipMemcpyAsync(status_out, w->status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
@@ -1450,7 +1466,8 @@ extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t
 extern "C" int h2v_probe_pairing(const h2v_plan *p, uint32_t n, const uint8_t *p1c, const uint8_t *p2c, uint8_t *out) {
     return h2v_probe_pairing_ex(p, n, p1c, p2c, out, -1, nullptr);
 }
-// impl: -1 default, 0 one-lane-per-proof kernel, 1 cooperative kernel; dbg (optional): n * 24 * 48 bytes
+// impl: -1 default, 0 one-lane-per-proof kernel, 1 cooperative kernel (the launcher's choice of engine), 2 / 3 its narrow / wide
+// engine whatever n; dbg (optional): n * 24 * 48 bytes
 // (f after the Miller loop and - cooperative kernel only - after the final exponentiation; canonical LE limbs)
 extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t *p1c, const uint8_t *p2c, uint8_t *out, int impl, uint8_t *dbg) {
     if (!p || !p1c || !p2c || !out || n == 0) return fail(H2V_E_ARG, "bad argument");

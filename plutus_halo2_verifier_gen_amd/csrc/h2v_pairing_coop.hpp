@@ -29,14 +29,17 @@
                                              // measured 41 % bank-conflict cycles)
 #define COOP_GROUP_SLOTS 64                  // slots reserved per group (COOP_N_GROUP_SLOTS used)
 #define COOP_GROUP_DW (COOP_GROUP_SLOTS * COOP_SLOT_DW)
-#define COOP_GROUPS_PER_WAVE 2
+#define COOP_GROUPS_PER_WAVE 2               // the normal kernel; the narrow one has 4 (COOP_GROUPS_NARROW), the wide one 1
+#define COOP_GROUPS_NARROW 4
 #define COOP_TAB_DW ((16 * 2 * COOP_N_MUL_TERMS + 2 * 16 * 2 * COOP_N_LINE_TERMS + 16 * 2 * COOP_N_CSQR_TERMS + 16 * 2 * COOP_N_SQR_TERMS) / 4)  // operand tables, copied at start
-#define COOP_LDS_DW (COOP_GROUPS_PER_WAVE * COOP_GROUP_DW + COOP_N_SHARED_SLOTS * COOP_SLOT_DW + COOP_TAB_DW)
 
-// File-scope LDS so that every device function addresses it as LDS (ds_read/ds_write), not through flat pointers.
-__shared__ __attribute__((aligned(16))) uint32_t coop_lds[COOP_LDS_DW];
-#define COOP_SHR_OFF (COOP_GROUPS_PER_WAVE * COOP_GROUP_DW)
+// File-scope LDS so that every device function addresses it as LDS (ds_read/ds_write), not through flat pointers; sized
+// at launch (COOP_LDS_BYTES(groups)): wave-shared slots, operand tables, then one slot area per group of the wave.
+extern __shared__ __attribute__((aligned(16))) uint32_t coop_lds[];
+#define COOP_SHR_OFF 0
 #define COOP_TAB_OFF (COOP_SHR_OFF + COOP_N_SHARED_SLOTS * COOP_SLOT_DW)
+#define COOP_GRP_OFF ((COOP_TAB_OFF + COOP_TAB_DW + 3) & ~3)
+#define COOP_LDS_BYTES(groups) ((size_t)(COOP_GRP_OFF + (groups) * COOP_GROUP_DW) * 4)
 #define COOP_TAB_MUL_B 0                                   // byte offsets of the three tables inside the LDS copy
 #define COOP_TAB_LINE1_B (16 * 2 * COOP_N_MUL_TERMS)
 #define COOP_TAB_LINE2_B (COOP_TAB_LINE1_B + 16 * 2 * COOP_N_LINE_TERMS)
@@ -52,7 +55,11 @@ struct Coop {
     // batches too small to give every SIMD a wave otherwise): four lanes per coefficient (nq = 4, q = h + 2 * (lane >> 5)),
     // the upper half-wave mirroring the lower one's staging; the four reduced partial sums meet through
     // v_permlane16_swap and v_permlane32_swap.  Per engine call a lane then multiplies 3 / 2 / 1 terms instead of 6 / 4 / 2.
+    // NARROW kernel (four proofs per wave, for callers that keep the chip full with several batches in flight: 21 % fewer
+    // instructions per pairing, twice the chain): ONE lane per coefficient (nq = 1, q = 0), no exchange; every lane plays
+    // both staging roles (both = true, h = 0).
     int q, nq;
+    bool both;
 };
 
 H2V_DI uint32_t *coop_slot(const Coop &c, int s) {
@@ -140,7 +147,7 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
 #pragma unroll
             for (int j = 0; j < 14; j++) acc[i + j] += (uint64_t)x[i] * y[j];
     }
-    if (TRIPLE) {   // x3 as one shift-add per column (the compiler's choice was two v_mad_u64_u32 per column)
+    if (TRIPLE && c.nq >= 2) {   // x3 as one shift-add per column (the compiler's choice was two v_mad_u64_u32 per column)
 #pragma unroll
         for (int i = 0; i < 28; i++) {
             uint64_t t3;
@@ -170,10 +177,17 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
     // exchange 14 reduced limbs instead of 28 64-bit columns.  v_permlane16_swap exchanges the odd 16-lane rows of
     // its first operand with the even rows of its second: called on two copies of a register, one copy ends up
     // holding (own | partner) and the other (partner | own) by row, so their sum is own + partner in every lane.
+    if (c.nq >= 2) {   // (wave-uniform)
 #pragma unroll
-    for (int i = 0; i < 14; i++) {
-        const auto sw = __builtin_amdgcn_permlane16_swap(r.l[i], r.l[i], false, false);
-        r.l[i] = sw[0] + sw[1];
+        for (int i = 0; i < 14; i++) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(r.l[i], r.l[i], false, false);
+            r.l[i] = sw[0] + sw[1];
+        }
+    } else if (TRIPLE) {
+        // one lane per coefficient: all four terms of the cyclotomic squaring in one set of columns (4 x 14 x 2 x 2^56: no
+        // room for the factor 3), so the REDUCED sum is tripled: below 3 (4 * 168 / 2520 + 1) p = 3.8 p
+#pragma unroll
+        for (int i = 0; i < 14; i++) r.l[i] *= 3u;
     }
     if (c.nq == 4) {   // (wave-uniform) the other half-wave holds the sum of the other two quarters
 #pragma unroll
@@ -182,8 +196,9 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
             r.l[i] = sw[0] + sw[1];
         }
     }
-    // value: two halves < 2 * 1.4 p; four quarters < 4 * (3 * 168 / 2520 + 1) p = 4.8 p (every operand bound of the
-    // staging code assumes v <= 6, CONJ and INV v <= 5); limbs back below 2^28
+    // value: two halves < 2 * 1.4 p; four quarters < 4 * (3 * 168 / 2520 + 1) p = 4.8 p; one lane: (12 * 7 * 13 / 2520 + 1) p =
+    // 1.43 p (MUL), 1.56 p (SQR), 3.8 p (CSQR, above) (every operand bound of the staging code assumes v <= 6, CONJ and INV
+    // v <= 5); limbs back below 2^28
     f28_carry(r);
     return f28_pack(r);
 }
@@ -205,7 +220,7 @@ H2V_DI F28 coop_shfl_xor1(const F28 &a) {
 }
 // stage a distributed value (v <= 6) as the A operand (a_{k,part}, and -a_{k,1})
 H2V_DI void coop_stage_a(const Coop &c, const F28 &a) {
-    if (c.g < 12 && c.h == 0) {
+    if (c.g < 12 && c.h == 0) {   // (narrow kernel: h = 0 in every lane)
         coop_store28(coop_slot(c, COOP_SLOT_A + c.g), a);
         if (c.g & 1) {
             F28 n;
@@ -218,7 +233,7 @@ H2V_DI void coop_stage_a(const Coop &c, const F28 &a) {
 // stage a distributed value (v <= 6) as the B operand (b and xi*b)
 H2V_DI void coop_stage_b(const Coop &c, const F28 &b) {
     const F28 pb = coop_shfl_xor1(b);
-    if (c.g < 12 && c.h == 1) {
+    if (c.g < 12 && (c.both || c.h == 1)) {
         coop_store28(coop_slot(c, COOP_SLOT_B + c.g), b);
         F28 xb, t;
         F28_NEG(t, pb, 7, 1);                  // 7p - b1
@@ -247,16 +262,14 @@ H2V_DI F28 coop_mul(const Coop &c, const F28 &a, const F28 &b) {
 // after the other): both halves hold a and its Fp2 partner, every lane forms 7p - a, the half-0 lanes carry and store
 // that (NA; odd g), the half-1 lanes carry and store partner + (a or 7p - a) (S / M), and the uncarried first store is
 // a << h (A or D).
-H2V_DI F28 coop_csqr(const Coop &c, const F28 &a) {
-    const F28 pa = coop_shfl_xor1(a);          // the other part of the same Fp2 coefficient
-    const bool odd = (c.g & 1) != 0, hi = c.h != 0;
-    F28 neg, v, u;
-    F28_NEG(neg, a, 7, 1);                     // 7p - a                                   (7, 3)
+H2V_DI void coop_csqr_stage(const Coop &c, const F28 &a, const F28 &pa, const F28 &neg, const bool hi) {
+    const bool odd = (c.g & 1) != 0;
+    F28 v, u;
 #pragma unroll
     for (int i = 0; i < 14; i++) {
         const uint32_t t = odd ? neg.l[i] : a.l[i];      // imaginary-part lane: M = re - im = pa + (7p - a); real: S = a + pa
         v.l[i] = hi ? pa.l[i] + t : neg.l[i];
-        u.l[i] = a.l[i] << c.h;                // A = a (6, 1) | D = 2a (12, 2): limbs below 2^29 - see the headroom note at the engine
+        u.l[i] = a.l[i] << (hi ? 1 : 0);       // A = a (6, 1) | D = 2a (12, 2): limbs below 2^29 - see the headroom note at the engine
     }
     f28_carry(v);                              // NA (7, 1) | S (12, 1) / M (13, 1)
     if (c.g < 12) {
@@ -267,6 +280,17 @@ H2V_DI F28 coop_csqr(const Coop &c, const F28 &a) {
             f28_mul_small<2>(nd, v);
             coop_store28(coop_slot(c, COOP_SLOT_ND2), nd);
         }
+    }
+}
+H2V_DI F28 coop_csqr(const Coop &c, const F28 &a) {
+    const F28 pa = coop_shfl_xor1(a);          // the other part of the same Fp2 coefficient
+    F28 neg;
+    F28_NEG(neg, a, 7, 1);                     // 7p - a                                   (7, 3)
+    if (c.both) {                              // narrow kernel: the lane plays both roles, one after the other
+        coop_csqr_stage(c, a, pa, neg, false);
+        coop_csqr_stage(c, a, pa, neg, true);
+    } else {
+        coop_csqr_stage(c, a, pa, neg, c.h != 0);
     }
     __syncthreads();
     const F28 r = coop_engine<COOP_N_CSQR_TERMS, true>(c, COOP_TAB_CSQR_B + c.g * 2 * COOP_N_CSQR_TERMS);
@@ -280,7 +304,7 @@ H2V_DI F28 coop_csqr(const Coop &c, const F28 &a) {
 H2V_DI F28 coop_sqr(const Coop &c, const F28 &a) {
     coop_stage_a(c, a);
     const F28 pa = coop_shfl_xor1(a);          // the other part of the same Fp2 coefficient
-    if (c.g < 12 && c.h == 1) {
+    if (c.g < 12 && (c.both || c.h == 1)) {
         F28 d2, pd2, t, xd;
         f28_mul_small<2>(d2, a);               // (12, 2): stored with limbs below 2^29
         coop_store28(coop_slot(c, COOP_SLOT_D + c.g), d2);
@@ -411,21 +435,23 @@ H2V_DI F28 coop_inv(const Coop &c, const F28 &f, bool &ok) {
 // big-integer pairing by tools/gen_coop_program.py).  Fp12 variables live in a private array, so no vector state is
 // live across the engine call (the first version kept them in VGPRs and spent 65 % of its wave-cycles waiting on
 // the spills around every call).
-template <bool WIDE>
+template <bool WIDE, bool NARROW = false>
 H2V_DI void pairing_coop_body(const H2vDevPlan &plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
                               const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac /* folded el (recursion) or NULL */,
                               uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg, const uint32_t bid,
                               bool *verdict_out = nullptr /* WIDE: the verdict, in every lane */) {
-    const int lane = threadIdx.x, grp = WIDE ? 0 : lane >> 5;
+    static_assert(!(WIDE && NARROW), "one proof per wave, or four");
+    const int lane = threadIdx.x, grp = WIDE ? 0 : NARROW ? lane >> 4 : lane >> 5;
     Coop c;
     c.g = lane & 15;
-    c.h = (lane >> 4) & 1;
-    c.nq = WIDE ? 4 : 2;
+    c.h = NARROW ? 0 : (lane >> 4) & 1;
+    c.both = NARROW;
+    c.nq = WIDE ? 4 : NARROW ? 1 : 2;
     c.q = WIDE ? c.h + 2 * (lane >> 5) : c.h;
-    c.grp_off = grp * COOP_GROUP_DW;
-    const int leader = grp * 32;  // lane (g = 0, h = 0) of the group
+    c.grp_off = COOP_GRP_OFF + grp * COOP_GROUP_DW;
+    const int leader = NARROW ? grp * 16 : grp * 32;  // lane (g = 0, h = 0) of the group
     const bool is_leader = lane == leader;
-    const uint32_t i = WIDE ? bid : bid * COOP_GROUPS_PER_WAVE + grp;
+    const uint32_t i = WIDE ? bid : bid * (NARROW ? COOP_GROUPS_NARROW : COOP_GROUPS_PER_WAVE) + grp;
     const bool live = i < n;
     const uint32_t ii = live ? i : n - 1;  // dead groups shadow the last proof, never write
     const uint32_t slots = H2V_SLOTS(plan);
@@ -598,7 +624,7 @@ H2V_DI void pairing_coop_body(const H2vDevPlan &plan, uint32_t n, const uint32_t
     if (c.g == 0) { Fp one; fp_set_one(one); mine = fp_eq(res, one); }
     else if (c.g < 12) mine = fp_is_zero(res);
     const unsigned long long bal = __ballot(mine);
-    const bool is_one = WIDE ? bal == ~0ull : ((bal >> leader) & 0xffffffffull) == 0xffffffffull;
+    const bool is_one = WIDE ? bal == ~0ull : NARROW ? ((bal >> leader) & 0xffffull) == 0xffffull : ((bal >> leader) & 0xffffffffull) == 0xffffffffull;
     inv_ok = __shfl((int)inv_ok, leader) != 0;
     if (is_leader && live) {
         if (st == 0 && !(is_one && inv_ok)) st |= H2V_ST_PAIRING;
@@ -627,6 +653,13 @@ k_pairing_coop_wide(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pt
                     const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac, uint32_t *__restrict__ status,
                     uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
     pairing_coop_body<true>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg, blockIdx.x);
+}
+// four proofs per wave, one lane per coefficient: fewest instructions per pairing, longest chain (see Coop)
+extern "C" __global__ void __launch_bounds__(64, 2)
+k_pairing_coop_narrow(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
+                      const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac, uint32_t *__restrict__ status,
+                      uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
+    pairing_coop_body<false, true>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg, blockIdx.x);
 }
 // The single pairing of the RLC batch mode with its epilogue fused in: batch check passed -> accept[i] = good_i for the whole
 // batch and *skip = 1 (the per-proof kernels queued behind return at once); failed -> *skip = 0 and accept[] is left to them.

@@ -198,12 +198,13 @@ def test_pairing_cooperative_matches_one_lane_kernel(be, orc, circuits):
     p1 += [bls.g1_compress(None), bls.g1_compress(bls.G1_GEN), bls.g1_compress(None)]
     p2 += [bls.g1_compress(None), bls.g1_compress(None), bls.g1_compress(bls.G1_GEN)]
     acc0, dump0 = be.probe_pairing_ex(dp, p1, p2, impl=0)
-    acc1, dump1 = be.probe_pairing_ex(dp, p1, p2, impl=1)
-    assert acc0 == acc1 == [1, 1, 0] * 3 + [1, 0, 0]
-    for i in range(len(p1)):
-        assert dump0[i][0] == dump1[i][0], "Miller loop value differs for pair %d" % i
-        is_one = dump1[i][1] == [1] + [0] * 11
-        assert is_one == bool(acc1[i])
+    for impl in (1, 2, 3):   # the launcher's choice (wide for 12 pairs), the narrow engine (16 lanes per proof), the wide one (64)
+        acc1, dump1 = be.probe_pairing_ex(dp, p1, p2, impl=impl)
+        assert acc0 == acc1 == [1, 1, 0] * 3 + [1, 0, 0], impl
+        for i in range(len(p1)):
+            assert dump0[i][0] == dump1[i][0], "Miller loop value differs for pair %d (engine %d)" % (i, impl)
+            is_one = dump1[i][1] == [1] + [0] * 11
+            assert is_one == bool(acc1[i])
 
 
 TRACE_NAMES = ["theta", "beta", "gamma", "trash", "y", "x", "x1", "x2", "x3", "x4", "x_prev", "x_next", "x_last", "xn",
