@@ -719,8 +719,15 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         const uint32_t lo = (uint32_t)((uint64_t)n * k / pipes), hi = (uint32_t)((uint64_t)n * (k + 1) / pipes), m = hi - lo;
         hipEvent_t *ev = w->ring[slot][k];
         static const bool dec_queue_on = []() { const char *e = getenv("H2V_DEC_QUEUE"); return e ? atoi(e) != 0 : true; }();
-        if (int rcs = ws_streams(w, k, true, true, split_dec && !dec_queue_on)) return rcs;
-        hipStream_t pm = w->pmain[k], ps = w->pside[k];
+        // A caller that keeps >= 6 batches in flight (h2v_workspace_hint_in_flight) gets the whole pipeline on ITS stream: the
+        // other batches fill the chip, and one stream per batch keeps many batches within the 16 hardware queues (three
+        // streams per batch collide from the sixth batch on).  Measured, 40 steps of simple_mul x 4096: three streams 5 / 8 / 11
+        // in flight 4.46 / 4.66 / 4.75 ms per step, one stream 4.80 / 4.39 / 4.50.  H2V_ONE_STREAM = 0 / 1 forces the choice.
+        static const int env_one = []() { const char *e = getenv("H2V_ONE_STREAM"); return e ? atoi(e) : -1; }();
+        const bool one_stream = pipes == 1 && (env_one >= 0 ? env_one != 0 : w->in_flight_hint >= 6);
+        if (!one_stream)
+            if (int rcs = ws_streams(w, k, true, true, split_dec && !dec_queue_on)) return rcs;
+        hipStream_t pm = one_stream ? st : w->pmain[k], ps = one_stream ? st : w->pside[k];
         const uint64_t *off_k = off + lo;
         const uint8_t *inst_k = inst ? inst + (size_t)lo * d.n_pi * 32 : nullptr;
         const uint8_t *ci_k = ci ? ci + (size_t)lo * 48 : nullptr;
@@ -763,7 +770,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         auto sub_half = [&]() {
             // the subgroup tests as a launch of their own (only without the queue)
             if (!split_dec) return 0;
-            hipStream_t pb = dec_queue ? ps : w->psub[k];   // (with the queue there is no third launch: only the events are recorded)
+            hipStream_t pb = (dec_queue || one_stream) ? ps : w->psub[k];   // (with the queue there is no third launch: only the events are recorded)
             HIPCHK(hipStreamWaitEvent(pb, w->ev_fork, 0));
             HIPCHK(hipEventRecord(ev[7], pb));
             if (!dec_queue) hipLaunchKernelGGL(k_g1_decompress, dim3(dec_grid), dim3(64), 0, pb, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, (uint32_t *)nullptr, 2u, vsub_k);
