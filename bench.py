@@ -334,7 +334,7 @@ def main():
             tm = wss1[0].timings(j)
             a1["transcript_combiner"] += tm.transcript_combiner_ms / 5; a1["g1_decompress"] += tm.g1_decompress_ms / 5
             a1["g1_msm"] += tm.g1_msm_ms / 5; a1["pairing"] += tm.pairing_ms / 5
-        kernel_ms_alone = dict(a1, ms_per_step=_el1 / 5 * 1e3)
+        kernel_ms_alone = dict(a1, ms_per_step=_el1 / 5 * 1e3, msm_lpt=tm.msm_lanes_per_term or 2, pair_lanes=tm.pairing_lanes_per_proof or 32)
         wss1[0].close()
         del wss1
     n_accept = int(accept.sum())
@@ -413,10 +413,12 @@ def main():
         else:
             tpl = msm_lpt - 16 if msm_lpt in (18, 20) else 1     # several terms per lane (H2V_MSM_TPL): shared doublings
             quad = msm_lpt if msm_lpt == 8 else 0                # a quad per GLV half (small launches of few terms)
-            kname = {"g1_msm": "k_g1_msm_multi%d" % tpl if tpl > 1 else "k_g1_msm_fixed" if msm_lpt == 3 else "k_g1_msm_merged" if msm_lpt == 1
-                               else "k_g1_msm_quad" if quad == 8 else "k_g1_msm", "g1_decompress": dec_name,
-                     "transcript_combiner": vm_name,
-                     "pairing": {16: "k_pairing_coop_narrow", 64: "k_pairing_coop_wide", 1: "k_pairing_check"}.get(pair_lanes, "k_pairing_coop")}
+
+            def shape_names(lpt_code, lanes):   # the kernels behind the launcher's reported shapes
+                return {"g1_msm": {18: "k_g1_msm_multi2", 20: "k_g1_msm_multi4", 3: "k_g1_msm_fixed", 1: "k_g1_msm_merged", 8: "k_g1_msm_quad"}.get(lpt_code, "k_g1_msm"),
+                        "g1_decompress": dec_name, "transcript_combiner": vm_name,
+                        "pairing": {16: "k_pairing_coop_narrow", 64: "k_pairing_coop_wide", 1: "k_pairing_check"}.get(lanes, "k_pairing_coop")}
+            kname = shape_names(msm_lpt, pair_lanes)
             # lanes per coefficient 1 / 2 / 4 (narrow / normal / wide engine): a lane multiplies 1/nq of a coefficient's terms and reduces once
             nq = {16: 1, 64: 4}.get(pair_lanes, 2)
             pairing_lane = sum(calls * ((terms // nq) * 196 + 196) for calls, terms in ((35, 12), (63, 8), (315, 4), (136, 6)))
@@ -483,7 +485,8 @@ def main():
             "int_roofline": int_roof(dominant),
             "msm_int_roofline": int_roof(msm_key),
             "kernel_ms": {kname[k]: round(v, 4) for k, v in kernel_ms.items()},
-            "kernel_ms_one_step_in_flight": ({kname[k]: round(v, 4) for k, v in kernel_ms_alone.items() if k in kname} if kernel_ms_alone else None),
+            "kernel_ms_one_step_in_flight": ({shape_names(kernel_ms_alone["msm_lpt"], kernel_ms_alone["pair_lanes"])[k]: round(v, 4)
+                                              for k, v in kernel_ms_alone.items() if k in kname} if kernel_ms_alone and args.mode == "per-proof" else None),
             "ms_per_step_one_step_in_flight": round(kernel_ms_alone["ms_per_step"], 4) if kernel_ms_alone else None,
             "step_int_roofline": {"what": "analytical lane-level multiply-adds of ALL kernels of a step / ms_per_step, against the measured v_mad_u64_u32 ceiling",
                                   "achieved": round(sum(mads.values()) / (elapsed / args.steps) / 1e12, 3), "peak": round(IMAD_PEAK_TOPS, 2) if IMAD_PEAK_TOPS else None,

@@ -17,7 +17,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # the profiled command: the steps-in-flight count the run above settled on, and nothing but warm-up + timed steps, so
 # that rocprofv3's per-kernel averages and the line's event-timed kernel_ms cover the same launches
 INF=$(python -c "import json,sys; print(json.load(open('$O/${TAG}_bench.json'))['config']['steps_in_flight'])")
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py $ARGS --steps 20 --warmup 5 --inflight $INF --timed-only > $O/prof_$TAG.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py $ARGS --steps 60 --warmup 5 --inflight $INF --timed-only > $O/prof_$TAG.log 2>&1
 grep "^{" $O/prof_$TAG.log | tail -1 > $O/${TAG}_bench_under_rocprof.json
 for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
   n=$(echo $c | cut -d" " -f1)
