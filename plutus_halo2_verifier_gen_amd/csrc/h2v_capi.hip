@@ -639,14 +639,15 @@ static void launch_ivc_fold(const H2vDevPlan &d, uint32_t n, const uint32_t *pts
 // kernel stays as a cross-check (H2V_PAIRING=legacy, or impl = 0 in the probe).
 static uint32_t launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
                                 const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st, const uint32_t *skip = nullptr,
-                                bool prefer_narrow = false) {
+                                bool prefer_narrow = false, double wide_up_to = -1.0) {
+    if (wide_up_to < 0) wide_up_to = msm_n_simd();
     // The WIDE engine (one proof per wave, four lanes per coefficient: 3 / 2 / 1 terms per lane and call instead of 6 / 4 / 2)
     // when even one wave per proof leaves SIMDs free: n <= #SIMDs.  Above that the two-proofs-per-wave kernel does less
     // total work.  H2V_PAIRING_WIDE = 0 / 1 forces the choice; the conditional (RLC fall-back) launch is never wide.
     static const int env_wide = []() { const char *e = getenv("H2V_PAIRING_WIDE"); return e ? atoi(e) : -1; }();
     static const int env_narrow = []() { const char *e = getenv("H2V_PAIRING_NARROW"); return e ? atoi(e) : -1; }();
     // impl 2 / 3 (probe): the narrow / the wide kernel whatever n
-    const bool wide = !skip && impl != 2 && (impl == 3 || (env_wide >= 0 ? env_wide != 0 : (double)n <= msm_n_simd()));
+    const bool wide = !skip && impl != 2 && (impl == 3 || (env_wide >= 0 ? env_wide != 0 : (double)n <= wide_up_to));
     const bool narrow = !skip && !wide && (impl == 2 || env_narrow > 0 || (env_narrow < 0 && prefer_narrow));
     if (impl == 0) { hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg); return 1; }
     else if (wide) hipLaunchKernelGGL(k_pairing_coop_wide, dim3(n), dim3(64), COOP_LDS_BYTES(1), st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
@@ -666,7 +667,11 @@ static uint32_t launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *
     static const int impl = []() { const char *e = getenv("H2V_PAIRING"); return (e && strcmp(e, "legacy") == 0) ? 0 : 1; }();
     const double S = msm_n_simd();
     const bool prefer_narrow = in_flight_hint >= 4 ? (double)n >= 2.0 * S : ((double)n > 2.0 * S && (double)n <= 4.0 * S);
-    return launch_pairing_impl(impl, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, st, nullptr, prefer_narrow);
+    // (the wide engine issues twice the instructions of the normal one: a caller that keeps the chip full takes it only up to
+    // #SIMDs / 2 proofs - sha256 shape x 1024, four in flight: wide 3.18, normal 2.98, narrow 3.12 ms per step; secp256k1 x 512:
+    // wide 2.37, normal 2.47, narrow 2.64)
+    return launch_pairing_impl(impl, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, st, nullptr, prefer_narrow,
+                               in_flight_hint >= 4 ? S / 2.0 : S);
 }
 
 // ---------------------------------------------------------------------------------------------- pipeline
