@@ -809,7 +809,8 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
             const uint32_t pbf = split.fix.bs / mf.n_fixl;
             hipLaunchKernelGGL(k_g1_msm_fixed, dim3((m + pbf - 1) / pbf), dim3(split.fix.bs), (size_t)split.fix.bs * 172, ps, d, mf, m, pbf, scal_k, pts_k, (uint32_t *)nullptr);
             HIPCHK(hipEventRecord(w->ev_fix[k], ps));
-            (void)launch_msm_ladders(d, mv, m, split.var, scal_k, pts_k, nullptr, pm);
+            if (msm_terms_per_lane(w->in_flight_hint) > 1) (void)launch_msm_range(d, mv, m, scal_k, pts_k, nullptr, pm, w->in_flight_hint);   // (several terms per lane)
+            else (void)launch_msm_ladders(d, mv, m, split.var, scal_k, pts_k, nullptr, pm);
             HIPCHK(hipStreamWaitEvent(pm, w->ev_fix[k], 0));
             hipLaunchKernelGGL(k_g1_sum_pairs, dim3((m + 63) / 64), dim3(64), 0, pm, m, er_k, erf_k);
             w->ring_lpt[slot] = 3;

@@ -131,7 +131,7 @@ def test_in_flight_hint_changes_the_shape_not_the_verdicts(be, circuits):
     """h2v_workspace_hint_in_flight(>= 4): the per-proof MSM runs two terms per lane (k_g1_msm_multi2, reported as 18) -
     the accept vector and the statuses stay those of the default shape."""
     from plutus_halo2_verifier_gen_amd import synth
-    for name in ("simple_mul", "lookup_table"):
+    for name in ("simple_mul", "lookup_table", "atms_with_lookups"):   # (atms at 2048+ proofs: ladders beside a fixed-base launch)
         vk, td, pl, dp, ov = circuits[name]
         batch = synth.forge_batch(vk, td, 96, seed=61, plan=pl, workers=2)
         batch = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.3, seed=62, kinds=list(synth.CORRUPTIONS))
@@ -144,6 +144,15 @@ def test_in_flight_hint_changes_the_shape_not_the_verdicts(be, circuits):
         with pytest.raises(be.H2VError):
             ws5.hint_in_flight(0)
         ws1.close(); ws5.close()
+    # the split launch (per-proof terms two per lane beside the fixed-base lanes) needs a batch that does not fit one wave per SIMD
+    vk, td, pl, dp, ov = circuits["atms_with_lookups"]
+    batch = synth.forge_batch(vk, td, 2048, seed=63, plan=pl, workers=8)
+    batch = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.05, seed=64, kinds=list(synth.CORRUPTIONS))
+    ws = be.Workspace(dp, 2048)
+    ws.hint_in_flight(5)
+    assert list(dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws)) == batch.expected
+    assert ws.timings().msm_lanes_per_term == 3 and ws.timings().pairing_lanes_per_proof == 16
+    ws.close()
 
 
 def test_quad_cooperative_addition_in_every_lane(be):
