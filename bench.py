@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--mode", default="per-proof", choices=["per-proof", "rlc"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--inflight", type=int, default=0, help="steps in flight (workspaces / streams); default: 2 (per-proof, batches above 1024), 4 (per-proof, smaller), 7 (rlc)")
-    ap.add_argument("--msm-tpl", type=int, default=0, choices=[0, 1, 2, 4],
+    ap.add_argument("--msm-tpl", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="per-proof MSM: terms per lane (sets H2V_MSM_TPL; 2 / 4 share the doublings of a lane's terms)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo = rehearsal of the N > 1 code path on a box with one GPU "
@@ -411,11 +411,11 @@ def main():
             }
             msm_key = "bucket_accumulate"
         else:
-            tpl = msm_lpt - 16 if msm_lpt in (18, 20) else 1     # several terms per lane (H2V_MSM_TPL): shared doublings
+            tpl = msm_lpt - 16 if msm_lpt in (18, 19, 20) else 1     # several terms per lane (H2V_MSM_TPL): shared doublings
             quad = msm_lpt if msm_lpt == 8 else 0                # a quad per GLV half (small launches of few terms)
 
             def shape_names(lpt_code, lanes):   # the kernels behind the launcher's reported shapes
-                return {"g1_msm": {18: "k_g1_msm_multi2", 20: "k_g1_msm_multi4", 3: "k_g1_msm_fixed", 1: "k_g1_msm_merged", 8: "k_g1_msm_quad"}.get(lpt_code, "k_g1_msm"),
+                return {"g1_msm": {18: "k_g1_msm_multi2", 19: "k_g1_msm_multi3", 20: "k_g1_msm_multi4", 3: "k_g1_msm_fixed", 1: "k_g1_msm_merged", 8: "k_g1_msm_quad"}.get(lpt_code, "k_g1_msm"),
                         "g1_decompress": dec_name, "transcript_combiner": vm_name,
                         "pairing": {16: "k_pairing_coop_narrow", 64: "k_pairing_coop_wide", 1: "k_pairing_check"}.get(lanes, "k_pairing_coop")}
             kname = shape_names(msm_lpt, pair_lanes)

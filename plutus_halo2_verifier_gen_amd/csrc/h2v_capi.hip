@@ -570,7 +570,7 @@ static uint32_t launch_msm_ladders(const H2vDevPlan &d, const H2vMsmArgs &ma, ui
 // bound by the instructions issued, not by chain length, and two terms per lane issue 26 % fewer multiply-adds per proof
 // (measured, simple_mul x 4096: 5 in flight 5.12 -> 4.66 ms per step; with 3 in flight 5.04 -> 5.01).
 static int msm_terms_per_lane(uint32_t in_flight_hint) {
-    static const int v = []() { const char *e = getenv("H2V_MSM_TPL"); const int t = e ? atoi(e) : 0; return t == 1 || t == 2 || t == 4 ? t : 0; }();
+    static const int v = []() { const char *e = getenv("H2V_MSM_TPL"); const int t = e ? atoi(e) : 0; return t >= 1 && t <= 4 ? t : 0; }();
     return v ? v : (in_flight_hint >= 4 ? 2 : 1);
 }
 static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const uint32_t *scalars, const uint32_t *pts,
@@ -580,6 +580,7 @@ static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint
         const uint32_t lpp = (ma.n_terms + tpl - 1) / tpl, bs = 256;
         const uint32_t per_block = bs / lpp, blocks = (n + per_block - 1) / per_block;
         if (tpl == 2) hipLaunchKernelGGL(k_g1_msm_multi2, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
+        else if (tpl == 3) hipLaunchKernelGGL(k_g1_msm_multi3, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
         else hipLaunchKernelGGL(k_g1_msm_multi4, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
         return 16 + (uint32_t)tpl;   // reported as msm_lanes_per_term: 18 / 20 = two / four terms per lane
     }

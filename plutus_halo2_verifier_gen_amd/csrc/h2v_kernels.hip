@@ -1076,6 +1076,13 @@ k_g1_msm_multi4(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, 
     (void)tabws;
     msm_multi_body<4>(plan, ma, n, per_block, scalars, pts, red);
 }
+extern "C" __global__ void __launch_bounds__(256, 2)
+k_g1_msm_multi3(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, const uint32_t *__restrict__ scalars,
+                const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
+    extern __shared__ uint32_t red[];
+    (void)tabws;
+    msm_multi_body<3>(plan, ma, n, per_block, scalars, pts, red);
+}
 
 // er += er_fix (complete Jacobian addition, one lane per proof): joins the two launches of a split MSM
 extern "C" __global__ void __launch_bounds__(64)

@@ -562,7 +562,7 @@ def test_alternate_pipeline_modes(be, env, tmp_path):
     assert r.returncode == 0 and "modes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("lpt", ["1", "2", "8", "tpl2", "tpl4"])
+@pytest.mark.parametrize("lpt", ["1", "2", "8", "tpl2", "tpl3", "tpl4"])
 def test_g1_msm_forced_shape(be, lpt):
     """test_g1_msm (edge scalars, equal / opposite / infinity bases, T = 1 .. 64) again with the MSM shape forced: the
     probe's small batches would otherwise always take two lanes per term.  tpl2 / tpl4: several terms per lane on one
