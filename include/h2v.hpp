@@ -140,6 +140,8 @@ class Workspace {
     Workspace &operator=(const Workspace &) = delete;
     ~Workspace() { h2v_workspace_free(w_); }
     h2v_workspace *handle() const { return w_; }
+    /// tuning hint (h2v_workspace_hint_in_flight): the caller keeps n batches in flight, one workspace each; never changes results
+    void hint_in_flight(uint32_t n) { check(h2v_workspace_hint_in_flight(w_, n)); }
     void submit(const h2v_batch &batch, bool rlc = false) {
         check(h2v_verify_batch_submit(vk_.handle(), &batch, w_, rlc ? H2V_SUBMIT_RLC : 0u, nullptr));
         n_ = batch.n;

@@ -66,6 +66,7 @@ int main(int argc, char **argv) {
         for (uint8_t a : racc) rbits.push_back(a ? '1' : '0');
         std::printf("rlc %s\nrlc_fell_back %d\n", rbits.c_str(), fell_back ? 1 : 0);
         h2v::Workspace w0(vk, n), w1(vk, n);
+        w0.hint_in_flight(5);   // (a tuning hint: other launch shapes, the same verdicts)
         w0.submit(batch, false);
         w1.submit(batch, true);
         std::string s0, s1;
