@@ -29,6 +29,8 @@ b = synth.forge_batch(vk, td, args.batch, seed=1000, plan=pl, workers=16)
 dp = backend.DevicePlan(pl.to_bytes(), 0)
 W = args.workspaces
 wss = [backend.Workspace(dp, args.batch) for _ in range(W)]
+for w_ in wss:
+    w_.hint_in_flight(W)      # (from 4 up: launch shapes that issue fewer instructions)
 hb, keep = dp.host_batch(b.proofs, b.proof_off, b.instances, b.committed)
 rlc = args.mode == "rlc"
 seed = bytes(range(32))
@@ -46,7 +48,7 @@ def run(steps):
     return acc
 
 
-run(6)
+run(max(6, W))
 t0 = time.perf_counter()
 acc = run(args.steps)
 dt = (time.perf_counter() - t0) / args.steps
