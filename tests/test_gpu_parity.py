@@ -206,10 +206,14 @@ def test_pairing_cooperative_matches_one_lane_kernel(be, orc, circuits):
         p2.append(bls.g1_compress(sA))
     p1 += [bls.g1_compress(None), bls.g1_compress(bls.G1_GEN), bls.g1_compress(None)]
     p2 += [bls.g1_compress(None), bls.g1_compress(None), bls.g1_compress(bls.G1_GEN)]
+    for k in range(2):   # 14 pairs: the last wave of every engine has idle groups (two of four in the narrow one)
+        A = bls.g1_mul(bls.G1_GEN, rng.randrange(1, R))
+        p1.append(bls.g1_compress(A))
+        p2.append(bls.g1_compress(bls.g1_mul(A, td.s) if k == 0 else bls.g1_mul(A, td.s + 1)))
     acc0, dump0 = be.probe_pairing_ex(dp, p1, p2, impl=0)
     for impl in (1, 2, 3):   # the launcher's choice (wide for 12 pairs), the narrow engine (16 lanes per proof), the wide one (64)
         acc1, dump1 = be.probe_pairing_ex(dp, p1, p2, impl=impl)
-        assert acc0 == acc1 == [1, 1, 0] * 3 + [1, 0, 0], impl
+        assert acc0 == acc1 == [1, 1, 0] * 3 + [1, 0, 0] + [1, 0], impl
         for i in range(len(p1)):
             assert dump0[i][0] == dump1[i][0], "Miller loop value differs for pair %d (engine %d)" % (i, impl)
             is_one = dump1[i][1] == [1] + [0] * 11
