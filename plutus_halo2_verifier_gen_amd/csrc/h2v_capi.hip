@@ -1163,7 +1163,7 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     // one_stream (h2v_rlc_opts.flags & H2V_RLC_ONE_STREAM, or the environment variable of that name = 1 / 0): everything on
     // the caller's stream, decompression before the combiner - one stream per batch in flight instead of two
     static const int env_one = []() { const char *e = getenv("H2V_RLC_ONE_STREAM"); return e ? atoi(e) : -1; }();
-    const bool one_stream = env_one >= 0 ? env_one != 0 : one_stream_opt;
+    const bool one_stream = env_one >= 0 ? env_one != 0 : (one_stream_opt || w->in_flight_hint >= 3);   // (the flag, or the caller's in-flight hint)
     if (!one_stream && (rc = ws_streams(w, 0, false, true, false))) return rc;
     hipStream_t pm = st, ps = one_stream ? st : w->pside[0];
     if (!one_stream) {
