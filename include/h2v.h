@@ -89,7 +89,9 @@ int h2v_workspace_create(const h2v_plan *plan, uint64_t max_batch, h2v_workspace
 void h2v_workspace_free(h2v_workspace *ws);
 /* (new) Tuning hint: the caller keeps n_in_flight batches in flight on this device (each on its own workspace).  From 4 up
  * the launcher prefers shapes that issue fewer instructions over shapes with shorter dependent chains (per-proof MSM: two
- * terms per lane on one accumulator).  Results do not depend on it.  Default 1. */
+ * terms per lane on one accumulator; the narrow pairing engine from 2 x #SIMDs proofs; from 6 the whole per-proof pipeline on
+ * the caller's stream; RLC mode: from 3 the one-stream form, as with H2V_RLC_ONE_STREAM).  Results do not depend on it.
+ * Default 1. */
 int h2v_workspace_hint_in_flight(h2v_workspace *ws, uint32_t n_in_flight);
 /* Per-kernel device times of a past call that used `ws` (calls_back = 0: the most recent; up to 63 back), from HIP
  * events recorded on the streams the kernels ran on.  Synchronise the launch stream before asking. */
