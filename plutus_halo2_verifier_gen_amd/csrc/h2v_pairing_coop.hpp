@@ -119,7 +119,9 @@ H2V_DI void coop_load28_pair(uint32_t (&x)[14], uint32_t (&y)[14], const uint32_
 
 // out = sum_t X[tab[2t]] * Y[tab[2t+1]]  (mod p), one Montgomery reduction.  NT <= 12 (accumulator headroom).
 // TRIPLE: the column accumulators are multiplied by 3 before the reduction (6 terms * 3 still fits 64 bits).
-template <int NT, bool TRIPLE>
+// NQ: lanes per coefficient (Coop::nq) as a compile-time constant - one instantiation per engine (narrow / normal / wide), so
+// that the term loop, the exchange and the tripling carry no wave-uniform branches.
+template <int NT, bool TRIPLE, int NQ>
 H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
     const uint8_t *tab = reinterpret_cast<const uint8_t *>(coop_lds + COOP_TAB_OFF) + tab_row_byte;
     static_assert(NT <= 12, "column accumulators hold at most 12 unreduced products");
@@ -128,7 +130,7 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
     uint64_t acc[28];
     {   // first term initialises the columns (no zero-fill of 56 registers)
         uint32_t x[14], y[14];
-        coop_load28_pair(x, y, coop_slot(c, tab[2 * c.q]), coop_slot(c, tab[2 * c.q + 1]));
+        coop_load28_pair(x, y, coop_slot(c, tab[2 * (NQ == 1 ? 0 : c.q)]), coop_slot(c, tab[2 * (NQ == 1 ? 0 : c.q) + 1]));
 #pragma unroll
         for (int i = 0; i < 14; i++)
 #pragma unroll
@@ -139,7 +141,7 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
         acc[27] = 0;
     }
 #pragma unroll 1
-    for (int t = c.q + c.nq; t < NT; t += c.nq) {
+    for (int t = (NQ == 1 ? 0 : c.q) + NQ; t < NT; t += NQ) {
         uint32_t x[14], y[14];
         coop_load28_pair(x, y, coop_slot(c, tab[2 * t]), coop_slot(c, tab[2 * t + 1]));
 #pragma unroll
@@ -147,7 +149,7 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
 #pragma unroll
             for (int j = 0; j < 14; j++) acc[i + j] += (uint64_t)x[i] * y[j];
     }
-    if (TRIPLE && c.nq >= 2) {   // x3 as one shift-add per column (the compiler's choice was two v_mad_u64_u32 per column)
+    if (TRIPLE && NQ >= 2) {   // x3 as one shift-add per column (the compiler's choice was two v_mad_u64_u32 per column)
 #pragma unroll
         for (int i = 0; i < 28; i++) {
             uint64_t t3;
@@ -177,7 +179,7 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
     // exchange 14 reduced limbs instead of 28 64-bit columns.  v_permlane16_swap exchanges the odd 16-lane rows of
     // its first operand with the even rows of its second: called on two copies of a register, one copy ends up
     // holding (own | partner) and the other (partner | own) by row, so their sum is own + partner in every lane.
-    if (c.nq >= 2) {   // (wave-uniform)
+    if (NQ >= 2) {
 #pragma unroll
         for (int i = 0; i < 14; i++) {
             const auto sw = __builtin_amdgcn_permlane16_swap(r.l[i], r.l[i], false, false);
@@ -189,7 +191,7 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
 #pragma unroll
         for (int i = 0; i < 14; i++) r.l[i] *= 3u;
     }
-    if (c.nq == 4) {   // (wave-uniform) the other half-wave holds the sum of the other two quarters
+    if (NQ == 4) {   // the other half-wave holds the sum of the other two quarters
 #pragma unroll
         for (int i = 0; i < 14; i++) {
             const auto sw = __builtin_amdgcn_permlane32_swap(r.l[i], r.l[i], false, false);
@@ -199,12 +201,13 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
     // value: two halves < 2 * 1.4 p; four quarters < 4 * (3 * 168 / 2520 + 1) p = 4.8 p; one lane: (12 * 7 * 13 / 2520 + 1) p =
     // 1.43 p (MUL), 1.56 p (SQR), 3.8 p (CSQR, above) (every operand bound of the staging code assumes v <= 6, CONJ and INV
     // v <= 5); limbs back below 2^28
-    f28_carry(r);
+    if (NQ >= 2 || TRIPLE) f28_carry(r);   // (one lane per coefficient, no tripling: the limbs left the extraction carried)
     return f28_pack(r);
 }
 template <int NT, bool TRIPLE>
 H2V_DI F28 coop_engine(const Coop &c, const int tab_row_byte) {
-    const F28Regs z = coop_accumulate<NT, TRIPLE>(c, tab_row_byte);
+    const F28Regs z = c.nq == 1 ? coop_accumulate<NT, TRIPLE, 1>(c, tab_row_byte)     // (wave-uniform: a kernel only ever takes one of these)
+                      : c.nq == 2 ? coop_accumulate<NT, TRIPLE, 2>(c, tab_row_byte) : coop_accumulate<NT, TRIPLE, 4>(c, tab_row_byte);
     return f28_unpack(z.a, z.b, z.c, z.d);
 }
 
