@@ -135,15 +135,17 @@ def test_in_flight_hint_changes_the_shape_not_the_verdicts(be, circuits):
         vk, td, pl, dp, ov = circuits[name]
         batch = synth.forge_batch(vk, td, 96, seed=61, plan=pl, workers=2)
         batch = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.3, seed=62, kinds=list(synth.CORRUPTIONS))
-        ws1, ws5 = be.Workspace(dp, 96), be.Workspace(dp, 96)
+        ws1, ws5, ws8 = be.Workspace(dp, 96), be.Workspace(dp, 96), be.Workspace(dp, 96)
         ws5.hint_in_flight(5)
+        ws8.hint_in_flight(8)     # from 6: the whole pipeline on the caller's stream
         a1 = dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws1)
         a5 = dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws5)
-        assert list(a1) == list(a5) == batch.expected
+        a8 = dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws8)
+        assert list(a1) == list(a5) == list(a8) == batch.expected
         assert ws1.timings().msm_lanes_per_term in (1, 2, 3) and ws5.timings().msm_lanes_per_term in (18, 3)
         with pytest.raises(be.H2VError):
             ws5.hint_in_flight(0)
-        ws1.close(); ws5.close()
+        ws1.close(); ws5.close(); ws8.close()
     # the split launch (per-proof terms two per lane beside the fixed-base lanes) needs a batch that does not fit one wave per SIMD
     vk, td, pl, dp, ov = circuits["atms_with_lookups"]
     batch = synth.forge_batch(vk, td, 2048, seed=63, plan=pl, workers=8)
