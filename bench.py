@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rlc-secondary", action="store_true", help="per-proof runs: skip the extra measurement of the RLC mode")
     ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--hint", type=int, default=0, help="h2v_workspace_hint_in_flight value (default: the steps in flight); the counter passes of "
+                                                     "tools/scripts/profile_round.sh run one step at a time with the shapes of the timed run")
     ap.add_argument("--timed-only", action="store_true",
                     help="launch nothing but warm-up + the timed steps (no in-flight probe, no one-step pass, no RLC secondary, no reject "
                          "dataset, no CPU baseline): the form profiled under rocprofv3, whose per-kernel averages then cover the same "
@@ -199,7 +201,7 @@ def main():
         """warmup + `steps` timed passes in `mode` with `inflight` steps in flight; returns (elapsed s, workspaces, accept)"""
         wss = [backend.Workspace(dp, B) for _ in range(inflight)]
         for w_ in wss:
-            w_.hint_in_flight(inflight)     # (from 4 up the library prefers launch shapes that issue fewer instructions)
+            w_.hint_in_flight(args.hint or inflight)     # (from 4 up the library prefers launch shapes that issue fewer instructions)
         # (the same few torch streams in every measurement of this process: every stream that was ever created keeps a
         #  hardware queue busy in the runtime's round-robin, and later measurements would collide with the earlier ones')
         while len(stream_pool) < inflight:

@@ -21,9 +21,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 grep "^{" $O/prof_$TAG.log | tail -1 > $O/${TAG}_bench_under_rocprof.json
 for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
   n=$(echo $c | cut -d" " -f1)
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${TAG}_$n -- python3 bench.py $ARGS --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > $O/pmc_${TAG}_$n.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${TAG}_$n -- python3 bench.py $ARGS --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 --hint $INF > $O/pmc_${TAG}_$n.log 2>&1 || exit 1
 done
-{ echo "# workload=$WL batch=$BATCH mode=$MODE tag=$TAG (rocprofv3 --pmc, separate passes; bench.py $ARGS --steps 2 --warmup 1 --inflight 1)"; python tools/pmc_summary.py $O/pmc_${TAG}_*; } > $O/${TAG}_pmc_summary.txt
+{ echo "# workload=$WL batch=$BATCH mode=$MODE tag=$TAG (rocprofv3 --pmc, separate passes; bench.py $ARGS --steps 2 --warmup 1 --inflight 1 --hint $INF)"; python tools/pmc_summary.py $O/pmc_${TAG}_*; } > $O/${TAG}_pmc_summary.txt
 grep -E "INSTS_VALU|FETCH|WRITE_SIZE|WAIT_ANY|WAVE_CYCLES" $O/${TAG}_pmc_summary.txt
 cat $O/prof_$TAG/*/*kernel_stats.csv | head -12
 cp $O/prof_$TAG/*/*kernel_stats.csv $O/${TAG}_kernel_stats.csv
