@@ -492,7 +492,7 @@ def test_exported_artefact_files_verify_on_gpu(be, circuits, tmp_path, capsys):
     assert capsys.readouterr().out.count("reject") == 2
 
 
-@pytest.mark.parametrize("name,n", [("lookup_table", 2048), ("atms_with_lookups", 2048), ("sha256", 1024), ("secp256k1", 512),
+@pytest.mark.parametrize("name,n", [("simple_mul", 4096), ("lookup_table", 2048), ("atms_with_lookups", 2048), ("sha256", 1024), ("secp256k1", 512),
                                     ("ivc", 1024)])
 def test_baseline_config_sizes(be, circuits, name, n):
     """The other BASELINE configurations at their full batch sizes: the verdict vector equals the construction (every
@@ -506,6 +506,12 @@ def test_baseline_config_sizes(be, circuits, name, n):
     ws = be.Workspace(dp, n)
     got = dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws)
     assert list(got) == batch.expected and 0 < sum(got) < n
+    # the launch shapes of a caller that keeps five batches in flight (two MSM terms per lane, narrow pairing engine from
+    # 2048 proofs up): the same vector
+    ws5 = be.Workspace(dp, n)
+    ws5.hint_in_flight(5)
+    assert list(dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws5)) == list(got)
+    ws5.close()
     order = list(range(n))
     random.Random(15).shuffle(order)
     perm = _permute(batch, order, n_pi)
