@@ -161,4 +161,47 @@ class Workspace {
     uint64_t n_ = 0;
 };
 
+// A verifier that keeps `depth` batches in flight (one workspace each, h2v_workspace_hint_in_flight(depth)): push() hands a
+// batch over (its host buffers may be reused at once) and returns the accept vector of the batch pushed `depth` calls
+// earlier, if there is one; drain() collects the rest in order.  depth 5 (per proof) / 11 (RLC) reach the device-resident
+// throughput on one MI355X (tools/bench_host_path.py).  Every batch must fit `max_batch`.
+class BatchStream {
+  public:
+    BatchStream(const VerifyingKey &vk, uint64_t max_batch, unsigned depth, bool rlc = false) : rlc_(rlc) {
+        if (depth == 0) throw Error(H2V_E_ARG, "BatchStream: depth must be at least 1");
+        for (unsigned k = 0; k < depth; k++) {
+            ws_.emplace_back(new Workspace(vk, max_batch));
+            ws_.back()->hint_in_flight(depth);
+        }
+    }
+    ~BatchStream() { for (Workspace *w : ws_) delete w; }
+    BatchStream(const BatchStream &) = delete;
+    BatchStream &operator=(const BatchStream &) = delete;
+    /// returns true and fills `done` when the batch pushed depth calls earlier has been collected
+    bool push(const h2v_batch &batch, std::vector<uint8_t> *done = nullptr) {
+        Workspace &w = *ws_[next_ % ws_.size()];
+        bool have = false;
+        if (next_ >= ws_.size()) {
+            std::vector<uint8_t> acc = w.wait();
+            if (done) *done = std::move(acc);
+            have = true;
+            collected_++;
+        }
+        w.submit(batch, rlc_);
+        next_++;
+        return have;
+    }
+    /// accept vectors of the batches still in flight, oldest first
+    std::vector<std::vector<uint8_t>> drain() {
+        std::vector<std::vector<uint8_t>> out;
+        for (; collected_ < next_; collected_++) out.push_back(ws_[collected_ % ws_.size()]->wait());
+        return out;
+    }
+
+  private:
+    std::vector<Workspace *> ws_;
+    uint64_t next_ = 0, collected_ = 0;
+    bool rlc_;
+};
+
 }  // namespace h2v

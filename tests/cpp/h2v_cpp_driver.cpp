@@ -73,6 +73,18 @@ int main(int argc, char **argv) {
         for (uint8_t a : w0.wait()) s0.push_back(a ? '1' : '0');
         for (uint8_t a : w1.wait()) s1.push_back(a ? '1' : '0');
         std::printf("stream0 %s\nstream1 %s\n", s0.c_str(), s1.c_str());
+        // seven batches through a stream of depth 3 (per proof, then RLC): every collected vector equals the blocking call's
+        for (int rlc = 0; rlc < 2; rlc++) {
+            h2v::BatchStream bs(vk, n, 3, rlc != 0);
+            std::vector<std::vector<uint8_t>> got;
+            std::vector<uint8_t> done;
+            for (int k = 0; k < 7; k++)
+                if (bs.push(batch, &done)) got.push_back(done);
+            for (auto &v : bs.drain()) got.push_back(v);
+            bool same = got.size() == 7;
+            for (auto &v : got) same = same && v == acc;
+            std::printf("batch_stream_%s %d\n", rlc ? "rlc" : "per_proof", same ? 1 : 0);
+        }
         // a consumed guard must refuse a second use; a wrong instance count must be refused by prepare
         bool refused = false;
         try {

@@ -66,3 +66,4 @@ def test_cpp_prepare_verify_on_gpu(driver, tmp_path):
     assert lines["rlc"] == want and lines["stream0"] == want and lines["stream1"] == want
     assert lines["rlc_fell_back"] == "1"          # the corrupted proofs are caught only by the pairing
     assert lines["misuse_refused"] == "1"
+    assert lines["batch_stream_per_proof"] == "1" and lines["batch_stream_rlc"] == "1"   # h2v::BatchStream, depth 3, seven batches

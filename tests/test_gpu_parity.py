@@ -127,6 +127,31 @@ def test_g1_msm(be, orc):
             assert r == orc.g1_msm(ss, ps)
 
 
+def test_batch_stream_keeps_batches_in_flight(be, circuits):
+    """backend.BatchStream (depth 4: the in-flight launch shapes) over nine batches of different content and size, per proof
+    and RLC: every collected vector is the blocking call's, in order."""
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    batches = []
+    for k in range(9):
+        n = 40 + 7 * k
+        b = synth.forge_batch(vk, td, n, seed=300 + k, plan=pl, workers=2)
+        b = synth.with_rejects(pl, b, vk.n_public_inputs, fraction=0.2, seed=400 + k, kinds=list(synth.CORRUPTIONS))
+        batches.append(b)
+    for rlc in (False, True):
+        bs = be.BatchStream(dp, 128, 4, rlc=rlc)
+        got, keep = [], []
+        for b in batches:
+            hb, k_ = dp.host_batch(b.proofs, b.proof_off, b.instances, b.committed)
+            keep.append(k_)
+            r = bs.push(hb, b.n)
+            if r is not None:
+                got.append(r)
+        got += bs.drain()
+        assert [list(a) for a, _fb in got] == [b.expected for b in batches], rlc
+        bs.close()
+
+
 def test_in_flight_hint_changes_the_shape_not_the_verdicts(be, circuits):
     """h2v_workspace_hint_in_flight(>= 4): the per-proof MSM runs two terms per lane (k_g1_msm_multi2, reported as 18) -
     the accept vector and the statuses stay those of the default shape."""
