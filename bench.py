@@ -281,6 +281,21 @@ def main():
     if args.timed_only:
         args.no_cpu_baseline = args.no_rlc_secondary = True
         inflight_candidates = inflight_candidates[:1]
+    # with several steps in flight the event-timed kernel durations include what the kernels lose to each other; a short
+    # pass with ONE step in flight gives the kernels' own durations beside them.  It runs FIRST: after runs with many
+    # streams the runtime may map the combiner's and the decompression's stream onto one hardware queue, and the event-timed
+    # duration of the second then includes its wait for the first (combiner 1.5 instead of 0.66 ms).
+    kernel_ms_alone = None
+    if args.mode == "per-proof" and not args.timed_only and len(inflight_candidates) > 1:
+        _el1, wss1, _acc1 = timed_run("per-proof", 1, 5, 3, False)
+        a1 = {"transcript_combiner": 0.0, "g1_decompress": 0.0, "g1_msm": 0.0, "pairing": 0.0}
+        for j in range(5):
+            tm = wss1[0].timings(j)
+            a1["transcript_combiner"] += tm.transcript_combiner_ms / 5; a1["g1_decompress"] += tm.g1_decompress_ms / 5
+            a1["g1_msm"] += tm.g1_msm_ms / 5; a1["pairing"] += tm.pairing_ms / 5
+        kernel_ms_alone = dict(a1, ms_per_step=_el1 / 5 * 1e3, msm_lpt=tm.msm_lanes_per_term or 2, pair_lanes=tm.pairing_lanes_per_proof or 32)
+        wss1[0].close()
+        del wss1
     inflight, inflight_probe = pick_inflight(args.mode, inflight_candidates)
     elapsed, wss, accept = timed_run(args.mode, inflight, args.steps, args.warmup, True)
 
@@ -324,21 +339,11 @@ def main():
         batch_latency_ms = span / k_steps
         all_batch_ok = None
 
-    # with several steps in flight the event-timed kernel durations include what the kernels lose to each other; a short
-    # pass with ONE step in flight gives the kernels' own durations beside them
-    kernel_ms_alone = None
-    if inflight > 1 and args.mode == "per-proof" and not args.timed_only:
+    if inflight <= 1:
+        kernel_ms_alone = None
+    if kernel_ms_alone is not None:
         for w_ in wss[1:]:
             w_.close()            # (their event rings have been read; their streams give their hardware queues back)
-        _el1, wss1, _acc1 = timed_run("per-proof", 1, 5, 3, False)
-        a1 = {"transcript_combiner": 0.0, "g1_decompress": 0.0, "g1_msm": 0.0, "pairing": 0.0}
-        for j in range(5):
-            tm = wss1[0].timings(j)
-            a1["transcript_combiner"] += tm.transcript_combiner_ms / 5; a1["g1_decompress"] += tm.g1_decompress_ms / 5
-            a1["g1_msm"] += tm.g1_msm_ms / 5; a1["pairing"] += tm.pairing_ms / 5
-        kernel_ms_alone = dict(a1, ms_per_step=_el1 / 5 * 1e3, msm_lpt=tm.msm_lanes_per_term or 2, pair_lanes=tm.pairing_lanes_per_proof or 32)
-        wss1[0].close()
-        del wss1
     n_accept = int(accept.sum())
     ok_all = n_accept == B  # the synthetic batch is 100 % accepting
     if world > 1:
