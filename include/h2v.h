@@ -87,6 +87,28 @@ int h2v_plan_info(const h2v_plan *plan, uint32_t *proof_len, uint32_t *n_public_
  * (they never write past a buffer).  One workspace serves one call at a time. */
 int h2v_workspace_create(const h2v_plan *plan, uint64_t max_batch, h2v_workspace **out);
 void h2v_workspace_free(h2v_workspace *ws);
+/* (round 3) LANES: the pipelining that callers used to build from several workspaces and streams, inside the library.
+ * A laned workspace owns n_lanes sub-workspaces of `chunk` proofs each, every one with its own library-owned stream.  A verify
+ * call on it (device-resident, host-buffer or RLC form, any n <= max_batch) is cut into chunks of at most `chunk` proofs
+ * that go round robin through the lanes, so that the decompression / combiner kernels of one chunk run beside the MSM and
+ * pairing kernels of others; accept[] / status[] are written in place, chunk by chunk, and the caller's stream waits for
+ * the last one (unless joins are deferred, below).  Device memory is n_lanes x chunk proofs' worth, whatever max_batch is.
+ * Verdicts never depend on n_lanes or chunk (tests/test_gpu_parity.py::test_verdicts_do_not_depend_on_the_chunking); in
+ * RLC mode every chunk is its own batch check.
+ *   n_lanes = 0 / chunk = 0: the library's choice for this plan (chunk = the batch that gives every kernel one wave per
+ *   SIMD: 4096 proofs for 16 MSM terms, 1024 for 60; 5 lanes per-proof).  h2v_workspace_create(plan, max_batch) itself
+ *   returns a laned workspace when max_batch >= 2 x that chunk.  n_lanes <= 16. */
+int h2v_workspace_create_lanes(const h2v_plan *plan, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk, h2v_workspace **out);
+/* Deferred joins (laned workspaces): with defer = 1 a device-resident verify call returns without making the caller's stream
+ * wait for its chunks, so the chunks of CONSECUTIVE calls overlap in the lanes - one workspace then does what five
+ * workspaces on five streams did (a stream of batches: DESIGN.md section 6).  The inputs of a call must stay untouched, and
+ * its accept[] / status[] unread, until h2v_workspace_join(ws, stream) has been called and `stream` has reached that point
+ * (stream = NULL: block the host instead).  Calls still start in submission order, each after whatever was enqueued on its
+ * `stream` argument before it. */
+int h2v_workspace_defer_joins(h2v_workspace *ws, int defer);
+int h2v_workspace_join(h2v_workspace *ws, void *stream);
+/* lanes and chunk size of a workspace (1 lane = not laned) */
+int h2v_workspace_lanes(const h2v_workspace *ws, uint32_t *n_lanes, uint32_t *chunk);
 /* (new) Tuning hint: the caller keeps n_in_flight batches in flight on this device (each on its own workspace).  From 4 up
  * the launcher prefers shapes that issue fewer instructions over shapes with shorter dependent chains (per-proof MSM: two
  * terms per lane on one accumulator; the narrow pairing engine from 2 x #SIMDs proofs; from 6 the whole per-proof pipeline on

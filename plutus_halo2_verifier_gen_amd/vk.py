@@ -326,8 +326,9 @@ def expr_op_counts(e, acc=None):
     elif t == "neg":
         acc["neg"] += 1
         expr_op_counts(e[1], acc)
-    elif t == "scaled":
+    elif t == "scaled":   # one multiplication by one constant (`from_int` in the reference's ScalarOps)
         acc["mul"] += 1
+        acc["const"] += 1
         expr_op_counts(e[1], acc)
     elif t == "sum":
         acc["add"] += 1
@@ -483,24 +484,157 @@ def atms_with_lookups_vk(seed: int = 0x48325633):
                       gate_ops={"mul": 60, "add": 50, "neg": 10}, adv_rot_sets=adv, n_pi=2, n_ci=0)
 
 
-def sha256_vk(seed: int = 0x48325634):
-    """sha256-chip shape (/root/reference/docs/chip_profiles.json "sha256"; examples/sha256.rs:42,133): 8 advice,
-    25 fixed, 7 copy-constraint columns, 2 lookup arguments (6 expressions), 22 gate expressions
-    (156 mul / 173 add / 22 neg), degree 5, committed instance column (= identity in the example), 32 public
-    inputs, commitment-map set sizes [36,3,2,2,8]."""
-    adv = [[0, 1, -1]] * 2 + [[0, 1]] * 1 + [[0]] * 5
-    return _shaped_vk("sha256", seed, k=17, degree=5, n_adv=8, n_fix=25, n_cc=7,
-                      lookup_arg_exprs=[3, 3], gate_exprs=22,
-                      gate_ops={"mul": 156, "add": 173, "neg": 22}, adv_rot_sets=adv, n_pi=32, n_ci=1)
+def _exact_gate_exprs(rng, n_adv_q, n_fix_q, n_exprs, n_mul, n_add, n_neg, n_const, max_factors=4):
+    """`n_exprs` gate polynomials whose Expression trees hold EXACTLY n_mul multiplications (Product or Scaled nodes),
+    n_add Sum nodes, n_neg Negated nodes and n_const constants in total - the figures the reference's cost model keeps
+    per chip (stats/chips/types/scalar_ops.rs; a Scaled node is one multiplication by one `from_int` constant).
+    Shape: every polynomial is a sum of terms, a term a product of 1..max_factors advice / fixed evaluations, optionally
+    scaled by a constant, optionally negated - sums of low-degree products, as foreign-field and spread-table gates are
+    (a chain of multiplications by fresh leaves would exceed the circuit degree long before 641 multiplications)."""
+    n_terms = n_add + n_exprs
+    assert n_const <= n_terms and n_neg <= n_terms
+    extra = n_mul - n_const            # Product nodes = sum over terms of (factors - 1)
+    assert 0 <= extra <= n_terms * (max_factors - 1), "op counts do not fit sums of products of this degree"
+    factors = [1] * n_terms
+    open_terms = list(range(n_terms))
+    for _ in range(extra):
+        t = open_terms[rng.randrange(len(open_terms))]
+        factors[t] += 1
+        if factors[t] == max_factors:
+            open_terms.remove(t)
+    scaled_terms = set(rng.sample(range(n_terms), n_const))
+    neg_terms = set(rng.sample(range(n_terms), n_neg))
+
+    def leaf():
+        return advice(rng.randrange(n_adv_q)) if rng.random() < 0.6 else fixed(rng.randrange(n_fix_q))
+
+    terms = []
+    for t in range(n_terms):
+        e = leaf()
+        for _ in range(factors[t] - 1):
+            e = mul(e, leaf())
+        if t in scaled_terms:
+            e = scaled(e, rng.randrange(1, bls.R))
+        if t in neg_terms:
+            e = neg(e)
+        terms.append(e)
+    rng.shuffle(terms)
+    per = [1 + c for c in _split_counts(rng, n_add, n_exprs)]
+    out, k = [], 0
+    for n in per:
+        e = terms[k]
+        for t in terms[k + 1:k + n]:
+            e = add(e, t)
+        out.append(e)
+        k += n
+    assert k == n_terms
+    return out
 
 
-def secp256k1_vk(seed: int = 0x48325635):
-    """secp256k1 foreign-field chip shape (docs/chip_profiles.json "secp256k1"): 9 advice, 23 fixed, 10 copy-
-    constraint columns, 1 lookup argument (10 expressions), 22 gate expressions (641 mul / 476 add / 67 neg)."""
-    adv = [[0, 1, -1]] * 2 + [[0, 1]] * 2 + [[0]] * 5
-    return _shaped_vk("secp256k1", seed, k=17, degree=5, n_adv=9, n_fix=23, n_cc=10,
-                      lookup_arg_exprs=[10], gate_exprs=22,
-                      gate_ops={"mul": 641, "add": 476, "neg": 67}, adv_rot_sets=adv, n_pi=4, n_ci=1)
+def chip_profile_vk(name, seed, profile, *, advice_rotations, lookup_input, n_adv_cc, k=17, bf=6, n_pi=1, n_ci=0,
+                    instance_in_permutation=False):
+    """A key with the shape the reference's chip profile records (docs/chip_profiles.json, written by
+    src/plutus_gen/stats/profile.rs:54-162; the fixture tests/golden/reference_kats.json "chip_profiles" holds the
+    numbers): advice / fixed columns, copy-constrained columns, lookup arguments, gate-expression count and op counts,
+    and - through the rotation sets - the commitment map.  What the profile does not hold is given by the caller and
+    cited there: which rotations each advice column is queried at and what one lookup input expression looks like.
+
+    Conventions of the profile that this follows (tests/test_host_logic.py::test_chip_shapes_match_reference_profile):
+      * pi = 1, ci = 0, and `copy_constraints` EXCLUDES the instance column (profile.rs:28-31): with
+        instance_in_permutation=False the permutation runs over n_adv_cc advice columns and copy_constraints - n_adv_cc
+        fixed columns only.  The example wrappers put the public-input column and the committed-instance column back
+        (stats/estimate/build.rs:166-177);
+      * lookup ARGUMENTS = (proof_commitments - advice - ceil(cc / (degree - 2)) - degree - 2) / 3, `lookups` = their
+        expressions in total; the (degree - 1) + 1 vanishing commitments and the 2 of the multi-open argument are the rest;
+      * gate_ops / lookup_ops are the per-expression counts plus one add and one mul per expression after the first of
+        every gate / argument (ScalarExpression::batch_expressions, stats/chips/types/expression.rs:52-66)."""
+    rng = random.Random(seed)
+    degree = profile["degree"]
+    n_adv, n_fix, cc = profile["advice_cols"], profile["fixed_cols"], profile["copy_constraints"]
+    assert len(advice_rotations) == n_adv
+    chunks = -(-cc // (degree - 2))
+    n_lookup_args, rem = divmod(profile["proof_commitments"] - n_adv - chunks - degree - 2, 3)
+    assert rem == 0 and n_lookup_args >= 0
+    aq = [(c, r) for c, rots in enumerate(advice_rotations) for r in rots]
+    fq = [(c, 0) for c in range(n_fix)]
+    g = profile["gate_ops"]
+    batching = profile["gate_expressions"] - profile["gates"]
+    gates = _exact_gate_exprs(rng, len(aq), len(fq), profile["gate_expressions"], g["mul"] - batching,
+                              g["add"] - batching, g["neg"], g["from_int"])
+    lookups = []
+    if n_lookup_args:
+        per_arg, rem = divmod(profile["lookups"], n_lookup_args)
+        assert rem == 0
+        for _ in range(n_lookup_args):
+            ins = [lookup_input(rng, len(aq), len(fq)) for _ in range(per_arg)]
+            tabs = [fixed(rng.randrange(len(fq))) for _ in range(per_arg)]
+            lookups.append((ins, tabs))
+    cur_adv = [c for c, rots in enumerate(advice_rotations) if 0 in rots]
+    perm_cols = [("advice", c) for c in cur_adv[:n_adv_cc]] + [("fixed", c) for c in range(cc - n_adv_cc)]
+    assert len(perm_cols) == cc
+    iq = []
+    if n_ci:
+        iq.append((0, 0))               # the committed column is opened at x (extraction/mod.rs:126-138)
+    if instance_in_permutation:
+        if n_ci:
+            perm_cols.append(("instance", 0))
+        perm_cols.append(("instance", n_ci))
+        iq.append((n_ci, 0))
+    return _finish(name, rng, k=k, bf=bf, degree=degree, n_adv=n_adv, n_fix=n_fix, aq=aq, fq=fq, iq=iq, gates=gates,
+                   lookups=lookups, trash=[], perm_cols=perm_cols, n_pi=n_pi, n_ci=n_ci)
+
+
+# docs/chip_profiles.json "sha256" / "secp256k1" as committed in the reference (the CPU suite checks these literals
+# against the extracted fixture, so a drift of either side fails a test).
+SHA256_PROFILE = {"degree": 5, "advice_cols": 8, "fixed_cols": 25, "copy_constraints": 7, "gates": 14,
+                  "gate_expressions": 22, "lookups": 6, "proof_commitments": 24, "vk_commitments": 32, "evals": 64,
+                  "gate_ops": {"neg": 22, "add": 173, "sub": 0, "mul": 156, "from_int": 116},
+                  "lookup_ops": {"neg": 0, "add": 4, "sub": 0, "mul": 10, "from_int": 0}, "proof_size": 3200,
+                  "commitment_map_sets": [[1, 36], [2, 3], [3, 2], [2, 2], [3, 8]]}
+SECP256K1_PROFILE = {"degree": 5, "advice_cols": 9, "fixed_cols": 23, "copy_constraints": 10, "gates": 11,
+                     "gate_expressions": 22, "lookups": 10, "proof_commitments": 23, "vk_commitments": 33, "evals": 64,
+                     "gate_ops": {"neg": 67, "add": 476, "sub": 0, "mul": 641, "from_int": 403},
+                     "lookup_ops": {"neg": 10, "add": 19, "sub": 0, "mul": 19, "from_int": 10}, "proof_size": 3152,
+                     "commitment_map_sets": [[1, 37], [2, 2], [3, 3], [2, 2], [3, 7]]}
+
+
+def sha256_vk(seed: int = 0x48325634, chip_alone: bool = False):
+    """sha256 chip shape, pinned on /root/reference/docs/chip_profiles.json "sha256" (SHA256_PROFILE): 8 advice columns,
+    ALL queried at {prev, cur, next} (stats/chips/primitives/hash/sha256.rs:9-22; six of them copy-constrained), 25 fixed
+    at {cur}, 7 copy-constrained columns (6 advice + native's fixed_values, chips/primitives/native.rs:34), 2 lookup
+    arguments of 3 expressions `q_lookup * advice` (sha256.rs:95-110), 22 gate expressions in 14 gates with 148 mul /
+    165 add / 22 neg / 116 constants of their own, degree 5 => commitment-map sets
+    {cur}: 36, {cur,next}: 3, {cur,next,last}: 2, {prev,cur}: 2, {prev,cur,next}: 8 and 57 MSM terms.
+    chip_alone=True is the profile's own setting (pi = 1, ci = 0, instance column outside the permutation).  The
+    default is the example's wrapper (examples/sha256.rs:42,131-137: 32 public inputs, one committed instance column
+    = identity): both instance columns join the permutation (build.rs:166-177: 9 columns, still 3 chunks) and the
+    committed column is opened at x: {cur} 36 -> 39, 60 MSM terms, 3 more evaluations.
+    The profile's `evals` = 64 / `proof_size` = 3200 count one evaluation per advice / fixed COLUMN (profile.rs:112);
+    a proof carries one per QUERY (24 + 25 here, as stats/estimate/build.rs:186-188 counts them): 80 scalars, 3712 B."""
+    adv = [[-1, 0, 1]] * 8
+    return chip_profile_vk("sha256", seed, SHA256_PROFILE, advice_rotations=adv, n_adv_cc=6,
+                           lookup_input=lambda rng, na, nf: mul(fixed(rng.randrange(nf)), advice(rng.randrange(na))),
+                           n_pi=1 if chip_alone else 32, n_ci=0 if chip_alone else 1,
+                           instance_in_permutation=not chip_alone)
+
+
+def secp256k1_vk(seed: int = 0x48325635, chip_alone: bool = False):
+    """secp256k1 foreign-field chip shape, pinned on docs/chip_profiles.json "secp256k1" (SECP256K1_PROFILE): 9 advice
+    columns - seven at {prev, cur, next}, one at {prev, cur}, one at {cur}: the only assignment that gives the profile's
+    commitment map {cur}: 37 = 23 fixed + 10 sigma + 2 vanishing + 1 permuted table + 1 advice, {cur,next}: 2 = z_0 + the
+    lookup product, {cur,next,last}: 3 = z_1..z_3, {prev,cur}: 2 = permuted input + 1 advice, {prev,cur,next}: 7 -,
+    23 fixed, 10 copy-constrained columns (9 advice + fixed_values), 1 lookup argument of 10 expressions (one negation,
+    one addition, one multiplication, one constant each), 22 gate expressions in 11 gates with 630 mul / 465 add /
+    67 neg / 403 constants of their own, degree 5 => 57 MSM terms.
+    Default = wrapper with 4 public inputs and a committed instance column (12 permutation columns, still 4 chunks;
+    60 terms); chip_alone=True = the profile's setting.  Proof: 79 scalars / 3632 B against the profile's per-column
+    count of 64 / 3152 B (see sha256_vk)."""
+    adv = [[-1, 0, 1]] * 7 + [[-1, 0]] + [[0]]
+    return chip_profile_vk("secp256k1", seed, SECP256K1_PROFILE, advice_rotations=adv, n_adv_cc=9,
+                           lookup_input=lambda rng, na, nf: scaled(sub(advice(rng.randrange(na)), advice(rng.randrange(na))),
+                                                                   rng.randrange(1, bls.R)),
+                           n_pi=1 if chip_alone else 4, n_ci=0 if chip_alone else 1,
+                           instance_in_permutation=not chip_alone)
 
 
 def trashcan_mix_vk(seed: int = 0x48325637):

@@ -14,6 +14,9 @@ Sources:
   aiken-verifier/templates/gates_test.hbs:9-79              lookup-identity KAT (inputs -> expected)
   aiken-verifier/templates/verification_h2.hbs:24, transcript.ak:99, vk_constants.hbs:18   constants
   aiken-verifier/aiken_halo2/lib/bls_utils.ak:119-128       g1_from_coords(x, y') == generator (sign-of-y semantics)
+  docs/chip_profiles.json                                   per-chip shape numbers (columns, copy constraints, lookups,
+                                                            gate op counts, proof / VK commitments, evals, commitment-map
+                                                            set sizes, proof bytes) that BASELINE configs[3] / [4] are built from
 """
 import json
 import os
@@ -125,6 +128,20 @@ def main():
     # function takes only the SIGN of y (the recursion fold rebuilds the accumulator points this way)
     cg = hexes(test_block(bu, "coord_generator"))
     kats["g1_from_coords_generator"] = {"x": cg[0], "y": cg[1]}
+    # docs/chip_profiles.json (written by src/plutus_gen/stats/profile.rs:54-162 at pi = 1, ci = 0): the numbers only.
+    # commitment_map is kept as [rotation-set size, #commitments] pairs in the file's order, which is the BTreeMap order
+    # of RotationSet (stats/chips/types/rotation_set.rs:2-11: derive(Ord) over first, prev, curr, next, next2, next3, last)
+    prof = json.loads(read("docs/chip_profiles.json"))
+    keep = ("degree", "advice_cols", "fixed_cols", "copy_constraints", "nb_lookup_tables", "gates", "gate_expressions",
+            "lookups", "trash", "proof_commitments", "vk_commitments", "evals", "gate_ops", "lookup_ops", "trash_ops",
+            "proof_size", "vk_size")
+    kats["chip_profiles"] = {}
+    for chip in ("sha256", "secp256k1"):
+        p = prof[chip]
+        d = {k: p[k] for k in keep}
+        d["commitment_map_sets"] = [[s[0], len(s)] for s in p["commitment_map"]]
+        assert all(len(set(s)) == 1 for s in p["commitment_map"])
+        kats["chip_profiles"][chip] = d
     with open(OUT, "w") as f:
         json.dump(kats, f, indent=1, sort_keys=True)
     print("wrote", OUT, len(json.dumps(kats)), "bytes")

@@ -137,7 +137,98 @@ def test_plan_blob_layout(simple):
     vk2, _ = V.sha256_vk()
     pl2 = PL.compile_plan(vk2)
     assert sum(1 for k, _ in pl2.terms if k == PL.TERM_COMMITTED_INSTANCE) == 1
-    assert pl2.n_terms == 58
+    assert pl2.n_terms == 60
+
+
+# rotation sets in the BTreeMap order of the reference's RotationSet (stats/chips/types/rotation_set.rs:2-11: Ord over the
+# flags first, prev, curr, next, next2, next3, last; false < true) - the order docs/chip_profiles.json lists the sets in
+_PROFILE_SET_ORDER = [(0,), (0, 1), (PL.ROT_LAST, 0, 1), (-1, 0), (-1, 0, 1)]
+
+
+def _set_sizes(pl):
+    sizes = {}
+    for e in pl.commitment_map:
+        key = tuple(r for r, _ in e["pairs"])
+        sizes[key] = sizes.get(key, 0) + 1
+    assert set(sizes) <= set(_PROFILE_SET_ORDER)
+    return [[len(k), sizes[k]] for k in _PROFILE_SET_ORDER if k in sizes]
+
+
+@pytest.mark.parametrize("name", ["sha256", "secp256k1"])
+def test_chip_shapes_match_reference_profile(kats, name):
+    """BASELINE configs[3] / [4] are built on /root/reference/docs/chip_profiles.json (fixture "chip_profiles", extracted by
+    tests/golden/make_reference_fixtures.py).  The chip-alone variant of the synthetic key (pi = 1, ci = 0, the profile's
+    own setting) compiles to EXACTLY the profile's numbers; the example-wrapper variant differs from it by the deltas
+    asserted one by one below."""
+    prof = kats["chip_profiles"][name]
+    mine = {"sha256": V.SHA256_PROFILE, "secp256k1": V.SECP256K1_PROFILE}[name]
+    for k, v in mine.items():
+        assert prof[k] == v, k                      # the literals in vk.py are the reference's
+    vk, _ = V.BUILDERS[name](chip_alone=True)
+    V.validate(vk)
+    pl = PL.compile_plan(vk)
+    d = prof["degree"]
+    assert vk.cs_degree == d and vk.num_advice_columns == prof["advice_cols"] and vk.num_fixed_columns == prof["fixed_cols"]
+    assert len(vk.permutation_columns) == prof["copy_constraints"] and vk.n_public_inputs == 1 and vk.n_committed_instances == 0
+    assert len(vk.gates) == prof["gate_expressions"]
+    assert sum(len(i) for i, _ in vk.lookups) == prof["lookups"]
+    # commitments: the proof's G1 count and the VK's
+    assert len(pl.points) == prof["proof_commitments"]
+    assert len(vk.fixed_commitments) + len(vk.permutation_commitments) == prof["vk_commitments"]
+    # the commitment map, set by set in the profile's order (stats/estimate/build.rs:252-273 / profile.rs:121-132)
+    assert _set_sizes(pl) == prof["commitment_map_sets"]
+    n_map = sum(c for _, c in prof["commitment_map_sets"])
+    assert len(pl.commitment_map) == n_map
+    # MSM width: every commitment of the map, vanishing_g expanded over its degree - 1 splits, + F, -G1, pi (App. A.3)
+    assert pl.n_terms == (n_map - 1) + (d - 1) + 3 == 57
+    # gate / lookup op counts: the profile's figures are the expressions' own plus one add + one mul per batched
+    # expression (ScalarExpression::batch_expressions, stats/chips/types/expression.rs:52-66)
+    own = {"neg": 0, "add": 0, "mul": 0, "const": 0}
+    for g in vk.gates:
+        V.expr_op_counts(g, own)
+    batching = prof["gate_expressions"] - prof["gates"]
+    assert own == {"neg": prof["gate_ops"]["neg"], "add": prof["gate_ops"]["add"] - batching,
+                   "mul": prof["gate_ops"]["mul"] - batching, "const": prof["gate_ops"]["from_int"]}
+    assert max(V.expr_degree(g) for g in vk.gates) <= d
+    lk = {"neg": 0, "add": 0, "mul": 0, "const": 0}
+    for ins, tabs in vk.lookups:
+        for e in list(ins) + list(tabs):
+            V.expr_op_counts(e, lk)
+    lbatch = prof["lookups"] - len(vk.lookups)
+    assert lk == {"neg": prof["lookup_ops"]["neg"], "add": prof["lookup_ops"]["add"] - lbatch,
+                  "mul": prof["lookup_ops"]["mul"] - lbatch, "const": prof["lookup_ops"]["from_int"]}
+    # evaluations and proof bytes.  The profile passes the number of advice + fixed COLUMNS as `nb_evaluations`
+    # (profile.rs:112), the estimator proper counts one evaluation per QUERY (estimate/build.rs:186-188) and so does a
+    # proof: the difference is exactly (#advice queries - #advice columns) scalars (fixed columns are queried once)
+    n_fr = (pl.proof_len - 48 * len(pl.points)) // 32
+    per_query_extra = len(vk.advice_queries) - vk.num_advice_columns
+    assert len(vk.fixed_queries) == vk.num_fixed_columns
+    assert n_fr == prof["evals"] + per_query_extra
+    assert pl.proof_len == prof["proof_size"] + 32 * per_query_extra
+    assert pl.proof_len == {"sha256": 3712, "secp256k1": 3632}[name]
+    # App. A.1 closed form with this key's counts
+    L, cc, S = len(vk.lookups), len(vk.permutation_columns), len(prof["commitment_map_sets"])
+    chunks = -(-cc // (d - 2))
+    assert len(pl.points) == vk.num_advice_columns + 3 * L + chunks + 1 + (d - 1) + 2
+    assert n_fr == len(vk.advice_queries) + len(vk.fixed_queries) + 1 + cc + (3 * chunks - 1) + 5 * L + S
+
+    # ---- the example wrapper (examples/sha256.rs:42,131-137: 32 public inputs + one committed instance column)
+    wk, _ = V.BUILDERS[name]()
+    wp = PL.compile_plan(wk)
+    assert wk.n_committed_instances == 1 and wk.n_public_inputs == {"sha256": 32, "secp256k1": 4}[name]
+    assert wk.gates == vk.gates and wk.lookups == vk.lookups and wk.advice_queries == vk.advice_queries
+    # both instance columns are copy-constrained (estimate/build.rs:166-177): two more sigma commitments, same chunk count
+    assert wk.permutation_columns == vk.permutation_columns + [("instance", 0), ("instance", 1)]
+    assert -(-len(wk.permutation_columns) // (d - 2)) == chunks and len(wp.points) == len(pl.points)
+    assert len(wk.permutation_commitments) == len(vk.permutation_commitments) + 2
+    # the committed column is opened at x: {cur} grows by the two sigmas + that column, nothing else moves
+    want = [list(x) for x in prof["commitment_map_sets"]]
+    want[0][1] += 3
+    assert _set_sizes(wp) == want
+    assert wp.n_terms == pl.n_terms + 3 and sum(1 for k, _ in wp.terms if k == PL.TERM_COMMITTED_INSTANCE) == 1
+    # three more evaluations in the proof (the committed column's and the two sigmas'): 96 bytes
+    assert wp.proof_len == pl.proof_len + 96
+    assert wp.stream_len == pl.stream_len + 96 + 3 + 49 + 33 * (wk.n_public_inputs - 1)
 
 
 def test_vk_json_roundtrip():
