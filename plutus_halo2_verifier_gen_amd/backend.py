@@ -60,7 +60,8 @@ def _rlc_opts(seed, one_stream: bool = False):
 
 EXPORTS = [
     "h2v_plan_load", "h2v_plan_free", "h2v_plan_info", "h2v_workspace_create", "h2v_workspace_free",
-    "h2v_workspace_timings", "h2v_workspace_hint_in_flight",
+    "h2v_workspace_timings", "h2v_workspace_hint_in_flight", "h2v_workspace_create_lanes", "h2v_workspace_defer_joins",
+    "h2v_workspace_join", "h2v_workspace_lanes",
     "h2v_verify_batch", "h2v_verify_batch_submit", "h2v_verify_batch_wait", "h2v_verify_batch_device", "h2v_verify_batch_rlc", "h2v_verify_batch_rlc_device",
     "h2v_workspace_rlc_result", "h2v_probe_g1_msm_pippenger", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
     "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_quad_madd", "h2v_probe_pairing", "h2v_probe_pairing_ex",
@@ -86,6 +87,10 @@ def lib():
         L.h2v_plan_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4
         L.h2v_workspace_create.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         L.h2v_workspace_free.argtypes = [C.c_void_p]
+        L.h2v_workspace_create_lanes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.h2v_workspace_defer_joins.argtypes = [C.c_void_p, C.c_int]
+        L.h2v_workspace_join.argtypes = [C.c_void_p, C.c_void_p]
+        L.h2v_workspace_lanes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.h2v_workspace_timings.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Timings)]
         L.h2v_verify_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
         L.h2v_verify_batch_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -235,10 +240,31 @@ class DevicePlan:
 
 
 class Workspace:
-    def __init__(self, plan: DevicePlan, max_batch: int):
+    """h2v_workspace.  lanes / chunk given (0 = the library's choice): a LANED workspace (h2v_workspace_create_lanes) -
+    calls on it are cut into chunks that are pipelined through library-owned lanes; plain Workspace(plan, n) is laned by
+    itself from twice the plan's chunk size up."""
+
+    def __init__(self, plan: DevicePlan, max_batch: int, lanes: Optional[int] = None, chunk: Optional[int] = None):
         self._h = C.c_void_p()
-        check(lib().h2v_workspace_create(plan.handle, max_batch, C.byref(self._h)))
+        if lanes is None and chunk is None:
+            check(lib().h2v_workspace_create(plan.handle, max_batch, C.byref(self._h)))
+        else:
+            check(lib().h2v_workspace_create_lanes(plan.handle, max_batch, lanes or 0, chunk or 0, C.byref(self._h)))
         self.max_batch = max_batch
+
+    def lanes(self):
+        """(number of lanes, chunk size); (1, max_batch) for a workspace that is not laned"""
+        a, b = C.c_uint32(), C.c_uint32()
+        check(lib().h2v_workspace_lanes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def defer_joins(self, on: bool = True) -> None:
+        """h2v_workspace_defer_joins: device-resident calls return without making the caller's stream wait, so that
+        consecutive calls overlap in the lanes; join() orders a stream behind everything submitted so far."""
+        check(lib().h2v_workspace_defer_joins(self._h, 1 if on else 0))
+
+    def join(self, stream=None) -> None:
+        check(lib().h2v_workspace_join(self._h, stream))
 
     @property
     def handle(self):

@@ -92,6 +92,27 @@ struct h2v_workspace {
     uint8_t ring_pipes[RING] = {}, ring_split[RING] = {}, ring_lpt[RING] = {}, ring_pair[RING] = {};
     uint64_t calls = 0;
     struct RlcWs *rlc = nullptr;   // buffers of the RLC batch mode, created by its first call
+    hipEvent_t p1_event = nullptr;  // (owned by the parent of a lane) recorded when phase 1 of a call on this workspace is enqueued
+    int one_stream_mode = -1;      // lanes: 1 = the whole pipeline on the stream it is given (-1: decided from the hint)
+    // ---- lanes (h2v_workspace_create_lanes): a laned workspace owns no kernel buffers of its own, only n_lanes ordinary
+    // workspaces of `chunk` proofs and one library-owned stream per lane.  A verify call is cut into chunks that go round
+    // robin through the lanes; chunk c of a call runs entirely on lane_st[lane of c], behind that lane's earlier chunks.
+    static constexpr int MAXL = 16;
+    uint32_t n_lanes = 0, chunk = 0;
+    h2v_workspace *lane[MAXL] = {};
+    hipStream_t lane_st[MAXL] = {};
+    hipEvent_t lane_ev[MAXL] = {};         // end of the lane's most recent chunk
+    hipEvent_t lane_p1[MAXL] = {};         // end of phase 1 (decompression + combiner) of the lane's most recent chunk
+    bool lane_busy[MAXL] = {};             // work enqueued since the last join
+    bool defer_joins = false;
+    int stagger = 1;                        // chunk c starts its phase 1 when chunk c - 1 has finished its own
+    uint64_t next_lane = 0;                 // round-robin position (persists across calls: consecutive calls interleave)
+    uint64_t last_p1_lane = ~0ull;
+    // per call (ring): number of chunks, first lane, and every lane's call counters when the call had been enqueued -
+    // what h2v_workspace_timings / _rlc_result need to find the chunks' event sets in the lanes' own rings
+    uint32_t lring_chunks[RING] = {}, lring_first[RING] = {};
+    uint64_t lring_calls[RING][MAXL] = {}, lring_rlc_calls[RING][MAXL] = {};
+    uint8_t lring_rlc[RING] = {};
 };
 
 // LDS left for the combiner's register file in a block: 160 KB minus the 8 KB hash buffer and 1 KB of slack
@@ -355,6 +376,14 @@ extern "C" int h2v_plan_trace_slots(const h2v_plan *p, uint32_t *slot_ids, uint3
 static void rlc_release(struct RlcWs *r);
 static void ws_release(h2v_workspace *w) {
     (void)hipSetDevice(w->device);
+    for (uint32_t l = 0; l < w->n_lanes; l++) {
+        if (w->lane_st[l]) { (void)hipStreamSynchronize(w->lane_st[l]); }
+        if (w->lane[l]) { ws_release(w->lane[l]); delete w->lane[l]; w->lane[l] = nullptr; }
+        if (w->lane_st[l]) (void)hipStreamDestroy(w->lane_st[l]);
+        if (w->lane_ev[l]) (void)hipEventDestroy(w->lane_ev[l]);
+        if (w->lane_p1[l]) (void)hipEventDestroy(w->lane_p1[l]);
+    }
+    w->n_lanes = 0;
     if (w->rlc) { rlc_release(w->rlc); w->rlc = nullptr; }
     void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->er_fix, w->dec_ctr, w->accept, w->in_block, w->msm_tab,
                     w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2, w->pt_tab};
@@ -420,9 +449,79 @@ static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bo
     *out = w;
     return H2V_OK;
 }
+// Chunk size of the lanes: the batch that gives the kernels of the per-proof pipeline about one wave per SIMD - the merged
+// MSM runs one lane per (proof, term): 65536 / T proofs for 1024 waves (T = 16: 4096, the BASELINE batch; T = 60: 1092) -
+// as a power of two between 1024 and 4096.
+static uint32_t default_chunk(const H2vDevPlan &d) {
+    const double want = 65536.0 / (double)(d.n_main_terms ? d.n_main_terms : 1);
+    uint32_t c = 1024;
+    while (c < 4096 && (double)c * 1.4142 < want) c <<= 1;
+    return c;
+}
+#define H2V_DEFAULT_LANES 8u
+extern "C" int h2v_workspace_create_lanes(const h2v_plan *p, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk, h2v_workspace **out) {
+    if (!p || !out) return fail(H2V_E_ARG, "null argument");
+    if (max_batch == 0 || max_batch > (1ull << 24)) return fail(H2V_E_ARG, "max_batch out of range");
+    if (n_lanes > (uint32_t)h2v_workspace::MAXL) return fail(H2V_E_ARG, "at most 16 lanes");
+    if (chunk == 0) chunk = default_chunk(p->d);
+    if ((uint64_t)chunk > max_batch) chunk = (uint32_t)max_batch;
+    const uint64_t n_chunks = (max_batch + chunk - 1) / chunk;
+    if (n_lanes == 0) n_lanes = H2V_DEFAULT_LANES;
+    if ((uint64_t)n_lanes > n_chunks && !false) { /* more lanes than one call can use still serve consecutive calls (deferred joins) */ }
+    HIPCHK(hipSetDevice(p->device));
+    h2v_workspace *w = new h2v_workspace();
+    w->device = p->device; w->cap = max_batch; w->chunk = chunk;
+    w->stride = (uint32_t)((max_batch + 63) / 64 * 64);
+    const H2vDevPlan &d = p->d;
+    w->sz_terms = d.n_terms; w->sz_slots = (uint32_t)H2V_SLOTS(d); w->sz_regs = 0; w->sz_trace = 0; w->sz_ivc = d.ivc != 0; w->sz_fix = d.fix_tab != nullptr;
+    bool ok = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) == hipSuccess && hipMalloc((void **)&w->accept, (size_t)max_batch) == hipSuccess;
+    for (uint32_t l = 0; l < n_lanes && ok; l++) {
+        h2v_workspace *lw = nullptr;
+        ok = ws_create_for(d, p->device, chunk, false, &lw) == H2V_OK;
+        if (!ok) break;
+        w->lane[l] = lw;
+        w->n_lanes = l + 1;
+        ok = hipStreamCreateWithFlags(&w->lane_st[l], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&w->lane_ev[l], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->lane_p1[l], hipEventDisableTiming) == hipSuccess;
+        lw->p1_event = w->lane_p1[l];
+        lw->one_stream_mode = 1;            // one stream per lane: n_lanes streams in all, whatever the hardware-queue count
+        lw->in_flight_hint = n_lanes;
+    }
+    if (!ok) { const std::string e = g_err; ws_release(w); delete w; return fail(H2V_E_DEVICE, "lane creation failed: " + e); }
+    if (const char *e = getenv("H2V_LANE_STAGGER")) w->stagger = atoi(e);          // experiment knobs, read per creation
+    if (const char *e = getenv("H2V_LANE_ONE_STREAM")) for (uint32_t l = 0; l < w->n_lanes; l++) w->lane[l]->one_stream_mode = atoi(e);
+    *out = w;
+    return H2V_OK;
+}
 extern "C" int h2v_workspace_create(const h2v_plan *p, uint64_t max_batch, h2v_workspace **out) {
     if (!p || !out) return fail(H2V_E_ARG, "null argument");
+    // a workspace for batches of at least two chunks is laned: the call is pipelined inside the library
+    if (max_batch >= 2ull * default_chunk(p->d)) return h2v_workspace_create_lanes(p, max_batch, 0, 0, out);
     return ws_create_for(p->d, p->device, max_batch, false, out);
+}
+extern "C" int h2v_workspace_lanes(const h2v_workspace *ws, uint32_t *n_lanes, uint32_t *chunk) {
+    if (!ws) return fail(H2V_E_ARG, "null argument");
+    if (n_lanes) *n_lanes = ws->n_lanes ? ws->n_lanes : 1;
+    if (chunk) *chunk = ws->n_lanes ? ws->chunk : (uint32_t)ws->cap;
+    return H2V_OK;
+}
+extern "C" int h2v_workspace_defer_joins(h2v_workspace *ws, int defer) {
+    if (!ws) return fail(H2V_E_ARG, "null argument");
+    if (!ws->n_lanes) return fail(H2V_E_ARG, "only a laned workspace can defer its joins (h2v_workspace_create_lanes)");
+    ws->defer_joins = defer != 0;
+    return H2V_OK;
+}
+// every lane that has work enqueued since the last join: `st` waits for its last chunk
+static int lanes_join(h2v_workspace *w, hipStream_t st) {
+    for (uint32_t l = 0; l < w->n_lanes; l++)
+        if (w->lane_busy[l]) { HIPCHK(hipStreamWaitEvent(st, w->lane_ev[l], 0)); w->lane_busy[l] = false; }
+    return H2V_OK;
+}
+extern "C" int h2v_workspace_join(h2v_workspace *ws, void *stream) {
+    if (!ws) return fail(H2V_E_ARG, "null argument");
+    if (!ws->n_lanes) return H2V_OK;   // an ordinary workspace's calls are already ordered on the caller's stream
+    HIPCHK(hipSetDevice(ws->device));
+    return lanes_join(ws, (hipStream_t)stream);
 }
 extern "C" void h2v_workspace_free(h2v_workspace *w) {
     if (!w) return;
@@ -432,6 +531,7 @@ extern "C" void h2v_workspace_free(h2v_workspace *w) {
 extern "C" int h2v_workspace_hint_in_flight(h2v_workspace *ws, uint32_t n_in_flight) {
     if (!ws || n_in_flight == 0) return fail(H2V_E_ARG, "bad argument");
     ws->in_flight_hint = n_in_flight;
+    for (uint32_t l = 0; l < ws->n_lanes; l++) ws->lane[l]->in_flight_hint = n_in_flight > ws->n_lanes ? n_in_flight : ws->n_lanes;
     return H2V_OK;
 }
 
@@ -441,6 +541,10 @@ static int ws_fits(const h2v_workspace *w, const h2v_plan *p, uint64_t n, bool w
     const H2vDevPlan &d = p->d;
     if (w->device != p->device) return fail(H2V_E_ARG, "workspace belongs to another device");
     if (w->cap < n) return fail(H2V_E_ARG, "workspace too small for this batch");
+    if (w->n_lanes) {
+        if (want_trace) return fail(H2V_E_ARG, "a laned workspace has no trace buffer");
+        return ws_fits(w->lane[0], p, n < w->chunk ? n : w->chunk, false);
+    }
     if (d.n_terms > w->sz_terms || H2V_SLOTS(d) > w->sz_slots) return fail(H2V_E_ARG, "workspace was created for a smaller plan (MSM terms / point slots)");
     if (vm_lds_slots(d) == 0 && d.n_regs > w->sz_regs) return fail(H2V_E_ARG, "workspace has no (or too small a) global register file for this plan");
     if (d.ivc && !w->sz_ivc) return fail(H2V_E_ARG, "workspace was created for a non-recursive plan");
@@ -730,7 +834,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         // streams per batch collide from the sixth batch on).  Measured, 40 steps of simple_mul x 4096: three streams 5 / 8 / 11
         // in flight 4.46 / 4.66 / 4.75 ms per step, one stream 4.80 / 4.39 / 4.50.  H2V_ONE_STREAM = 0 / 1 forces the choice.
         static const int env_one = []() { const char *e = getenv("H2V_ONE_STREAM"); return e ? atoi(e) : -1; }();
-        const bool one_stream = pipes == 1 && (env_one >= 0 ? env_one != 0 : w->in_flight_hint >= 6);
+        const bool one_stream = pipes == 1 && (w->one_stream_mode >= 0 ? w->one_stream_mode != 0 : env_one >= 0 ? env_one != 0 : w->in_flight_hint >= 6);
         if (!one_stream)
             if (int rcs = ws_streams(w, k, true, true, split_dec && !dec_queue_on)) return rcs;
         hipStream_t pm = one_stream ? st : w->pmain[k], ps = one_stream ? st : w->pside[k];
@@ -791,6 +895,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         // The MSM also waits for the subgroup launch although it does not read its result: a merged-halves MSM relies on
         // finding every SIMD empty (one wave each: 1.9 ms; a SIMD shared with a leftover wave: 2.2 ms for the launch)
         if (split_dec) HIPCHK(hipStreamWaitEvent(pm, w->ev_sub[k], 0));
+        if (w->p1_event && k == pipes - 1) HIPCHK(hipEventRecord(w->p1_event, pm));
         HIPCHK(hipEventRecord(ev[4], pm));
         uint32_t *tab_k = d.ivc ? w->msm_tab + (size_t)lo * 4 * 2 * 8 * 28 : nullptr;   // fold MSMs only
         const IvcBufs ib = {d.ivc ? w->accl + (size_t)lo * 36 : nullptr, d.ivc ? w->accr + (size_t)lo * 36 : nullptr,
@@ -839,6 +944,60 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
     return H2V_OK;
 }
 
+static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
+                   uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, const uint32_t seed[8], bool one_stream_opt);
+static uint64_t rlc_calls_of(const h2v_workspace *w);
+// A call on a laned workspace: chunks of at most w->chunk proofs, round robin through the lanes (continuing where the
+// previous call stopped).  Chunk c runs on its lane's own stream behind (1) everything the caller had enqueued on `st`
+// before the call, (2) the lane's earlier chunks, and (3) - staggering - phase 1 of chunk c - 1, so that the phases of
+// neighbouring chunks interleave instead of running in lockstep.  rlc: every chunk is its own batch check.
+static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
+                     uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, bool rlc, const uint32_t *seed, bool force_join) {
+    const H2vDevPlan &d = p->d;
+    const uint32_t L = w->n_lanes, nch = (n + w->chunk - 1) / w->chunk;
+    const int slot = (int)(w->calls % h2v_workspace::RING);
+    w->calls++;
+    w->lring_chunks[slot] = nch; w->lring_first[slot] = (uint32_t)(w->next_lane % L); w->lring_rlc[slot] = rlc ? 1 : 0;
+    HIPCHK(hipEventRecord(w->ev_fork, st));
+    for (uint32_t c = 0; c < nch; c++) {
+        const uint32_t l = (uint32_t)(w->next_lane++ % L);
+        h2v_workspace *lw = w->lane[l];
+        hipStream_t ls = w->lane_st[l];
+        const uint32_t lo = c * w->chunk, m = (n - lo) < w->chunk ? (n - lo) : w->chunk;
+        HIPCHK(hipStreamWaitEvent(ls, w->ev_fork, 0));
+        if (w->stagger && w->last_p1_lane != ~0ull && w->last_p1_lane != l) HIPCHK(hipStreamWaitEvent(ls, w->lane_p1[w->last_p1_lane], 0));
+        const uint8_t *inst_c = inst ? inst + (size_t)lo * d.n_pi * 32 : nullptr, *ci_c = ci ? ci + (size_t)lo * 48 : nullptr;
+        int rc;
+        if (rlc) {
+            uint32_t sd[8];
+            for (int k = 0; k < 8; k++) sd[k] = seed[k];
+            sd[7] ^= 0x9e3779b9u * (c + 1);      // (a chunk is its own batch check: its own coefficients)
+            rc = run_rlc(p, m, proofs, off + lo, inst_c, ci_c, accept + lo, status_out ? status_out + lo : nullptr, lw, ls, sd, true);
+        } else {
+            rc = run_pipeline(d, m, proofs, off + lo, inst_c, ci_c, accept + lo, status_out ? status_out + lo : nullptr, lw, ls, nullptr, false);
+        }
+        if (rc) { (void)hipStreamSynchronize(ls); return rc; }
+        HIPCHK(hipEventRecord(w->lane_ev[l], ls));
+        w->lane_busy[l] = true;
+        w->last_p1_lane = l;
+    }
+    for (uint32_t l = 0; l < L; l++) {
+        w->lring_calls[slot][l] = w->lane[l]->calls;
+        w->lring_rlc_calls[slot][l] = rlc_calls_of(w->lane[l]);
+    }
+    if (!w->defer_joins || force_join) return lanes_join(w, st);
+    return H2V_OK;
+}
+// chunk c of the call in ring slot `slot` ran on lane *l as that lane's call number (0-based, absolute) *idx
+static void laned_chunk_pos(const h2v_workspace *w, int slot, uint32_t c, bool rlc, uint32_t *l, uint64_t *idx) {
+    const uint32_t L = w->n_lanes, nch = w->lring_chunks[slot], f = w->lring_first[slot];
+    *l = (f + c) % L;
+    uint32_t uses = 0;                       // chunks of this call on that lane
+    for (uint32_t q = 0; q < nch; q++) if ((f + q) % L == *l) uses++;
+    const uint64_t end = rlc ? w->lring_rlc_calls[slot][*l] : w->lring_calls[slot][*l];
+    *idx = end - uses + c / L;
+}
+
 extern "C" int h2v_verify_batch_device(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, uint32_t *status,
                                        h2v_workspace *ws, void *stream, h2v_timings *timings) {
     if (!p || !b || !accept) return fail(H2V_E_ARG, "null argument");
@@ -854,6 +1013,15 @@ extern "C" int h2v_verify_batch_device(const h2v_plan *p, const h2v_batch *b, ui
         ws = tmp;
     }
     if (int rcf = ws_fits(ws, p, b->n, false)) { if (tmp) h2v_workspace_free(tmp); return rcf; }
+    if (ws->pending) return fail(H2V_E_ARG, "the workspace has a host batch in flight: call h2v_verify_batch_wait first");
+    if (ws->n_lanes) {
+        int rcl = run_laned(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, false, nullptr, timings != nullptr);
+        if (rcl == H2V_OK && timings) {
+            HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+            rcl = h2v_workspace_timings(ws, 0, timings);
+        }
+        return rcl;
+    }
     int rc = run_pipeline(p->d, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws,
                           (hipStream_t)stream, timings, false);
     if (tmp) {
@@ -870,6 +1038,32 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
     if (calls_back >= h2v_workspace::RING || calls_back >= w->calls) return fail(H2V_E_ARG, "no such call in the event ring");
     HIPCHK(hipSetDevice(w->device));
     const int slot = (int)((w->calls - 1 - calls_back) % h2v_workspace::RING);
+    if (w->n_lanes) {
+        // sums over the call's chunks (h2v_timings: `launches` = chunks); total_ms = first chunk's start .. the last end
+        if (w->lring_rlc[slot]) return fail(H2V_E_ARG, "that call ran in RLC mode: h2v_workspace_rlc_result");
+        memset(tm, 0, sizeof *tm);
+        const uint32_t nch = w->lring_chunks[slot];
+        hipEvent_t first = nullptr;
+        for (uint32_t c = 0; c < nch; c++) {
+            uint32_t l; uint64_t idx;
+            laned_chunk_pos(w, slot, c, false, &l, &idx);
+            h2v_workspace *lw = w->lane[l];
+            if (lw->calls - 1 - idx >= (uint64_t)h2v_workspace::RING) return fail(H2V_E_ARG, "the lanes' event rings have wrapped since that call");
+            h2v_timings t1;
+            int rc = h2v_workspace_timings(lw, (uint32_t)(lw->calls - 1 - idx), &t1);
+            if (rc) return rc;
+            tm->transcript_combiner_ms += t1.transcript_combiner_ms; tm->g1_decompress_ms += t1.g1_decompress_ms;
+            tm->g1_msm_ms += t1.g1_msm_ms; tm->pairing_ms += t1.pairing_ms;
+            tm->msm_lanes_per_term = t1.msm_lanes_per_term; tm->pairing_lanes_per_proof = t1.pairing_lanes_per_proof;
+            hipEvent_t *ev = lw->ring[idx % h2v_workspace::RING][0];
+            if (!first) first = ev[2];
+            float span = 0;
+            HIPCHK(hipEventElapsedTime(&span, first, ev[6]));
+            if (span > tm->total_ms) tm->total_ms = span;
+        }
+        tm->launches = nch;
+        return H2V_OK;
+    }
     const int pipes = w->ring_pipes[slot];
     memset(tm, 0, sizeof *tm);
     tm->launches = (uint32_t)pipes;
@@ -973,17 +1167,26 @@ extern "C" int h2v_verify_batch_submit(const h2v_plan *p, const h2v_batch *b, h2
         if ((rc = ws_fits(ws, p, b->n, false))) return rc;
         if ((rc = stage_inputs(p, b, ws))) return rc;
         const bool rlc = (flags & H2V_SUBMIT_RLC) && rlc_supported(p);
-        if (rlc) {
-            uint32_t seed[8];
-            if ((rc = rlc_seed(opts, seed))) return rc;
+        uint32_t seed[8] = {};
+        if (rlc && (rc = rlc_seed(opts, seed))) { (void)hipStreamSynchronize(ws->hs); return rc; }
+        if (ws->n_lanes) {
+            rc = run_laned(p, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, ws->hs, rlc, seed, true);
+        } else if (rlc) {
             rc = run_rlc(p, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, ws->hs, seed,
                          opts && (opts->flags & H2V_RLC_ONE_STREAM));
-            ws->pending_rlc = true;
         } else {
             rc = run_pipeline(p->d, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, ws->hs, nullptr, false);
         }
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(ws->h_accept, ws->accept, b->n, hipMemcpyDeviceToHost, ws->hs));
+        ws->pending_rlc = rlc;
+        if (rc == H2V_OK && hipMemcpyAsync(ws->h_accept, ws->accept, b->n, hipMemcpyDeviceToHost, ws->hs) != hipSuccess) rc = fail(H2V_E_DEVICE, "download of accept[] failed");
+        if (rc) {
+            // the upload from the pinned block and some kernels may already be enqueued: nothing of this workspace may be
+            // reused before they have drained
+            const std::string e = g_err;
+            (void)hipStreamSynchronize(ws->hs);
+            for (uint32_t l = 0; l < ws->n_lanes; l++) (void)hipStreamSynchronize(ws->lane_st[l]);
+            return fail(rc, e);
+        }
     }
     HIPCHK(hipEventRecord(ws->ev_host, ws->hs));
     ws->pending = true;
@@ -1146,6 +1349,7 @@ static int rlc_ensure(h2v_workspace *w, const h2v_plan *p) {
     w->rlc = r;
     return H2V_OK;
 }
+static uint64_t rlc_calls_of(const h2v_workspace *w) { return w->rlc ? w->rlc->calls : 0; }
 static bool rlc_supported(const h2v_plan *p) { return !p->d.ivc && p->n_var > 0 && p->n_fix > 0 && p->n_var + p->n_fix == p->d.n_terms; }
 
 // One batch in RLC mode.  Phase 1 as in run_pipeline (the decompression launch builds no window tables), then the batch
@@ -1163,7 +1367,7 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     // one_stream (h2v_rlc_opts.flags & H2V_RLC_ONE_STREAM, or the environment variable of that name = 1 / 0): everything on
     // the caller's stream, decompression before the combiner - one stream per batch in flight instead of two
     static const int env_one = []() { const char *e = getenv("H2V_RLC_ONE_STREAM"); return e ? atoi(e) : -1; }();
-    const bool one_stream = env_one >= 0 ? env_one != 0 : (one_stream_opt || w->in_flight_hint >= 3);   // (the flag, or the caller's in-flight hint)
+    const bool one_stream = w->one_stream_mode >= 0 ? w->one_stream_mode != 0 : env_one >= 0 ? env_one != 0 : (one_stream_opt || w->in_flight_hint >= 3);   // (the flag, or the caller's in-flight hint)
     if (!one_stream && (rc = ws_streams(w, 0, false, true, false))) return rc;
     hipStream_t pm = st, ps = one_stream ? st : w->pside[0];
     if (!one_stream) {
@@ -1188,6 +1392,7 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     HIPCHK(hipEventRecord(ev[3], pm));
     if (!one_stream) HIPCHK(hipStreamWaitEvent(pm, w->ev_join[0], 0));
     HIPCHK(hipEventRecord(ev[10], pm));
+    if (w->p1_event) HIPCHK(hipEventRecord(w->p1_event, pm));
     // the batch check
     RlcArgs ra = {n, p->n_var, p->n_fix, slots, d.pi_point, d.n_terms, d.terms, w->scalars, w->status, w->valid, w->valid_sub, {},
                   r->r_scal, r->r_idx, r->l_scal, r->l_idx, r->vk_part, r->good};
@@ -1256,11 +1461,15 @@ extern "C" int h2v_verify_batch_rlc_device(const h2v_plan *p, const h2v_batch *b
     if (!ws) return fail(H2V_E_ARG, "the RLC entry points need a workspace (results of the batch check live in it)");
     HIPCHK(hipSetDevice(p->device));
     if ((rc = ws_fits(ws, p, b->n, false))) return rc;
+    if (ws->pending) return fail(H2V_E_ARG, "the workspace has a host batch in flight: call h2v_verify_batch_wait first");
     // recursive plans fold an accumulator per proof (the challenge hashes that proof's own MSM result): no batch form
-    if (!rlc_supported(p))
+    if (!rlc_supported(p)) {
+        if (ws->n_lanes) return run_laned(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, false, nullptr, false);
         return run_pipeline(p->d, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, nullptr, false);
+    }
     uint32_t seed[8];
     if ((rc = rlc_seed(opts, seed))) return rc;
+    if (ws->n_lanes) return run_laned(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, true, seed, false);
     return run_rlc(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, seed,
                    opts && (opts->flags & H2V_RLC_ONE_STREAM));
 }
@@ -1273,6 +1482,41 @@ extern "C" int h2v_verify_batch_rlc(const h2v_plan *p, const h2v_batch *b, uint8
 // After the stream of an RLC call has been synchronised: did the batch check pass (1) or did the per-proof kernels run (0)?
 // kernel times of a past call (calls_back = 0: the most recent).
 extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, uint32_t *batch_accepted, h2v_rlc_timings *tm) {
+    if (w && w->n_lanes) {
+        // laned: the AND of the chunks' batch verdicts; times summed over the chunks, total = first start .. last verdict
+        if (w->calls == 0 || calls_back >= h2v_workspace::RING || calls_back >= w->calls) return fail(H2V_E_ARG, "no such call in the event ring");
+        const int slot = (int)((w->calls - 1 - calls_back) % h2v_workspace::RING);
+        if (!w->lring_rlc[slot]) return fail(H2V_E_ARG, "that call did not run in RLC mode");
+        if (batch_accepted) *batch_accepted = 1;
+        if (tm) memset(tm, 0, sizeof *tm);
+        hipEvent_t first = nullptr;
+        for (uint32_t c = 0; c < w->lring_chunks[slot]; c++) {
+            uint32_t l; uint64_t idx;
+            laned_chunk_pos(w, slot, c, true, &l, &idx);
+            h2v_workspace *lw = w->lane[l];
+            if (!lw->rlc || lw->rlc->calls - 1 - idx >= (uint64_t)h2v_workspace::RING) return fail(H2V_E_ARG, "the lanes' event rings have wrapped since that call");
+            const uint32_t back = (uint32_t)(lw->rlc->calls - 1 - idx);
+            uint32_t ok1 = 1;
+            h2v_rlc_timings t1;
+            // (the verdict word of a lane is overwritten by its next chunk: the verdict of a past call is exact only while
+            //  no later chunk has run on that lane - i.e. for calls_back = 0 after a join)
+            int rc = h2v_workspace_rlc_result(lw, back, batch_accepted && back == 0 ? &ok1 : nullptr, tm ? &t1 : nullptr);
+            if (rc) return rc;
+            if (batch_accepted && !ok1) *batch_accepted = 0;
+            if (tm) {
+                tm->transcript_combiner_ms += t1.transcript_combiner_ms; tm->g1_decompress_ms += t1.g1_decompress_ms; tm->prepare_ms += t1.prepare_ms;
+                tm->bucket_sort_ms += t1.bucket_sort_ms; tm->bucket_accumulate_ms += t1.bucket_accumulate_ms; tm->bucket_reduce_ms += t1.bucket_reduce_ms;
+                tm->pairing_ms += t1.pairing_ms;
+                tm->msm_terms = t1.msm_terms; tm->window_bits = t1.window_bits; tm->windows = t1.windows; tm->max_chain = t1.max_chain;
+                hipEvent_t *ev = lw->rlc->ring[idx % h2v_workspace::RING];
+                if (!first) first = ev[0];
+                float span = 0;
+                HIPCHK(hipEventElapsedTime(&span, first, ev[9]));
+                if (span > tm->total_ms) tm->total_ms = span;
+            }
+        }
+        return H2V_OK;
+    }
     if (!w || !w->rlc || w->rlc->calls == 0) return fail(H2V_E_ARG, "no RLC call was made with this workspace");
     RlcWs *r = w->rlc;
     HIPCHK(hipSetDevice(w->device));

@@ -176,6 +176,9 @@ class _Builder:
         self.cse: Dict[tuple, int] = {}
         self.const_reg: Dict[int, int] = {}
         self.value_of_const_reg: Dict[int, int] = {}
+        # scheduling hint: virtual register -> a register whose bundle must come first although the instruction does not
+        # read it (a re-load that would otherwise be hoisted to the top of the program and stay live all the way down)
+        self.not_before: Dict[int, int] = {}
 
     def new(self) -> int:
         self.n_virt += 1
@@ -506,7 +509,13 @@ def compile_plan(vk: VerifyingKey, lanes: Optional[int] = None, legacy_no_trash_
         pbasis = [b.mul(b.mul(inv_out[pi_idx[i]], common), b.const(pi_rot_w[i])) for i in range(vk.n_public_inputs)]
         acc = zero
         for i in range(vk.n_public_inputs):
-            acc = b.add(b.mul(pbasis[i], pis[i]), acc)
+            # the public input is loaded a second time, next to its use: the copy that was absorbed at the top of the
+            # program would otherwise occupy a register through the whole proof read and the batch inversion (32 of them
+            # for the sha256 wrapper: the difference between 16 and 8 proofs per block of the combiner kernel)
+            r = b.new()
+            b.emit(OP_LOAD_INSTANCE, r, i, 0)
+            b.not_before[r] = pbasis[i]
+            acc = b.add(b.mul(pbasis[i], r), acc)
         pub_eval = acc
     else:
         pub_eval = zero
@@ -754,7 +763,7 @@ def compile_plan(vk: VerifyingKey, lanes: Optional[int] = None, legacy_no_trash_
 
     # ---- register allocation (linear scan over the straight-line code)
     keep_alive = {r for _, r in trace_virt}
-    (instrs, n_regs, mapping, vm_lanes), wide = _schedule_and_allocate(b.code, keep_alive, lanes)
+    (instrs, n_regs, mapping, vm_lanes), wide = _schedule_and_allocate(b.code, keep_alive, lanes, b.not_before)
     trace = [(slot, mapping[r]) for slot, r in trace_virt]
 
     s_g2 = bls.g2_decompress(bytes.fromhex(vk.s_g2))
@@ -787,7 +796,7 @@ _COST_MUL, _COST_INV, _COST_CHEAP, _COST_BUNDLE = 1.0, 14.0, 0.06, 0.05
 _COST_TRANSCRIPT = {OP_ABSORB_REG: 1.6, OP_ABSORB_CI: 0.8, OP_READ_POINT: 0.8, OP_READ_SCALAR: 1.7, OP_SQUEEZE: 3.5}
 
 
-def _schedule(code, lanes: int, pack_mul: bool):
+def _schedule(code, lanes: int, pack_mul: bool, not_before=None):
     """List scheduling of the straight-line SSA program into bundles of `lanes` records.
 
     Every instruction goes to the earliest bundle after its operands' bundles that still has a free lane (records of a
@@ -807,6 +816,8 @@ def _schedule(code, lanes: int, pack_mul: bool):
         e = 0
         for r in _uses(op, dst, a, c):
             e = max(e, slot_of[r] + 1)
+        if not_before and op == OP_LOAD_INSTANCE and dst in not_before:
+            e = max(e, slot_of[not_before[dst]])   # (the same bundle is fine: it does not read that register)
         if op in TRANSCRIPT_OPS:
             s = len(bundles)   # later than every operand and every earlier transcript operation
             bundles.append([list(ins)] + [None] * (lanes - 1))
@@ -922,7 +933,7 @@ def check_bundles(instrs, lanes: int):
                     "a lane reads a register written in the same bundle"
 
 
-def _schedule_and_allocate(code, keep_alive, lanes: Optional[int]):
+def _schedule_and_allocate(code, keep_alive, lanes: Optional[int], not_before=None):
     """Two schedules of the program (a block of the combiner kernel has 64 lanes, so 64 / L proofs share its LDS
     register file):
       * narrow: the smallest lane count L whose register file fits in LDS - the batch then needs the fewest waves, which
@@ -934,7 +945,7 @@ def _schedule_and_allocate(code, keep_alive, lanes: Optional[int]):
     for L in ((lanes,) if lanes else VM_LANE_CHOICES):
         best = None
         for pack in (False, True):
-            bundles = _schedule(code, L, pack)
+            bundles = _schedule(code, L, pack, not_before)
             instrs, n_regs, mapping = _allocate(bundles, keep_alive)
             cost = _schedule_cost(bundles)
             if best is None or cost < best[0]:
