@@ -10,9 +10,12 @@ transcript replay + Fr combiner, G1 decompression, then
               point of the batch + ONE pairing (+ the per-proof kernels, skipped on the device unless the batch check fails).
 Workload: BASELINE.json configs[1] - simple_mul, 4096 proofs per GPU; --workload / --batch select the other configs.
 --scaling weak (default): every rank verifies --batch proofs; strong: the ranks split ONE batch of --batch proofs by
-contiguous index ranges (shard.shard_range).  Either way there is no data-path collective; the per-step accept bytes are
-gathered on rank 0 over RCCL as the north star asks.  --inflight P keeps P steps in flight on P workspaces / streams
-(every step still runs completely inside the timed region).  Prints ONE JSON line on rank 0.
+contiguous index ranges (shard.shard_range).  Either way there is no data-path collective; the accept bytes of all timed
+steps are gathered on rank 0 over RCCL (one collective after the last step, inside the timed region).
+--pipeline lanes (default): every step is ONE call on ONE laned workspace (h2v_workspace_create_lanes + deferred joins):
+the library keeps the steps in flight on its own lanes and streams; the caller owns one workspace and one stream and sets
+no environment variable.  --pipeline streams: round 2's caller-driven form (--inflight P workspaces on P torch streams),
+kept as a probe.  Every step runs completely inside the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -90,8 +93,10 @@ def pmc_traffic(kernel, workload, batch, mode):
             if len(f) >= 4 and f[0] == kernel and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[f[1]] = float(f[3])
         if len(vals) == 2:
-            return int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.basename(path)
-    return None, None
+            # MI355X_MICROARCH.md, HBM / rocprofv3: KiB on gfx950, and FETCH_SIZE tallies 128-byte requests at 64 bytes -
+            # "double it before comparing with a byte count"; WRITE_SIZE is exact
+            return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.basename(path)
+    return None, None, None
 
 
 def main():
@@ -103,7 +108,12 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="proofs per GPU (weak) / in total (strong); default: the workload's BASELINE size")
     ap.add_argument("--mode", default="per-proof", choices=["per-proof", "rlc"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--inflight", type=int, default=0, help="steps in flight (workspaces / streams); default: 2 (per-proof, batches above 1024), 4 (per-proof, smaller), 7 (rlc)")
+    ap.add_argument("--pipeline", default="lanes", choices=["lanes", "streams"],
+                    help="lanes: one laned workspace, the library pipelines the steps (default); streams: --inflight workspaces on torch streams")
+    ap.add_argument("--lanes", type=int, default=0, help="--pipeline lanes: number of lanes (0: the library's choice, 6 per-proof / 11 rlc)")
+    ap.add_argument("--inflight", type=int, default=0, help="--pipeline streams: steps in flight (workspaces / streams); default: probed")
+    ap.add_argument("--reject-fraction", type=float, default=0.0, help="timed steps run on a batch in which this fraction of the proofs has the reference example's byte flip")
+    ap.add_argument("--reject-count", type=int, default=0, help="timed steps run on a batch with exactly this many corrupted proofs (pairing-only rejects: wrong_pi)")
     ap.add_argument("--msm-tpl", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="per-proof MSM: terms per lane (sets H2V_MSM_TPL; 2 / 4 share the doublings of a lane's terms)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -123,21 +133,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # steps in flight: measured on MI355X - per-proof simple_mul x4096: 1 -> 6.11 ms per step, 2 -> 5.29,
-    # 3 -> 5.25; the 512 / 1024-proof batches of the large circuits, whose kernels are lone-wave chains: 1 -> 4.98 / 5.51 ms,
-    # 4 -> 2.74 / 3.31; RLC: 1 -> 5.0 ms, 4 -> 2.04, 5 -> 1.84 (stable over boxes and runs), 6 -> 1.80 OR 3.4-3.9 (bimodal:
-    # with twelve streams the runtime sometimes maps two busy ones onto one hardware queue), 7 -> 2.0 (the tail of a batch -
-    # bucket reduction, doublings, ONE pairing - is a few waves)
-    # Not every box overlaps streams equally well (one measured 2.2 ms -> 6.5 ms per RLC step with seven in flight where the
-    # others gain 3x), so without --inflight the count is PROBED: a few untimed steps with each candidate, the best one is used
-    # for the timed region and reported (config.steps_in_flight, inflight_probe_ms_per_step).
+    # --pipeline streams: the steps-in-flight count is PROBED (a few untimed steps with each candidate, the best one is used
+    # for the timed region and reported); --pipeline lanes: the library's lanes are the steps in flight.
     small = (args.batch or WORKLOADS[args.workload][1]) <= 1024
     inflight_candidates = [args.inflight] if args.inflight else ([11, 7, 5, 3, 1] if args.mode == "rlc" else [4, 2, 1] if small else [5, 3, 2, 1])
     inflight = inflight_candidates[0]
     if args.msm_tpl:
         os.environ["H2V_MSM_TPL"] = str(args.msm_tpl)
-    # several steps in flight use 3 streams each: more hardware queues than the runtime's default of 4, or they serialise
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # (round 2 exported GPU_MAX_HW_QUEUES=16 here; the library's streams now get hardware queues of their own - csrc: make_stream)
 
     import torch
     import torch.distributed as dist
@@ -178,15 +181,39 @@ def main():
     batch = synth.forge_batch(vk, td, B, seed=1000 + rank, workers=workers, plan=pl)
     t_forge = time.time() - t0
 
+    timed_batch, timed_expected = batch, None
+    if args.reject_fraction > 0 or args.reject_count > 0:
+        # timed reject scenario: the steps run on a batch that holds corrupted proofs (RLC mode: the batch check fails and the
+        # fall-back decides).  --reject-count: exactly that many proofs with a wrong pi (only the pairing catches them);
+        # --reject-fraction: the reference example's byte flip (examples/simple_mul.rs:87-95)
+        import random as _random
+        if args.reject_count > 0:
+            rng = _random.Random(4242 + rank)
+            bad = set(rng.sample(range(B), min(args.reject_count, B)))
+            ps, ins, exp = [], [], [1] * B
+            for i in range(B):
+                pr, it = batch.proof(i), batch.instances[32 * vk.n_public_inputs * i:32 * vk.n_public_inputs * (i + 1)]
+                if i in bad:
+                    pr, it = synth.corrupt(pl, pr, it, "wrong_pi", rng)
+                    exp[i] = 0
+                ps.append(pr); ins.append(it)
+            off_ = [0]
+            for pr in ps:
+                off_.append(off_[-1] + len(pr))
+            timed_batch = synth.Batch(n=B, proofs=b"".join(ps), proof_off=off_, instances=b"".join(ins), committed=batch.committed, expected=exp)
+        else:
+            timed_batch = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=args.reject_fraction, seed=78 + rank, kinds=["flip_first_scalar"])
+        timed_expected = list(timed_batch.expected)
+
     dp = backend.DevicePlan(pl.to_bytes(), device=local_rank)
 
     def to_dev(b):
         return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) if b else torch.zeros(1, dtype=torch.uint8, device=dev)
 
-    d_proofs = to_dev(batch.proofs)
-    d_off = torch.tensor(batch.proof_off, dtype=torch.int64).to(dev)
-    d_inst = to_dev(batch.instances)
-    d_ci = to_dev(batch.committed) if batch.committed else None
+    d_proofs = to_dev(timed_batch.proofs)
+    d_off = torch.tensor(timed_batch.proof_off, dtype=torch.int64).to(dev)
+    d_inst = to_dev(timed_batch.instances)
+    d_ci = to_dev(timed_batch.committed) if timed_batch.committed else None
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live
     Bmax = B
     if world > 1:
@@ -196,9 +223,89 @@ def main():
     rlc_seed = bytes((7 * k + 1) & 0xff for k in range(32))   # fixed for the timed steps (reproducible); a service draws it per batch
 
     stream_pool = []
+    caller = torch.cuda.Stream(device=dev)   # --pipeline lanes: the ONE stream the caller submits on (not the legacy NULL stream)
+    RING = 16                                # accept / status buffers the steps cycle through (>= lanes: a lane runs its chunks in order)
 
-    def timed_run(mode, inflight, steps, warmup, gather):
-        """warmup + `steps` timed passes in `mode` with `inflight` steps in flight; returns (elapsed s, workspaces, accept)"""
+    def batch_ptrs(acc, st_):
+        return (B, d_proofs.data_ptr(), d_off.data_ptr(), d_inst.data_ptr(), d_ci.data_ptr() if d_ci is not None else None, acc.data_ptr(), st_.data_ptr())
+
+    class Run:
+        """what a timed run leaves behind: elapsed seconds, the last step's accept bytes, per-step kernel timings"""
+        def __init__(self, el, accept, timings, rlc_result, close, in_flight, all_steps_ok):
+            self.el, self.accept, self.timings, self.rlc_result, self.close, self.in_flight, self.all_steps_ok = el, accept, timings, rlc_result, close, in_flight, all_steps_ok
+
+    def finish_timing(t0):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    def gather_all(d_accepts, steps, n_slots):
+        """ONE collective for the accept bytes of all timed steps (rank r sends steps x Bmax bytes), after the last step: a
+        gather per step inside the loop would serialise the steps in flight on the host."""
+        k_keep = min(steps, n_slots)
+        send = torch.zeros(k_keep, Bmax, dtype=torch.uint8, device=dev)
+        for j in range(k_keep):
+            send[j, :B].copy_(d_accepts[(steps - 1 - j) % n_slots])
+        send = send.to(cdev)
+        recv = [torch.zeros(k_keep, Bmax, dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None
+        dist.gather(send, recv, dst=0)
+        return recv
+
+    def check_gathered(recv):
+        sizes = [shard.shard_range(B_arg, r, world)[1] - shard.shard_range(B_arg, r, world)[0] if args.scaling == "strong" else B_arg for r in range(world)]
+        gather_state["ok"] = all(bool(recv[r][:, :sizes[r]].all().item()) for r in range(world))
+
+    def expected_ok(acc_np):
+        return bool((acc_np == 1).all()) if timed_expected is None else [int(x) for x in acc_np] == timed_expected
+
+    def lanes_run(mode, steps, warmup, gather, lanes=None):
+        """--pipeline lanes: every step is one call on ONE laned workspace; joins are deferred, so the library keeps as many
+        steps in flight as it has lanes.  One workspace, one caller stream."""
+        ws = backend.Workspace(dp, B, lanes=args.lanes if lanes is None else lanes, chunk=0)
+        ws.defer_joins(True)
+        n_lanes, chunk = ws.lanes()
+        in_flight = n_lanes if (mode == "rlc" or args.lanes or lanes) else min(n_lanes, 6)
+        if args.hint:
+            ws.hint_in_flight(args.hint)
+        d_accepts = [torch.zeros(B, dtype=torch.uint8, device=dev) for _ in range(RING)]
+        d_statuses = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(RING)]
+        cs = caller.cuda_stream
+        torch.cuda.synchronize()
+
+        def step(k):
+            if mode == "rlc":
+                dp.verify_batch_rlc_device(*batch_ptrs(d_accepts[k % RING], d_statuses[k % RING]), ws=ws, stream=cs, seed=rlc_seed)
+            else:
+                dp.verify_batch_device(*batch_ptrs(d_accepts[k % RING], d_statuses[k % RING]), ws=ws, stream=cs)
+
+        for k in range(max(warmup, n_lanes)):   # untimed; at least one step on every lane (a lane's first use creates it)
+            step(k)
+        ws.join(cs)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k)
+        ws.join(cs)
+        recv = None
+        if gather and world > 1:
+            with torch.cuda.stream(caller):
+                recv = gather_all(d_accepts, steps, RING)
+        el = finish_timing(t0)
+        if recv is not None and rank == 0:
+            check_gathered(recv)
+        ok = all(expected_ok(d_accepts[(steps - 1 - j) % RING].cpu().numpy()) for j in range(min(steps, RING)))
+        return Run(el, d_accepts[(steps - 1) % RING].cpu().numpy(), lambda j: ws.timings(j), lambda j: ws.rlc_result(calls_back=j), ws.close, in_flight, ok)
+
+    def streams_run(mode, inflight, steps, warmup, gather, sync_every_step=False):
+        """--pipeline streams (round 2): `inflight` workspaces on `inflight` torch streams, driven from here"""
         wss = [backend.Workspace(dp, B) for _ in range(inflight)]
         for w_ in wss:
             w_.hint_in_flight(args.hint or inflight)     # (from 4 up the library prefers launch shapes that issue fewer instructions)
@@ -209,9 +316,6 @@ def main():
         streams = stream_pool[:inflight] if inflight > 1 else [None]
         d_accepts = [torch.zeros(B, dtype=torch.uint8, device=dev) for _ in range(inflight)]
         d_statuses = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(inflight)]
-        use_gather = gather and world > 1
-        g_send = [torch.zeros(Bmax, dtype=torch.uint8, device=cdev) for _ in range(inflight)] if use_gather else None
-        gathered = [[torch.zeros(Bmax, dtype=torch.uint8, device=cdev) for _ in range(world)] for _ in range(inflight)] if (use_gather and rank == 0) else None
         torch.cuda.synchronize()
 
         def step(k):
@@ -222,19 +326,15 @@ def main():
                 ctx.__enter__()
             try:
                 stream = torch.cuda.current_stream().cuda_stream
-                ptrs = (B, d_proofs.data_ptr(), d_off.data_ptr(), d_inst.data_ptr(), d_ci.data_ptr() if d_ci is not None else None,
-                        d_accepts[slot].data_ptr(), d_statuses[slot].data_ptr())
                 if mode == "rlc":
-                    dp.verify_batch_rlc_device(*ptrs, ws=wss[slot], stream=stream, seed=rlc_seed, one_stream=inflight >= 3)
+                    dp.verify_batch_rlc_device(*batch_ptrs(d_accepts[slot], d_statuses[slot]), ws=wss[slot], stream=stream, seed=rlc_seed, one_stream=inflight >= 3)
                 else:
-                    dp.verify_batch_device(*ptrs, ws=wss[slot], stream=stream)
-                if use_gather:
-                    # final accept/reject gather over RCCL (xGMI): the rank's accept bytes (padded to the widest shard)
-                    g_send[slot][:B].copy_(d_accepts[slot])
-                    dist.gather(g_send[slot], gathered[slot] if gathered else None, dst=0)
+                    dp.verify_batch_device(*batch_ptrs(d_accepts[slot], d_statuses[slot]), ws=wss[slot], stream=stream)
             finally:
                 if ctx is not None:
                     ctx.__exit__(None, None, None)
+            if sync_every_step:
+                torch.cuda.synchronize()
 
         for k in range(max(warmup, inflight)):   # untimed; at least one step on every workspace (their first use allocates)
             step(k)
@@ -244,20 +344,21 @@ def main():
         t0 = time.perf_counter()
         for k in range(steps):
             step(k)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        el = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        if gathered is not None:   # rank 0: what arrived over the collective is every rank's (all-accepting) vector
-            sizes = [shard.shard_range(B_arg, r, world)[1] - shard.shard_range(B_arg, r, world)[0] if args.scaling == "strong" else B_arg
-                     for r in range(world)]
-            last = gathered[(steps - 1) % inflight]
-            gather_state["ok"] = all(bool(last[r][:sizes[r]].all().item()) for r in range(world))
-        return el, wss, d_accepts[(steps - 1) % inflight].cpu().numpy()
+        recv = None
+        if gather and world > 1:
+            torch.cuda.synchronize()
+            recv = gather_all(d_accepts, steps, inflight)
+        el = finish_timing(t0)
+        if recv is not None and rank == 0:
+            check_gathered(recv)
+
+        def close():
+            for w_ in wss:
+                w_.close()
+        ok = all(expected_ok(d_accepts[(steps - 1 - j) % inflight].cpu().numpy()) for j in range(min(steps, inflight)))
+        return Run(el, d_accepts[(steps - 1) % inflight].cpu().numpy(),
+                   lambda j: wss[(steps - 1 - j) % inflight].timings(j // inflight),
+                   lambda j: wss[(steps - 1 - j) % inflight].rlc_result(calls_back=j // inflight), close, inflight, ok)
 
     def pick_inflight(mode, candidates):
         """a few untimed steps with each candidate number of steps in flight; returns (best, {candidate: ms per step})"""
@@ -266,10 +367,9 @@ def main():
         seen = {}
         for cand in candidates:
             k = args.steps            # as many steps as the timed region: filling and draining the pipeline count the same
-            el_, w_, _a = timed_run(mode, cand, k, min(args.warmup, 3), False)
-            for x in w_:
-                x.close()
-            seen[cand] = round(el_ / k * 1e3, 4)
+            r_ = streams_run(mode, cand, k, min(args.warmup, 3), False)
+            r_.close()
+            seen[cand] = round(r_.el / k * 1e3, 4)
         best = min(seen, key=seen.get)
         if world > 1:   # every rank the same count (the slowest rank's view decides nothing: take rank 0's)
             t = torch.tensor([best], device=cdev)
@@ -277,75 +377,73 @@ def main():
             best = int(t.item())
         return best, seen
 
+    PP_KEYS = ["transcript_combiner", "g1_decompress", "g1_msm", "pairing"]
+    RLC_KEYS = ["transcript_combiner", "g1_decompress", "rlc_prepare", "bucket_sort", "bucket_accumulate", "bucket_reduce", "pairing"]
+
+    def kernel_times(run, mode, k_steps):
+        """averages of the event-timed kernel durations over the last k_steps steps of a run"""
+        info = {}
+        if mode == "rlc":
+            acc = {k: 0.0 for k in RLC_KEYS}
+            span, all_ok = 0.0, True
+            for j in range(k_steps):
+                ok, tm = run.rlc_result(j)
+                all_ok = all_ok and ok
+                for nm, v in zip(RLC_KEYS, [tm.transcript_combiner_ms, tm.g1_decompress_ms, tm.prepare_ms, tm.bucket_sort_ms,
+                                            tm.bucket_accumulate_ms, tm.bucket_reduce_ms, tm.pairing_ms]):
+                    acc[nm] += v
+                span += tm.total_ms
+                info = {"msm_terms": tm.msm_terms, "window_bits": tm.window_bits, "windows_per_glv_half": tm.windows, "max_entries_per_lane": tm.max_chain}
+            return {k: v / k_steps for k, v in acc.items()}, span / k_steps, dict(launches=1, msm_lpt=0, pair_lanes=64, rlc_shape=info, all_batch_ok=all_ok)
+        acc = {k: 0.0 for k in PP_KEYS}
+        span, launches, msm_lpt, pair_lanes = 0.0, 1, 2, 32
+        for j in range(k_steps):
+            tm = run.timings(j)
+            launches = max(1, tm.launches)
+            msm_lpt = tm.msm_lanes_per_term or 2
+            pair_lanes = tm.pairing_lanes_per_proof or 32
+            for nm, v in zip(PP_KEYS, [tm.transcript_combiner_ms, tm.g1_decompress_ms, tm.g1_msm_ms, tm.pairing_ms]):
+                acc[nm] += v
+            span += tm.total_ms
+        return {k: v / k_steps for k, v in acc.items()}, span / k_steps, dict(launches=launches, msm_lpt=msm_lpt, pair_lanes=pair_lanes, rlc_shape=None, all_batch_ok=None)
+
     gather_state = {"ok": None}
     if args.timed_only:
         args.no_cpu_baseline = args.no_rlc_secondary = True
         inflight_candidates = inflight_candidates[:1]
-    # with several steps in flight the event-timed kernel durations include what the kernels lose to each other; a short
-    # pass with ONE step in flight gives the kernels' own durations beside them.  It runs FIRST: after runs with many
-    # streams the runtime may map the combiner's and the decompression's stream onto one hardware queue, and the event-timed
-    # duration of the second then includes its wait for the first (combiner 1.5 instead of 0.66 ms).
-    kernel_ms_alone = None
-    if args.mode == "per-proof" and not args.timed_only and len(inflight_candidates) > 1:
-        _el1, wss1, _acc1 = timed_run("per-proof", 1, 5, 3, False)
-        a1 = {"transcript_combiner": 0.0, "g1_decompress": 0.0, "g1_msm": 0.0, "pairing": 0.0}
-        for j in range(5):
-            tm = wss1[0].timings(j)
-            a1["transcript_combiner"] += tm.transcript_combiner_ms / 5; a1["g1_decompress"] += tm.g1_decompress_ms / 5
-            a1["g1_msm"] += tm.g1_msm_ms / 5; a1["pairing"] += tm.pairing_ms / 5
-        kernel_ms_alone = dict(a1, ms_per_step=_el1 / 5 * 1e3, msm_lpt=tm.msm_lanes_per_term or 2, pair_lanes=tm.pairing_lanes_per_proof or 32)
-        wss1[0].close()
-        del wss1
-    inflight, inflight_probe = pick_inflight(args.mode, inflight_candidates)
-    elapsed, wss, accept = timed_run(args.mode, inflight, args.steps, args.warmup, True)
-
-    # per-kernel device time over the timed steps (HIP events recorded on the kernels' own streams, event rings of the
-    # workspaces): averages over the last min(steps, 64) steps
-    k_steps = min(args.steps, 64)
-    rlc_shape = None
-    if args.mode == "rlc":
-        names = ["transcript_combiner", "g1_decompress", "rlc_prepare", "bucket_sort", "bucket_accumulate", "bucket_reduce", "pairing"]
-        acc = {k: 0.0 for k in names}
-        span = 0.0
-        all_batch_ok = True
-        for j in range(k_steps):
-            slot = (args.steps - 1 - j) % inflight
-            ok, tm = wss[slot].rlc_result(calls_back=j // inflight)
-            all_batch_ok = all_batch_ok and ok
-            for nm, v in zip(names, [tm.transcript_combiner_ms, tm.g1_decompress_ms, tm.prepare_ms, tm.bucket_sort_ms,
-                                     tm.bucket_accumulate_ms, tm.bucket_reduce_ms, tm.pairing_ms]):
-                acc[nm] += v
-            span += tm.total_ms
-            rlc_shape = {"msm_terms": tm.msm_terms, "window_bits": tm.window_bits, "windows_per_glv_half": tm.windows,
-                         "max_entries_per_lane": tm.max_chain}
-        kernel_ms = {k: v / k_steps for k, v in acc.items()}
-        batch_latency_ms = span / k_steps
-        launches, msm_lpt, pair_lanes = 1, 0, 64
+    inflight_probe = None
+    if args.pipeline == "streams":
+        inflight, inflight_probe = pick_inflight(args.mode, inflight_candidates)
+        run = streams_run(args.mode, inflight, args.steps, args.warmup, True)
     else:
-        acc = {"transcript_combiner": 0.0, "g1_decompress": 0.0, "g1_msm": 0.0, "pairing": 0.0}
-        launches, msm_lpt, span, pair_lanes = 1, 2, 0.0, 32
-        for j in range(k_steps):
-            slot = (args.steps - 1 - j) % inflight
-            tm = wss[slot].timings(j // inflight)
-            launches = max(1, tm.launches)
-            msm_lpt = tm.msm_lanes_per_term or 2
-            pair_lanes = tm.pairing_lanes_per_proof or 32
-            acc["transcript_combiner"] += tm.transcript_combiner_ms
-            acc["g1_decompress"] += tm.g1_decompress_ms
-            acc["g1_msm"] += tm.g1_msm_ms
-            acc["pairing"] += tm.pairing_ms
-            span += tm.total_ms
-        kernel_ms = {k: v / k_steps for k, v in acc.items()}
-        batch_latency_ms = span / k_steps
-        all_batch_ok = None
+        run = lanes_run(args.mode, args.steps, args.warmup, True)
+        inflight = run.in_flight
+    elapsed, accept = run.el, run.accept
+    k_steps = min(args.steps, 48)
+    kernel_ms_overlapped, batch_latency_ms, shape = kernel_times(run, args.mode, k_steps)
+    launches, msm_lpt, pair_lanes, rlc_shape, all_batch_ok = shape["launches"], shape["msm_lpt"], shape["pair_lanes"], shape["rlc_shape"], shape["all_batch_ok"]
+    steps_ok = run.all_steps_ok
+    run.close()
+    # The kernels' OWN durations: with several steps in flight the event-timed durations above include what the kernels lose
+    # to each other (a pairing launch "takes" 9 ms of a 4.3 ms step).  A second pass runs ONE step at a time - same launch
+    # shapes (the in-flight hint of the timed run), the host synchronises after every step - and `roofline` / `int_roofline`
+    # are computed from ITS durations; the overlapped ones are reported beside them.
+    alone = None
+    if inflight > 1 or args.timed_only:
+        saved_hint = args.hint
+        args.hint = args.hint or inflight
+        r1 = streams_run(args.mode, 1, 6, 2, False, sync_every_step=True)
+        args.hint = saved_hint
+        kernel_ms, _lat1, shape1 = kernel_times(r1, args.mode, 6)
+        alone = {"ms_per_step": r1.el / 6 * 1e3, "msm_lpt": shape1["msm_lpt"], "pair_lanes": shape1["pair_lanes"]}
+        if shape1["msm_lpt"] != msm_lpt or shape1["pair_lanes"] != pair_lanes:
+            alone["note"] = "launch shapes differ from the timed run's"
+        msm_lpt, pair_lanes = shape1["msm_lpt"], shape1["pair_lanes"]
+        r1.close()
+    else:
+        kernel_ms = kernel_ms_overlapped
 
-    if inflight <= 1:
-        kernel_ms_alone = None
-    if kernel_ms_alone is not None:
-        for w_ in wss[1:]:
-            w_.close()            # (their event rings have been read; their streams give their hardware queues back)
-    n_accept = int(accept.sum())
-    ok_all = n_accept == B  # the synthetic batch is 100 % accepting
+    ok_all = bool(steps_ok)   # every checked step returned exactly the expected vector (all ones, or the reject dataset's)
     if world > 1:
         flag = torch.tensor([1 if ok_all else 0], device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -355,30 +453,33 @@ def main():
     # timed region - and reported under "rlc_mode" of the one JSON line; `value` stays the per-proof figure the BASELINE
     # config ("G1 MSM + one pairing per proof") names.
     rlc_secondary = None
-    if args.mode == "per-proof" and not args.no_rlc_secondary and vk.recursion_vks is None:
-        for w_ in wss[1:]:
-            w_.close()
-        inflight2, probe2 = pick_inflight("rlc", [11, 7, 5, 3, 1])
-        el2, wss2, acc2 = timed_run("rlc", inflight2, args.steps, args.warmup, False)
-        ok2, tm2 = wss2[0].rlc_result()
-        rlc_secondary = {"value": round(B_total * args.steps / el2, 2), "unit": "proofs/s", "ms_per_step": round(el2 / args.steps * 1e3, 4),
-                         "steps_in_flight": inflight2, "inflight_probe_ms_per_step": probe2, "all_accepted": bool(int(acc2.sum()) == B), "batch_check_passed": ok2,
+    if args.mode == "per-proof" and not args.no_rlc_secondary and vk.recursion_vks is None and timed_expected is None:
+        if args.pipeline == "streams":
+            inflight2, probe2 = pick_inflight("rlc", [11, 7, 5, 3, 1])
+            r2 = streams_run("rlc", inflight2, args.steps, args.warmup, False)
+        else:
+            r2, probe2 = lanes_run("rlc", args.steps, args.warmup, False), None
+            inflight2 = r2.in_flight
+        ok2, tm2 = r2.rlc_result(0)
+        rlc_secondary = {"value": round(B_total * args.steps / r2.el, 2), "unit": "proofs/s", "ms_per_step": round(r2.el / args.steps * 1e3, 4),
+                         "steps_in_flight": inflight2, "inflight_probe_ms_per_step": probe2, "all_accepted": bool(r2.all_steps_ok), "batch_check_passed": ok2,
                          "bucket_msm_terms": tm2.msm_terms, "k_pip_accumulate_ms": round(tm2.bucket_accumulate_ms, 4),
                          "msm_GBps_algorithmic": round((128 * tm2.msm_terms + 144) / (tm2.bucket_accumulate_ms * 1e-3) / 1e9, 3) if tm2.bucket_accumulate_ms > 0 else None,
-                         "note": "python bench.py --mode rlc prints the full line (roofline of the bucket kernel, kernel times)"}
-        for w_ in wss2:
-            w_.close()
-        del wss2
+                         "note": "ALL-HONEST-PROVERS figure (a batch with a rejecting proof pays the fall-back: --mode rlc --reject-count 1); "
+                                 "python bench.py --mode rlc prints the full line"}
+        r2.close()
 
     # second dataset (untimed): 1 % of the proofs get the reference example's byte flip (examples/simple_mul.rs:87-95,
     # first scalar of the proof) - exactly those proofs must be rejected (rlc: through the per-proof fall-back)
     reject_check = None
     if rank == 0 and not args.timed_only:
         rej = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.01, seed=77, kinds=["flip_first_scalar"])
+        ws_r = backend.Workspace(dp, B)
         if args.mode == "rlc":
-            got, fell_back = dp.verify_batch_rlc(rej.proofs, rej.proof_off, rej.instances, rej.committed, ws=wss[0])
+            got, fell_back = dp.verify_batch_rlc(rej.proofs, rej.proof_off, rej.instances, rej.committed, ws=ws_r)
         else:
-            got, fell_back = dp.verify_batch(rej.proofs, rej.proof_off, rej.instances, rej.committed, ws=wss[0]), None
+            got, fell_back = dp.verify_batch(rej.proofs, rej.proof_off, rej.instances, rej.committed, ws=ws_r), None
+        ws_r.close()
         reject_check = {"fraction": 0.01, "corrupted": rej.expected.count(0), "rejected": int(B - sum(got)),
                         "exactly_the_corrupted_ones": list(got) == rej.expected, "fell_back_to_per_proof_kernels": fell_back}
 
@@ -455,10 +556,12 @@ def main():
         def roof(k):
             # the contract's HBM roofline of one kernel: ALGORITHMIC bytes per launch / its average launch duration
             gbps = bytes_per_launch[k] / (kernel_ms[k] * 1e-3) / 1e9 if kernel_ms[k] > 0 else 0.0
-            traffic, src = pmc_traffic(kname[k], args.workload, B, args.mode)
+            traffic, traffic_raw, src = pmc_traffic(kname[k], args.workload, B, args.mode)
             return {"kernel": kname[k], "bound": "hbm", "achieved": round(gbps, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(gbps / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": src,
-                    "avg_launch_ms": round(kernel_ms[k] / launches, 4), "launches_per_step": launches,
+                    "frac": round(gbps / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_uncorrected_fetch_plus_write": traffic_raw, "traffic_source": src,
+                    "avg_launch_ms": round(kernel_ms[k] / launches, 4),
+                    "duration_is": "the kernel's own (one step at a time, same launch shape)" if alone else "from the timed steps (one step in flight)",
+                    "avg_launch_ms_in_the_timed_steps": round(kernel_ms_overlapped[k] / launches, 4), "launches_per_step": launches,
                     "algorithmic_bytes_per_launch": bytes_per_launch[k] // launches,
                     "note": "integer-issue bound (see int_roofline): ~10^5 multiply-adds per 128-byte MSM term"}
 
@@ -470,6 +573,8 @@ def main():
                     "mads_per_launch": mads[k] // launches}
 
         dominant = max(kernel_ms, key=kernel_ms.get)
+        # what feeds `roofline` must be a duration the step can contain
+        assert kernel_ms[dominant] / launches <= elapsed / args.steps * 1e3 * 1.05 or not alone, (kernel_ms, elapsed / args.steps * 1e3)
         result = {
             "metric": "halo2_proofs_verified_per_sec",
             "value": round(B_total * args.steps / elapsed, 2),
@@ -485,22 +590,27 @@ def main():
             "data": "synthetic",
             "config": {"workload": label, "mode": args.mode, "proofs_per_gpu": B, "proofs_per_step_all_gpus": B_total, "proof_bytes": pl.proof_len,
                        "msm_terms_per_proof": T, "g1_points_per_proof": slots, "public_inputs": pl.n_pi, "plan_instructions": len(pl.instrs),
+                       "pipeline": "lanes (one laned workspace, one caller stream; the library keeps the steps in flight)" if args.pipeline == "lanes"
+                                   else "streams (caller-driven: one workspace and one torch stream per step in flight)",
                        "steps_in_flight": inflight, "inflight_probe_ms_per_step": inflight_probe,
-                       "parallelism": ("independent proofs sharded per GPU (%s); accept gather over RCCL" % args.scaling) if world > 1 else "1 GPU"},
+                       "timed_dataset": "all accepting" if timed_expected is None else "%d of %d proofs corrupted" % (timed_expected.count(0), B),
+                       "parallelism": ("independent proofs sharded per GPU (%s); accept bytes of all steps gathered once over %s" % (
+                           args.scaling, "RCCL" if args.dist_backend == "nccl" else "gloo (rehearsal)")) if world > 1 else "1 GPU"},
             "roofline": roof(dominant),
             "msm_roofline": roof(msm_key),
             "int_roofline": int_roof(dominant),
             "msm_int_roofline": int_roof(msm_key),
             "kernel_ms": {kname[k]: round(v, 4) for k, v in kernel_ms.items()},
-            "kernel_ms_one_step_in_flight": ({shape_names(kernel_ms_alone["msm_lpt"], kernel_ms_alone["pair_lanes"])[k]: round(v, 4)
-                                              for k, v in kernel_ms_alone.items() if k in kname} if kernel_ms_alone and args.mode == "per-proof" else None),
-            "ms_per_step_one_step_in_flight": round(kernel_ms_alone["ms_per_step"], 4) if kernel_ms_alone else None,
+            "kernel_ms_is": "each kernel's own duration, one step at a time" if alone else "durations in the timed steps",
+            "kernel_ms_in_the_timed_steps": {kname[k]: round(v, 4) for k, v in kernel_ms_overlapped.items()},
+            "ms_per_step_one_step_at_a_time": round(alone["ms_per_step"], 4) if alone else None,
             "step_int_roofline": {"what": "analytical lane-level multiply-adds of ALL kernels of a step / ms_per_step, against the measured v_mad_u64_u32 ceiling",
                                   "achieved": round(sum(mads.values()) / (elapsed / args.steps) / 1e12, 3), "peak": round(IMAD_PEAK_TOPS, 2) if IMAD_PEAK_TOPS else None,
                                   "unit": "T lane-mad/s", "frac": round(sum(mads.values()) / (elapsed / args.steps) / 1e12 / IMAD_PEAK_TOPS, 4) if IMAD_PEAK_TOPS else None},
             "batch_latency_ms": round(batch_latency_ms, 4),
             "pipelines_per_step": launches, "msm_lanes_per_term": msm_lpt, "pairing_lanes_per_proof": pair_lanes if args.mode == "per-proof" else None,
-            "all_accepted": ok_all,
+            "all_accepted": ok_all if timed_expected is None else None,
+            "verdicts_as_expected_every_checked_step": ok_all,
             "gathered_accept_vectors_all_ones": gather_state["ok"],
             "reject_dataset": reject_check,
             "forge_seconds": round(t_forge, 2),
@@ -520,7 +630,7 @@ def main():
         dist.barrier()   # rank 0 is still checking the reject dataset / printing: leave together
         dist.destroy_process_group()
     if not ok_all:
-        raise SystemExit("bench: GPU rejected proofs of an all-accepting synthetic batch")
+        raise SystemExit("bench: the GPU's verdict vector differs from the synthetic batch's expected one")
 
 
 def cpu_baseline(vk, batch, pl, sample, gpu_accept):

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -79,6 +80,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise H2VError("HIP backend library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)" % LIB_PATH)
+        # PyTorch-ROCm bundles its own copy of the HIP runtime under the system's soname.  If this library came first, the
+        # process would hold /opt/rocm's runtime and a later `import torch` could no longer see the GPU ("No HIP GPUs are
+        # available"): a Python host that may hand over torch tensors lets torch load its runtime first.
+        if "torch" not in sys.modules and os.environ.get("H2V_NO_TORCH_PRELOAD") is None:
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         L.h2v_last_error.restype = C.c_char_p
         L.h2v_build_id.restype = C.c_char_p

@@ -92,7 +92,6 @@ struct h2v_workspace {
     uint8_t ring_pipes[RING] = {}, ring_split[RING] = {}, ring_lpt[RING] = {}, ring_pair[RING] = {};
     uint64_t calls = 0;
     struct RlcWs *rlc = nullptr;   // buffers of the RLC batch mode, created by its first call
-    hipEvent_t p1_event = nullptr;  // (owned by the parent of a lane) recorded when phase 1 of a call on this workspace is enqueued
     int one_stream_mode = -1;      // lanes: 1 = the whole pipeline on the stream it is given (-1: decided from the hint)
     // ---- lanes (h2v_workspace_create_lanes): a laned workspace owns no kernel buffers of its own, only n_lanes ordinary
     // workspaces of `chunk` proofs and one library-owned stream per lane.  A verify call is cut into chunks that go round
@@ -102,15 +101,16 @@ struct h2v_workspace {
     h2v_workspace *lane[MAXL] = {};
     hipStream_t lane_st[MAXL] = {};
     hipEvent_t lane_ev[MAXL] = {};         // end of the lane's most recent chunk
-    hipEvent_t lane_p1[MAXL] = {};         // end of phase 1 (decompression + combiner) of the lane's most recent chunk
     bool lane_busy[MAXL] = {};             // work enqueued since the last join
     bool defer_joins = false;
-    int stagger = 1;                        // chunk c starts its phase 1 when chunk c - 1 has finished its own
+    uint32_t lanes_per_proof = 0;           // lanes the per-proof mode cycles through (the RLC mode uses all n_lanes)
     uint64_t next_lane = 0;                 // round-robin position (persists across calls: consecutive calls interleave)
-    uint64_t last_p1_lane = ~0ull;
+    H2vDevPlan lane_plan{};                 // the creating plan's shape: lanes are created when first used
+    uint32_t *rlc_fail = nullptr;           // RING counters: failed batch checks among the chunks of a call (RLC mode)
+    uint32_t *rlc_fail_ptr = nullptr;       // (a lane: where its batch check reports a failure; set by the parent per call)
     // per call (ring): number of chunks, first lane, and every lane's call counters when the call had been enqueued -
     // what h2v_workspace_timings / _rlc_result need to find the chunks' event sets in the lanes' own rings
-    uint32_t lring_chunks[RING] = {}, lring_first[RING] = {};
+    uint32_t lring_chunks[RING] = {}, lring_first[RING] = {}, lring_mod[RING] = {};
     uint64_t lring_calls[RING][MAXL] = {}, lring_rlc_calls[RING][MAXL] = {};
     uint8_t lring_rlc[RING] = {};
 };
@@ -374,27 +374,26 @@ extern "C" int h2v_plan_trace_slots(const h2v_plan *p, uint32_t *slot_ids, uint3
 
 // ---------------------------------------------------------------------------------------------- workspace
 static void rlc_release(struct RlcWs *r);
+static hipError_t make_stream(hipStream_t *s);
 static void ws_release(h2v_workspace *w) {
     (void)hipSetDevice(w->device);
-    for (uint32_t l = 0; l < w->n_lanes; l++) {
+    for (uint32_t l = 0; l < (uint32_t)h2v_workspace::MAXL; l++) {
         if (w->lane_st[l]) { (void)hipStreamSynchronize(w->lane_st[l]); }
         if (w->lane[l]) { ws_release(w->lane[l]); delete w->lane[l]; w->lane[l] = nullptr; }
-        if (w->lane_st[l]) (void)hipStreamDestroy(w->lane_st[l]);
         if (w->lane_ev[l]) (void)hipEventDestroy(w->lane_ev[l]);
-        if (w->lane_p1[l]) (void)hipEventDestroy(w->lane_p1[l]);
     }
     w->n_lanes = 0;
     if (w->rlc) { rlc_release(w->rlc); w->rlc = nullptr; }
-    void *ptrs[] = {w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->er_fix, w->dec_ctr, w->accept, w->in_block, w->msm_tab,
+    void *ptrs[] = {w->rlc_fail, w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->er_fix, w->dec_ctr, w->accept, w->in_block, w->msm_tab,
                     w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2, w->pt_tab};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (w->h_block) (void)hipHostFree(w->h_block);
     if (w->h_accept) (void)hipHostFree(w->h_accept);
-    if (w->hs) (void)hipStreamDestroy(w->hs);
+    if (w->hs) (void)hipStreamSynchronize(w->hs);   // (pool streams are shared and never destroyed: make_stream)
     if (w->ev_host) (void)hipEventDestroy(w->ev_host);
-    for (hipStream_t q : w->pmain) if (q) (void)hipStreamDestroy(q);
-    for (hipStream_t q : w->pside) if (q) (void)hipStreamDestroy(q);
-    for (hipStream_t q : w->psub) if (q) (void)hipStreamDestroy(q);
+    for (hipStream_t q : w->pmain) if (q) (void)hipStreamSynchronize(q);
+    for (hipStream_t q : w->pside) if (q) (void)hipStreamSynchronize(q);
+    for (hipStream_t q : w->psub) if (q) (void)hipStreamSynchronize(q);
     for (hipEvent_t e : w->ev_sub) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : w->ev_fix) if (e) (void)hipEventDestroy(e);
     if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
@@ -458,45 +457,54 @@ static uint32_t default_chunk(const H2vDevPlan &d) {
     while (c < 4096 && (double)c * 1.4142 < want) c <<= 1;
     return c;
 }
-#define H2V_DEFAULT_LANES 8u
+// Lanes: measured on MI355X, simple_mul, a stream of 4096-proof batches through one laned workspace (deferred joins; ms per
+// batch): per-proof mode, each lane's pipeline on the lane's stream with the decompression beside it on a side stream:
+// 4 lanes 4.60, 5: 4.35, 6: 4.31, 11: 4.72; everything on the lane's stream: 5: 4.64, 8: 4.26, 11: 4.43 (five caller-owned
+// workspaces on fifteen streams, round 2's bench: 4.50); RLC mode (one stream per lane): 8 lanes 1.65, 11: 1.54, 16: 1.47.
+#define H2V_DEFAULT_LANES 11u
+#define H2V_PER_PROOF_LANES 6u
+static int ensure_lane(h2v_workspace *w, uint32_t l) {
+    if (w->lane[l]) return H2V_OK;
+    h2v_workspace *lw = nullptr;
+    int rc = ws_create_for(w->lane_plan, w->device, w->chunk, false, &lw);
+    if (rc) return rc;
+    w->lane[l] = lw;
+    lw->one_stream_mode = 2;            // the pipeline on the lane's stream, the decompression beside it on one side stream
+    if (const char *e = getenv("H2V_LANE_ONE_STREAM")) lw->one_stream_mode = atoi(e);   // experiment knob, read per creation
+    lw->in_flight_hint = w->in_flight_hint > w->n_lanes ? w->in_flight_hint : w->n_lanes;
+    if (make_stream(&w->lane_st[l]) != hipSuccess || hipEventCreateWithFlags(&w->lane_ev[l], hipEventDisableTiming) != hipSuccess)
+        return fail(H2V_E_DEVICE, "lane stream / event creation failed");
+    return H2V_OK;
+}
 extern "C" int h2v_workspace_create_lanes(const h2v_plan *p, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk, h2v_workspace **out) {
     if (!p || !out) return fail(H2V_E_ARG, "null argument");
     if (max_batch == 0 || max_batch > (1ull << 24)) return fail(H2V_E_ARG, "max_batch out of range");
     if (n_lanes > (uint32_t)h2v_workspace::MAXL) return fail(H2V_E_ARG, "at most 16 lanes");
     if (chunk == 0) chunk = default_chunk(p->d);
     if ((uint64_t)chunk > max_batch) chunk = (uint32_t)max_batch;
-    const uint64_t n_chunks = (max_batch + chunk - 1) / chunk;
-    if (n_lanes == 0) n_lanes = H2V_DEFAULT_LANES;
-    if ((uint64_t)n_lanes > n_chunks && !false) { /* more lanes than one call can use still serve consecutive calls (deferred joins) */ }
     HIPCHK(hipSetDevice(p->device));
     h2v_workspace *w = new h2v_workspace();
     w->device = p->device; w->cap = max_batch; w->chunk = chunk;
     w->stride = (uint32_t)((max_batch + 63) / 64 * 64);
     const H2vDevPlan &d = p->d;
-    w->sz_terms = d.n_terms; w->sz_slots = (uint32_t)H2V_SLOTS(d); w->sz_regs = 0; w->sz_trace = 0; w->sz_ivc = d.ivc != 0; w->sz_fix = d.fix_tab != nullptr;
-    bool ok = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) == hipSuccess && hipMalloc((void **)&w->accept, (size_t)max_batch) == hipSuccess;
-    for (uint32_t l = 0; l < n_lanes && ok; l++) {
-        h2v_workspace *lw = nullptr;
-        ok = ws_create_for(d, p->device, chunk, false, &lw) == H2V_OK;
-        if (!ok) break;
-        w->lane[l] = lw;
-        w->n_lanes = l + 1;
-        ok = hipStreamCreateWithFlags(&w->lane_st[l], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&w->lane_ev[l], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&w->lane_p1[l], hipEventDisableTiming) == hipSuccess;
-        lw->p1_event = w->lane_p1[l];
-        lw->one_stream_mode = 1;            // one stream per lane: n_lanes streams in all, whatever the hardware-queue count
-        lw->in_flight_hint = n_lanes;
-    }
+    w->lane_plan = d;
+    w->sz_terms = d.n_terms; w->sz_slots = (uint32_t)H2V_SLOTS(d); w->sz_regs = vm_lds_slots(d) == 0 ? d.n_regs : 0; w->sz_trace = 0; w->sz_ivc = d.ivc != 0; w->sz_fix = d.fix_tab != nullptr;
+    w->lanes_per_proof = n_lanes ? n_lanes : H2V_PER_PROOF_LANES;     // an explicit lane count holds for both modes
+    w->n_lanes = n_lanes ? n_lanes : H2V_DEFAULT_LANES;
+    w->in_flight_hint = w->n_lanes;
+    bool ok = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) == hipSuccess && hipMalloc((void **)&w->accept, (size_t)max_batch) == hipSuccess &&
+              hipMalloc((void **)&w->rlc_fail, h2v_workspace::RING * 4) == hipSuccess && hipMemset(w->rlc_fail, 0, h2v_workspace::RING * 4) == hipSuccess;
+    // the first lane now (an allocation failure surfaces here, not in the middle of a verify call); the others on first use
+    if (ok) ok = ensure_lane(w, 0) == H2V_OK;
     if (!ok) { const std::string e = g_err; ws_release(w); delete w; return fail(H2V_E_DEVICE, "lane creation failed: " + e); }
-    if (const char *e = getenv("H2V_LANE_STAGGER")) w->stagger = atoi(e);          // experiment knobs, read per creation
-    if (const char *e = getenv("H2V_LANE_ONE_STREAM")) for (uint32_t l = 0; l < w->n_lanes; l++) w->lane[l]->one_stream_mode = atoi(e);
     *out = w;
     return H2V_OK;
 }
 extern "C" int h2v_workspace_create(const h2v_plan *p, uint64_t max_batch, h2v_workspace **out) {
     if (!p || !out) return fail(H2V_E_ARG, "null argument");
-    // a workspace for batches of at least two chunks is laned: the call is pipelined inside the library
-    if (max_batch >= 2ull * default_chunk(p->d)) return h2v_workspace_create_lanes(p, max_batch, 0, 0, out);
+    // a workspace for batches of at least four chunks is laned: the call is pipelined inside the library (measured,
+    // simple_mul: 8192 proofs in one launch per kernel 5.6 ms per 4096 against 5.9 in two chunks; 20480: 5.3 against 4.7)
+    if (max_batch >= 4ull * default_chunk(p->d)) return h2v_workspace_create_lanes(p, max_batch, 0, 0, out);
     return ws_create_for(p->d, p->device, max_batch, false, out);
 }
 extern "C" int h2v_workspace_lanes(const h2v_workspace *ws, uint32_t *n_lanes, uint32_t *chunk) {
@@ -531,7 +539,7 @@ extern "C" void h2v_workspace_free(h2v_workspace *w) {
 extern "C" int h2v_workspace_hint_in_flight(h2v_workspace *ws, uint32_t n_in_flight) {
     if (!ws || n_in_flight == 0) return fail(H2V_E_ARG, "bad argument");
     ws->in_flight_hint = n_in_flight;
-    for (uint32_t l = 0; l < ws->n_lanes; l++) ws->lane[l]->in_flight_hint = n_in_flight > ws->n_lanes ? n_in_flight : ws->n_lanes;
+    for (uint32_t l = 0; l < ws->n_lanes; l++) if (ws->lane[l]) ws->lane[l]->in_flight_hint = n_in_flight > ws->n_lanes ? n_in_flight : ws->n_lanes;
     return H2V_OK;
 }
 
@@ -553,11 +561,53 @@ static int ws_fits(const h2v_workspace *w, const h2v_plan *p, uint64_t n, bool w
     return H2V_OK;
 }
 
+// Library-owned streams.  The runtime multiplexes ordinary streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per
+// process, and kernels of two streams that share a queue run one after the other - with five batches in flight on three
+// streams each that is the difference between 5.7 and 4.3 ms per 4096-proof batch (round 2 needed GPU_MAX_HW_QUEUES=16 in
+// the caller's environment for it).  A stream created with an explicit CU mask gets a hardware queue of its own, whatever
+// the process-wide setting is (measured, default environment: 5 lanes 5.79 -> 4.34 ms per batch).  Every queue also gets
+// its own scratch arena, sized for the kernel with the largest private segment (a process that had created 47 of them
+// died with HSA_STATUS_ERROR_OUT_OF_RESOURCES at the next launch), so the library owns a fixed POOL of such streams per
+// device - H2V_QUEUE_POOL, default 12 - and hands them out round robin: workspaces share them (a stream is an ordering
+// domain, sharing one only adds order), they are never destroyed, and the mask names every CU.  Pool streams have the
+// default flags, i.e. they are ordered with the legacy NULL stream: callers that defer joins should not submit on the
+// NULL stream.  H2V_STREAM_CUMASK=0: plain non-blocking streams of the runtime's own pool instead.
+#include <mutex>
+static hipError_t make_stream(hipStream_t *s) {
+    static const int cumask = []() { const char *e = getenv("H2V_STREAM_CUMASK"); return e ? atoi(e) : 1; }();
+    static const size_t pool_cap = []() { const char *e = getenv("H2V_QUEUE_POOL"); const int v = e ? atoi(e) : 12; return (size_t)(v < 1 ? 1 : v > 32 ? 32 : v); }();
+    static std::mutex mu;
+    static std::vector<hipStream_t> pool[16];
+    static size_t next[16] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (pool[dev].size() < pool_cap) {
+        hipStream_t ns = nullptr;
+        if (cumask) {
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            std::vector<uint32_t> mask((cus + 31) / 32, 0xffffffffu);
+            if (cus % 32) mask.back() = (1u << (cus % 32)) - 1;
+            e = hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data());
+        } else {
+            e = hipStreamCreateWithFlags(&ns, hipStreamNonBlocking);
+        }
+        if (e != hipSuccess) return e;
+        pool[dev].push_back(ns);
+        *s = ns;
+        return hipSuccess;
+    }
+    *s = pool[dev][next[dev]++ % pool[dev].size()];
+    return hipSuccess;
+}
 // the main / side / third stream of pipeline chunk k, created when first asked for
 static int ws_streams(h2v_workspace *w, int k, bool need_main, bool need_side, bool need_sub) {
-    if (need_main && !w->pmain[k]) HIPCHK(hipStreamCreateWithFlags(&w->pmain[k], hipStreamNonBlocking));
-    if (need_side && !w->pside[k]) HIPCHK(hipStreamCreateWithFlags(&w->pside[k], hipStreamNonBlocking));
-    if (need_sub && !w->psub[k]) HIPCHK(hipStreamCreateWithFlags(&w->psub[k], hipStreamNonBlocking));
+    if (need_main && !w->pmain[k]) HIPCHK(make_stream(&w->pmain[k]));
+    if (need_side && !w->pside[k]) HIPCHK(make_stream(&w->pside[k]));
+    if (need_sub && !w->psub[k]) HIPCHK(make_stream(&w->psub[k]));
     return H2V_OK;
 }
 
@@ -834,10 +884,12 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         // streams per batch collide from the sixth batch on).  Measured, 40 steps of simple_mul x 4096: three streams 5 / 8 / 11
         // in flight 4.46 / 4.66 / 4.75 ms per step, one stream 4.80 / 4.39 / 4.50.  H2V_ONE_STREAM = 0 / 1 forces the choice.
         static const int env_one = []() { const char *e = getenv("H2V_ONE_STREAM"); return e ? atoi(e) : -1; }();
-        const bool one_stream = pipes == 1 && (w->one_stream_mode >= 0 ? w->one_stream_mode != 0 : env_one >= 0 ? env_one != 0 : w->in_flight_hint >= 6);
-        if (!one_stream)
-            if (int rcs = ws_streams(w, k, true, true, split_dec && !dec_queue_on)) return rcs;
-        hipStream_t pm = one_stream ? st : w->pmain[k], ps = one_stream ? st : w->pside[k];
+        const bool one_stream = pipes == 1 && (w->one_stream_mode >= 0 ? w->one_stream_mode == 1 : env_one >= 0 ? env_one != 0 : w->in_flight_hint >= 6);
+        // one_stream_mode 2 (lanes): the pipeline on the stream it is given, only the decompression beside it on a side stream
+        const bool two_stream = pipes == 1 && w->one_stream_mode == 2;
+        if (!one_stream || two_stream)
+            if (int rcs = ws_streams(w, k, !two_stream, true, !two_stream && split_dec && !dec_queue_on)) return rcs;
+        hipStream_t pm = (one_stream || two_stream) ? st : w->pmain[k], ps = (one_stream && !two_stream) ? st : w->pside[k];
         const uint64_t *off_k = off + lo;
         const uint8_t *inst_k = inst ? inst + (size_t)lo * d.n_pi * 32 : nullptr;
         const uint8_t *ci_k = ci ? ci + (size_t)lo * 48 : nullptr;
@@ -880,7 +932,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         auto sub_half = [&]() {
             // the subgroup tests as a launch of their own (only without the queue)
             if (!split_dec) return 0;
-            hipStream_t pb = (dec_queue || one_stream) ? ps : w->psub[k];   // (with the queue there is no third launch: only the events are recorded)
+            hipStream_t pb = (dec_queue || one_stream || two_stream) ? ps : w->psub[k];   // (with the queue there is no third launch: only the events are recorded)
             HIPCHK(hipStreamWaitEvent(pb, w->ev_fork, 0));
             HIPCHK(hipEventRecord(ev[7], pb));
             if (!dec_queue) hipLaunchKernelGGL(k_g1_decompress, dim3(dec_grid), dim3(64), 0, pb, d, m, proofs, off_k, ci_k, inst_k, pts_k, valid_k, (uint32_t *)nullptr, 2u, vsub_k);
@@ -895,7 +947,6 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         // The MSM also waits for the subgroup launch although it does not read its result: a merged-halves MSM relies on
         // finding every SIMD empty (one wave each: 1.9 ms; a SIMD shared with a leftover wave: 2.2 ms for the launch)
         if (split_dec) HIPCHK(hipStreamWaitEvent(pm, w->ev_sub[k], 0));
-        if (w->p1_event && k == pipes - 1) HIPCHK(hipEventRecord(w->p1_event, pm));
         HIPCHK(hipEventRecord(ev[4], pm));
         uint32_t *tab_k = d.ivc ? w->msm_tab + (size_t)lo * 4 * 2 * 8 * 28 : nullptr;   // fold MSMs only
         const IvcBufs ib = {d.ivc ? w->accl + (size_t)lo * 36 : nullptr, d.ivc ? w->accr + (size_t)lo * 36 : nullptr,
@@ -948,30 +999,35 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
                    uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, const uint32_t seed[8], bool one_stream_opt);
 static uint64_t rlc_calls_of(const h2v_workspace *w);
 // A call on a laned workspace: chunks of at most w->chunk proofs, round robin through the lanes (continuing where the
-// previous call stopped).  Chunk c runs on its lane's own stream behind (1) everything the caller had enqueued on `st`
-// before the call, (2) the lane's earlier chunks, and (3) - staggering - phase 1 of chunk c - 1, so that the phases of
-// neighbouring chunks interleave instead of running in lockstep.  rlc: every chunk is its own batch check.
+// previous call stopped).  Chunk c runs on its lane's own stream(s) behind everything the caller had enqueued on `st`
+// before the call and behind the lane's earlier chunks.  Nothing else orders the chunks: the kernels of neighbouring
+// chunks drift apart by themselves (a decompression launch wants every SIMD, so the second one queues behind the first),
+// and an explicit stagger - chunk c waiting for phase 1 of chunk c - 1 - measured 10-20 % slower.  rlc: every chunk is
+// its own batch check.
 static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
                      uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, bool rlc, const uint32_t *seed, bool force_join) {
     const H2vDevPlan &d = p->d;
-    const uint32_t L = w->n_lanes, nch = (n + w->chunk - 1) / w->chunk;
+    const uint32_t L = rlc ? w->n_lanes : (w->lanes_per_proof < w->n_lanes ? w->lanes_per_proof : w->n_lanes);
+    const uint32_t nch = (n + w->chunk - 1) / w->chunk;
     const int slot = (int)(w->calls % h2v_workspace::RING);
     w->calls++;
-    w->lring_chunks[slot] = nch; w->lring_first[slot] = (uint32_t)(w->next_lane % L); w->lring_rlc[slot] = rlc ? 1 : 0;
+    w->lring_chunks[slot] = nch; w->lring_first[slot] = (uint32_t)(w->next_lane % L); w->lring_mod[slot] = L; w->lring_rlc[slot] = rlc ? 1 : 0;
+    if (rlc) HIPCHK(hipMemsetAsync(w->rlc_fail + slot, 0, 4, st));
     HIPCHK(hipEventRecord(w->ev_fork, st));
     for (uint32_t c = 0; c < nch; c++) {
         const uint32_t l = (uint32_t)(w->next_lane++ % L);
+        int rc = ensure_lane(w, l);
+        if (rc) return rc;
         h2v_workspace *lw = w->lane[l];
         hipStream_t ls = w->lane_st[l];
         const uint32_t lo = c * w->chunk, m = (n - lo) < w->chunk ? (n - lo) : w->chunk;
         HIPCHK(hipStreamWaitEvent(ls, w->ev_fork, 0));
-        if (w->stagger && w->last_p1_lane != ~0ull && w->last_p1_lane != l) HIPCHK(hipStreamWaitEvent(ls, w->lane_p1[w->last_p1_lane], 0));
         const uint8_t *inst_c = inst ? inst + (size_t)lo * d.n_pi * 32 : nullptr, *ci_c = ci ? ci + (size_t)lo * 48 : nullptr;
-        int rc;
         if (rlc) {
             uint32_t sd[8];
             for (int k = 0; k < 8; k++) sd[k] = seed[k];
             sd[7] ^= 0x9e3779b9u * (c + 1);      // (a chunk is its own batch check: its own coefficients)
+            lw->rlc_fail_ptr = w->rlc_fail + slot;
             rc = run_rlc(p, m, proofs, off + lo, inst_c, ci_c, accept + lo, status_out ? status_out + lo : nullptr, lw, ls, sd, true);
         } else {
             rc = run_pipeline(d, m, proofs, off + lo, inst_c, ci_c, accept + lo, status_out ? status_out + lo : nullptr, lw, ls, nullptr, false);
@@ -979,18 +1035,17 @@ static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const
         if (rc) { (void)hipStreamSynchronize(ls); return rc; }
         HIPCHK(hipEventRecord(w->lane_ev[l], ls));
         w->lane_busy[l] = true;
-        w->last_p1_lane = l;
     }
-    for (uint32_t l = 0; l < L; l++) {
-        w->lring_calls[slot][l] = w->lane[l]->calls;
-        w->lring_rlc_calls[slot][l] = rlc_calls_of(w->lane[l]);
+    for (uint32_t l = 0; l < w->n_lanes; l++) {
+        w->lring_calls[slot][l] = w->lane[l] ? w->lane[l]->calls : 0;
+        w->lring_rlc_calls[slot][l] = w->lane[l] ? rlc_calls_of(w->lane[l]) : 0;
     }
     if (!w->defer_joins || force_join) return lanes_join(w, st);
     return H2V_OK;
 }
 // chunk c of the call in ring slot `slot` ran on lane *l as that lane's call number (0-based, absolute) *idx
 static void laned_chunk_pos(const h2v_workspace *w, int slot, uint32_t c, bool rlc, uint32_t *l, uint64_t *idx) {
-    const uint32_t L = w->n_lanes, nch = w->lring_chunks[slot], f = w->lring_first[slot];
+    const uint32_t L = w->lring_mod[slot], nch = w->lring_chunks[slot], f = w->lring_first[slot];
     *l = (f + c) % L;
     uint32_t uses = 0;                       // chunks of this call on that lane
     for (uint32_t q = 0; q < nch; q++) if ((f + q) % L == *l) uses++;
@@ -1100,7 +1155,7 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
 }
 
 static int host_stream(h2v_workspace *ws) {
-    if (!ws->hs) HIPCHK(hipStreamCreateWithFlags(&ws->hs, hipStreamNonBlocking));
+    if (!ws->hs) HIPCHK(make_stream(&ws->hs));
     if (!ws->ev_host) HIPCHK(hipEventCreateWithFlags(&ws->ev_host, hipEventDisableTiming));
     return H2V_OK;
 }
@@ -1184,7 +1239,7 @@ extern "C" int h2v_verify_batch_submit(const h2v_plan *p, const h2v_batch *b, h2
             // reused before they have drained
             const std::string e = g_err;
             (void)hipStreamSynchronize(ws->hs);
-            for (uint32_t l = 0; l < ws->n_lanes; l++) (void)hipStreamSynchronize(ws->lane_st[l]);
+            for (uint32_t l = 0; l < ws->n_lanes; l++) if (ws->lane_st[l]) (void)hipStreamSynchronize(ws->lane_st[l]);
             return fail(rc, e);
         }
     }
@@ -1392,7 +1447,6 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     HIPCHK(hipEventRecord(ev[3], pm));
     if (!one_stream) HIPCHK(hipStreamWaitEvent(pm, w->ev_join[0], 0));
     HIPCHK(hipEventRecord(ev[10], pm));
-    if (w->p1_event) HIPCHK(hipEventRecord(w->p1_event, pm));
     // the batch check
     RlcArgs ra = {n, p->n_var, p->n_fix, slots, d.pi_point, d.n_terms, d.terms, w->scalars, w->status, w->valid, w->valid_sub, {},
                   r->r_scal, r->r_idx, r->l_scal, r->l_idx, r->vk_part, r->good};
@@ -1416,7 +1470,7 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     uint8_t *valid1 = (uint8_t *)(r->misc + 26), *acc1 = (uint8_t *)(r->misc + 27);
     HIPCHK(hipMemsetAsync(r->misc + 24, 0, 8, pm));            // status of the batch check, skip flag
     HIPCHK(hipMemsetAsync(valid1, 1, 1, pm));
-    hipLaunchKernelGGL(k_pairing_rlc, dim3(1), dim3(64), COOP_LDS_BYTES(1), pm, d1, r->misc, valid1, r->sums, r->sums + 36, st1, acc1, n, r->good, accept, skip);
+    hipLaunchKernelGGL(k_pairing_rlc, dim3(1), dim3(64), COOP_LDS_BYTES(1), pm, d1, r->misc, valid1, r->sums, r->sums + 36, st1, acc1, n, r->good, accept, skip, w->rlc_fail_ptr);
     HIPCHK(hipEventRecord(ev[9], pm));
     // fall-back, skipped on the device when the batch check passed: window tables, per-proof MSM, per-proof pairing - small
     // grids that walk their logical blocks, so that finding out that they are not needed costs a few microseconds each
@@ -1487,33 +1541,31 @@ extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, u
         if (w->calls == 0 || calls_back >= h2v_workspace::RING || calls_back >= w->calls) return fail(H2V_E_ARG, "no such call in the event ring");
         const int slot = (int)((w->calls - 1 - calls_back) % h2v_workspace::RING);
         if (!w->lring_rlc[slot]) return fail(H2V_E_ARG, "that call did not run in RLC mode");
-        if (batch_accepted) *batch_accepted = 1;
-        if (tm) memset(tm, 0, sizeof *tm);
+        if (batch_accepted) {
+            uint32_t failed = 0;
+            HIPCHK(hipMemcpy(&failed, w->rlc_fail + slot, 4, hipMemcpyDeviceToHost));
+            *batch_accepted = failed == 0 ? 1u : 0u;
+        }
+        if (!tm) return H2V_OK;
+        memset(tm, 0, sizeof *tm);
         hipEvent_t first = nullptr;
         for (uint32_t c = 0; c < w->lring_chunks[slot]; c++) {
             uint32_t l; uint64_t idx;
             laned_chunk_pos(w, slot, c, true, &l, &idx);
             h2v_workspace *lw = w->lane[l];
             if (!lw->rlc || lw->rlc->calls - 1 - idx >= (uint64_t)h2v_workspace::RING) return fail(H2V_E_ARG, "the lanes' event rings have wrapped since that call");
-            const uint32_t back = (uint32_t)(lw->rlc->calls - 1 - idx);
-            uint32_t ok1 = 1;
             h2v_rlc_timings t1;
-            // (the verdict word of a lane is overwritten by its next chunk: the verdict of a past call is exact only while
-            //  no later chunk has run on that lane - i.e. for calls_back = 0 after a join)
-            int rc = h2v_workspace_rlc_result(lw, back, batch_accepted && back == 0 ? &ok1 : nullptr, tm ? &t1 : nullptr);
+            int rc = h2v_workspace_rlc_result(lw, (uint32_t)(lw->rlc->calls - 1 - idx), nullptr, &t1);
             if (rc) return rc;
-            if (batch_accepted && !ok1) *batch_accepted = 0;
-            if (tm) {
-                tm->transcript_combiner_ms += t1.transcript_combiner_ms; tm->g1_decompress_ms += t1.g1_decompress_ms; tm->prepare_ms += t1.prepare_ms;
-                tm->bucket_sort_ms += t1.bucket_sort_ms; tm->bucket_accumulate_ms += t1.bucket_accumulate_ms; tm->bucket_reduce_ms += t1.bucket_reduce_ms;
-                tm->pairing_ms += t1.pairing_ms;
-                tm->msm_terms = t1.msm_terms; tm->window_bits = t1.window_bits; tm->windows = t1.windows; tm->max_chain = t1.max_chain;
-                hipEvent_t *ev = lw->rlc->ring[idx % h2v_workspace::RING];
-                if (!first) first = ev[0];
-                float span = 0;
-                HIPCHK(hipEventElapsedTime(&span, first, ev[9]));
-                if (span > tm->total_ms) tm->total_ms = span;
-            }
+            tm->transcript_combiner_ms += t1.transcript_combiner_ms; tm->g1_decompress_ms += t1.g1_decompress_ms; tm->prepare_ms += t1.prepare_ms;
+            tm->bucket_sort_ms += t1.bucket_sort_ms; tm->bucket_accumulate_ms += t1.bucket_accumulate_ms; tm->bucket_reduce_ms += t1.bucket_reduce_ms;
+            tm->pairing_ms += t1.pairing_ms;
+            tm->msm_terms = t1.msm_terms; tm->window_bits = t1.window_bits; tm->windows = t1.windows; tm->max_chain = t1.max_chain;
+            hipEvent_t *ev = lw->rlc->ring[idx % h2v_workspace::RING];
+            if (!first) first = ev[0];
+            float span = 0;
+            HIPCHK(hipEventElapsedTime(&span, first, ev[9]));
+            if (span > tm->total_ms) tm->total_ms = span;
         }
         return H2V_OK;
     }

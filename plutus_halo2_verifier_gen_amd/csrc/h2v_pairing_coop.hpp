@@ -669,10 +669,13 @@ k_pairing_coop_narrow(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ 
 extern "C" __global__ void __launch_bounds__(64, 2)
 k_pairing_rlc(H2vDevPlan plan, const uint32_t *__restrict__ pts1, const uint8_t *__restrict__ valid1, const uint32_t *__restrict__ er_jac,
               const uint32_t *__restrict__ el_jac, uint32_t *__restrict__ status1, uint8_t *__restrict__ accept1,
-              uint32_t n_batch, const uint8_t *__restrict__ good, uint8_t *__restrict__ accept, uint32_t *__restrict__ skip) {
+              uint32_t n_batch, const uint8_t *__restrict__ good, uint8_t *__restrict__ accept, uint32_t *__restrict__ skip,
+              uint32_t *__restrict__ fail_ctr) {
     bool ok = false;
     pairing_coop_body<true>(plan, 1u, pts1, valid1, nullptr, er_jac, el_jac, status1, accept1, nullptr, 0u, &ok);
     if (threadIdx.x == 0) skip[0] = ok ? 1u : 0u;
+    // (laned calls: one counter per call, shared by its chunks - how many batch checks of the call failed)
+    if (threadIdx.x == 0 && !ok && fail_ctr) atomicAdd(fail_ctr, 1u);
     if (ok)
         for (uint32_t i = threadIdx.x; i < n_batch; i += 64) accept[i] = good[i];
 }

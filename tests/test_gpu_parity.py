@@ -152,6 +152,63 @@ def test_batch_stream_keeps_batches_in_flight(be, circuits):
         bs.close()
 
 
+@pytest.mark.parametrize("name", ["simple_mul", "trashcan_mix", "ivc"])
+def test_verdicts_do_not_depend_on_the_chunking(be, circuits, name):
+    """Laned workspaces (h2v_workspace_create_lanes): a call is cut into chunks that run through library-owned lanes.  For
+    every (lanes, chunk) - ragged last chunk, more lanes than chunks, more chunks than lanes, chunk of 1 - the accept vector
+    is the unchunked call's and the oracle's, per proof and in RLC mode, through the host-buffer and the device-resident
+    entry points; and with deferred joins three consecutive calls on ONE workspace overlap in the lanes and still give
+    each call its own vector."""
+    import torch
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits[name]
+    n = 203
+    batch = synth.forge_batch(vk, td, n, seed=71, plan=pl, workers=4)
+    batch = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.3, seed=72, kinds=list(synth.CORRUPTIONS))
+    want = list(ov.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, threads=16))
+    assert want == batch.expected and 0 < sum(want) < n
+    plain = be.Workspace(dp, n)
+    assert plain.lanes() == (1, n)
+    assert list(dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=plain)) == want
+    plain.close()
+    dev = torch.device("cuda", 0)
+    up = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) if b else None
+    d_proofs, d_inst, d_ci = up(batch.proofs), up(batch.instances), up(batch.committed)
+    d_off = torch.tensor(batch.proof_off, dtype=torch.int64).to(dev)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    for lanes, chunk in [(3, 64), (2, 100), (16, 7), (5, 203), (4, 1000), (3, 1)]:
+        ws = be.Workspace(dp, n, lanes=lanes, chunk=chunk)
+        assert ws.lanes() == (lanes, min(chunk, n))
+        assert list(dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws)) == want, (lanes, chunk)
+        got, _fb = dp.verify_batch_rlc(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws, seed=bytes(range(32)))
+        assert list(got) == want, (lanes, chunk, "rlc")
+        # device-resident form: accept[] and status[] written in place chunk by chunk
+        acc = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+        st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        dp.verify_batch_device(n, ptr(d_proofs), ptr(d_off), ptr(d_inst), ptr(d_ci), acc.data_ptr(), st.data_ptr(), ws=ws)
+        torch.cuda.synchronize()
+        assert acc.cpu().tolist() == want and [int(x == 0) for x in st.cpu().tolist()] == want
+        if -(-n // min(chunk, n)) <= 32:      # (a lane remembers the events of its last 64 chunks)
+            tm = ws.timings()
+            assert tm.launches == -(-n // min(chunk, n)) and tm.pairing_ms > 0 and tm.total_ms > 0
+        ws.close()
+    # deferred joins: three calls of different sizes back to back on one workspace and one (non-default) stream
+    ws = be.Workspace(dp, n, lanes=3, chunk=40)
+    ws.defer_joins(True)
+    s = torch.cuda.Stream(device=dev)
+    sizes = [n, 150, 77]
+    accs = [torch.full((m,), 9, dtype=torch.uint8, device=dev) for m in sizes]
+    for m, a in zip(sizes, accs):
+        dp.verify_batch_device(m, ptr(d_proofs), ptr(d_off), ptr(d_inst), ptr(d_ci), a.data_ptr(), None, ws=ws, stream=s.cuda_stream)
+    ws.join(s.cuda_stream)
+    s.synchronize()
+    for m, a in zip(sizes, accs):
+        assert a.cpu().tolist() == want[:m]
+    with pytest.raises(be.H2VError):
+        be.Workspace(dp, n).defer_joins(True)      # only laned workspaces
+    ws.close()
+
+
 def test_in_flight_hint_changes_the_shape_not_the_verdicts(be, circuits):
     """h2v_workspace_hint_in_flight(>= 4): the per-proof MSM runs two terms per lane (k_g1_msm_multi2, reported as 18) -
     the accept vector and the statuses stay those of the default shape."""

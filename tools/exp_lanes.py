@@ -27,7 +27,7 @@ def main():
     vk, td = V.BUILDERS[args.workload]()
     pl = PL.compile_plan(vk)
     B = args.batch
-    nmax = max([int(x) for x in args.single.split(",")] + [B])
+    nmax = max([int(x) for x in args.single.split(",") if x] + [B])
     base = synth.forge_batch(vk, td, min(nmax, 4096), seed=1000, workers=16, plan=pl)
     reps = -(-nmax // base.n)
     proofs = base.proofs * reps
@@ -45,7 +45,11 @@ def main():
     seed = bytes(range(32))
     rlc = args.mode == "rlc"
 
+    caller = torch.cuda.Stream(device=dev)     # (not the legacy default stream: it synchronises with every blocking stream)
+    torch.cuda.set_stream(caller)
+
     def call(ws, n, acc, st_, stream=None):
+        stream = stream or caller.cuda_stream
         ptrs = (n, d_proofs.data_ptr(), d_off.data_ptr(), d_inst.data_ptr(), d_ci.data_ptr() if d_ci is not None else None, acc.data_ptr(), st_.data_ptr())
         if rlc:
             dp.verify_batch_rlc_device(*ptrs, ws=ws, stream=stream, seed=seed)
@@ -60,7 +64,7 @@ def main():
             backend.check(backend.lib().h2v_workspace_create_lanes(dp.handle, n, 1, n, C.byref(ws._h)))
         acc = torch.zeros(n, dtype=torch.uint8, device=dev)
         st_ = torch.zeros(n, dtype=torch.int32, device=dev)
-        for _ in range(2):
+        for _ in range(max(2, lanes)):
             call(ws, n, acc, st_)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -91,12 +95,12 @@ def main():
         sts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(lanes)]
         for k in range(lanes):
             call(ws, B, accs[k % lanes], sts[k % lanes])
-        ws.join(None)
+        ws.join(caller.cuda_stream)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(K):
             call(ws, B, accs[k % lanes], sts[k % lanes])
-        ws.join(None)
+        ws.join(caller.cuda_stream)
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / K
         ok = all(int(a.sum().item()) == B for a in accs)
