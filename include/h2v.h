@@ -153,13 +153,15 @@ int h2v_verify_batch_device(const h2v_plan *plan, const h2v_batch *batch, uint8_
  * for the whole batch, so accept[] is always what the per-proof mode returns, except with probability <= 2^-128 over the
  * seed (a rejecting proof hidden by the combination).  Recursive (IVC) plans have no batch form and run per proof.
  * ws must not be NULL for the device form. */
-#define H2V_RLC_SEED_GIVEN 1u
+#define H2V_RLC_SEED_GIVEN 1u /* TEST ONLY: soundness rests on the seed being unpredictable to the provers; without this flag
+                               * the library draws 32 bytes from the OS per call (getrandom) and fails closed.  With it, a
+                               * process-wide call counter is still mixed into the seed, so repeated calls differ. */
 #define H2V_RLC_ONE_STREAM 2u /* everything on the caller's stream (decompression before the combiner instead of beside it):
                                * 0.3 ms more per batch alone, but one stream per batch for callers that keep many batches in
                                * flight - more of them fit the hardware queues (measured: 2.47 M proofs/s with 7 in flight
                                * against 2.24 M with 5 on two streams each) */
 typedef struct h2v_rlc_opts_s {
-    uint8_t seed[32];   /* used when flags & H2V_RLC_SEED_GIVEN (tests, reproducible runs); must be unpredictable to provers */
+    uint8_t seed[32];   /* used when flags & H2V_RLC_SEED_GIVEN (tests, reproducible measurements - never a service) */
     uint32_t flags;
 } h2v_rlc_opts;
 typedef struct {

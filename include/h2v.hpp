@@ -14,9 +14,15 @@
 // `VerifyingKey` wraps a plan blob produced by plutus_halo2_verifier_gen_amd.plan.compile_plan(vk).to_bytes()
 // (the counterpart of extract_circuit, /root/reference/src/plutus_gen/extraction/mod.rs:31).
 #pragma once
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -133,9 +139,15 @@ inline std::vector<uint8_t> verify_batch_rlc(const VerifyingKey &vk, const h2v_b
 // A reusable workspace, and the streaming form: submit() returns once the batch is copied and everything is enqueued,
 // wait() collects the accept vector.  Alternate two Workspaces to overlap the upload of one batch with the kernels of the
 // previous one.
+// (A Workspace, BatchStream or NodeStream keeps a reference to its VerifyingKey: the key must outlive it.)
 class Workspace {
   public:
     Workspace(const VerifyingKey &vk, uint64_t max_batch) : vk_(vk) { check(h2v_workspace_create(vk.handle(), max_batch, &w_)); }
+    /// a LANED workspace (h2v_workspace_create_lanes): calls are cut into chunks that the library pipelines through its own
+    /// lanes and streams; n_lanes / chunk = 0: the library's choice
+    Workspace(const VerifyingKey &vk, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk) : vk_(vk) {
+        check(h2v_workspace_create_lanes(vk.handle(), max_batch, n_lanes, chunk, &w_));
+    }
     Workspace(const Workspace &) = delete;
     Workspace &operator=(const Workspace &) = delete;
     ~Workspace() { h2v_workspace_free(w_); }
@@ -170,11 +182,10 @@ class BatchStream {
     BatchStream(const VerifyingKey &vk, uint64_t max_batch, unsigned depth, bool rlc = false) : rlc_(rlc) {
         if (depth == 0) throw Error(H2V_E_ARG, "BatchStream: depth must be at least 1");
         for (unsigned k = 0; k < depth; k++) {
-            ws_.emplace_back(new Workspace(vk, max_batch));
+            ws_.emplace_back(new Workspace(vk, max_batch));   // (a throwing constructor leaves the earlier ones to the vector)
             ws_.back()->hint_in_flight(depth);
         }
     }
-    ~BatchStream() { for (Workspace *w : ws_) delete w; }
     BatchStream(const BatchStream &) = delete;
     BatchStream &operator=(const BatchStream &) = delete;
     /// returns true and fills `done` when the batch pushed depth calls earlier has been collected
@@ -199,9 +210,163 @@ class BatchStream {
     }
 
   private:
-    std::vector<Workspace *> ws_;
+    std::vector<std::unique_ptr<Workspace>> ws_;
     uint64_t next_ = 0, collected_ = 0;
     bool rlc_;
+};
+
+// Every GPU of one node behind one object, in ONE process (proofs are independent, so a batch is
+// cut into contiguous index ranges [g n / G, (g + 1) n / G), one per device; the plan is replicated; nothing is exchanged
+// but the accept bytes, which come back through each device's own pinned staging buffer).  Per device: its own
+// VerifyingKey (plan upload), a BatchStream of `depth` workspaces and a host thread that stages and submits that device's
+// shard, so the shards of one batch are packed and uploaded side by side.  push() / drain() as BatchStream; verify() is
+// the blocking form.  The same device may be listed more than once (two pipelines on one GPU: how the GPU test runs on a
+// one-GPU box).
+class NodeStream {
+  public:
+    NodeStream(const uint8_t *plan_blob, size_t len, const std::vector<int> &devices, uint64_t max_batch_per_device, unsigned depth,
+               bool rlc = false) {
+        if (devices.empty() || depth == 0) throw Error(H2V_E_ARG, "NodeStream: at least one device and depth >= 1");
+        for (int dev : devices) {
+            std::unique_ptr<Dev> d(new Dev());
+            d->vk.reset(new VerifyingKey(plan_blob, len, dev));
+            d->bs.reset(new BatchStream(*d->vk, max_batch_per_device, depth, rlc));
+            devs_.push_back(std::move(d));
+        }
+        for (auto &d : devs_) d->worker = std::thread([dp = d.get()] { dp->run(); });
+    }
+    ~NodeStream() {
+        for (auto &d : devs_) { { std::lock_guard<std::mutex> l(d->mu); d->stop = true; } d->cv.notify_all(); }
+        for (auto &d : devs_) if (d->worker.joinable()) d->worker.join();
+    }
+    NodeStream(const NodeStream &) = delete;
+    NodeStream &operator=(const NodeStream &) = delete;
+    size_t n_devices() const { return devs_.size(); }
+    /// shard g of n proofs: the contiguous range [lo, hi)  (plutus_halo2_verifier_gen_amd/shard.py: shard_range)
+    static std::pair<uint64_t, uint64_t> shard_range(uint64_t n, size_t g, size_t G) { return {n * g / G, n * (g + 1) / G}; }
+    /// hands a batch over (the caller's buffers may be reused when this returns); true + `done` = the accept vector of the
+    /// batch pushed `depth` calls earlier, reassembled in proof order
+    bool push(const h2v_batch &b, std::vector<uint8_t> *done = nullptr) {
+        const size_t G = devs_.size();
+        const uint32_t n_pi = devs_[0]->vk->n_public_inputs(), n_ci = devs_[0]->vk->n_committed_instances();
+        for (size_t g = 0; g < G; g++) {
+            const auto r = shard_range(b.n, g, G);
+            Dev &d = *devs_[g];
+            Job j;
+            j.n = r.second - r.first;
+            // offsets rebased to the shard's first byte, so that only the shard's bytes travel to its device
+            j.off.resize(j.n + 1);
+            for (uint64_t i = 0; i <= j.n; i++) j.off[i] = b.proof_off[r.first + i] - b.proof_off[r.first];
+            j.proofs = b.proofs + b.proof_off[r.first];
+            j.inst = b.instances ? b.instances + r.first * n_pi * 32 : nullptr;
+            j.ci = (b.committed && n_ci) ? b.committed + r.first * 48 : nullptr;
+            { std::lock_guard<std::mutex> l(d.mu); d.jobs.push_back(std::move(j)); d.staged = false; }
+            d.cv.notify_all();
+        }
+        bool have = true;
+        std::string err;
+        for (auto &d : devs_) {   // until every device has staged its shard (then the caller's buffers are free again)
+            std::unique_lock<std::mutex> l(d->mu);
+            d->cv.wait(l, [&] { return d->staged; });
+            if (!d->error.empty()) err = d->error;
+            have = have && !d->results.empty();
+        }
+        if (!err.empty()) throw Error(H2V_E_DEVICE, err);
+        sizes_.push_back(b.n);
+        if (have && done) *done = collect();
+        else if (have) (void)collect();
+        return have;
+    }
+    std::vector<std::vector<uint8_t>> drain() {
+        for (auto &d : devs_) {
+            { std::lock_guard<std::mutex> l(d->mu); d->drain = true; d->staged = false; }
+            d->cv.notify_all();
+        }
+        for (auto &d : devs_) {
+            std::unique_lock<std::mutex> l(d->mu);
+            d->cv.wait(l, [&] { return d->staged; });
+            if (!d->error.empty()) throw Error(H2V_E_DEVICE, d->error);
+        }
+        std::vector<std::vector<uint8_t>> out;
+        while (!sizes_.empty()) out.push_back(collect());
+        return out;
+    }
+    std::vector<uint8_t> verify(const h2v_batch &b) {
+        if (!sizes_.empty()) throw Error(H2V_E_ARG, "NodeStream::verify with batches in flight: drain() first");
+        push(b);
+        return drain().at(0);
+    }
+
+  private:
+    struct Job { uint64_t n = 0; std::vector<uint64_t> off; const uint8_t *proofs = nullptr, *inst = nullptr, *ci = nullptr; };
+    struct Dev {
+        std::unique_ptr<VerifyingKey> vk;
+        std::unique_ptr<BatchStream> bs;
+        std::thread worker;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<Job> jobs;
+        std::deque<std::vector<uint8_t>> results;
+        bool stop = false, drain = false, staged = true;
+        std::string error;
+        void run() {
+            for (;;) {
+                std::unique_lock<std::mutex> l(mu);
+                cv.wait(l, [&] { return stop || drain || !jobs.empty(); });
+                if (stop) return;
+                try {
+                    if (!jobs.empty()) {
+                        Job j = std::move(jobs.front());
+                        jobs.pop_front();
+                        l.unlock();
+                        std::vector<uint8_t> done;
+                        bool have = false;
+                        if (j.n) {
+                            const h2v_batch sb{j.n, j.proofs, j.off.data(), j.inst, j.ci};
+                            have = bs->push(sb, &done);
+                        } else {
+                            have = pending_empty_push(&done);
+                        }
+                        l.lock();
+                        if (have) results.push_back(std::move(done));
+                    } else {   // drain
+                        l.unlock();
+                        std::vector<std::vector<uint8_t>> rest = bs->drain();
+                        l.lock();
+                        for (auto &v : rest) results.push_back(std::move(v));
+                        drain = false;
+                    }
+                } catch (const std::exception &e) {
+                    if (!l.owns_lock()) l.lock();
+                    error = e.what();
+                    drain = false;
+                }
+                staged = true;
+                l.unlock();
+                cv.notify_all();
+            }
+        }
+        // (a device whose shard is empty - fewer proofs than devices - still takes part in the lockstep of the streams)
+        bool pending_empty_push(std::vector<uint8_t> *done) {
+            static const uint64_t zero_off[1] = {0};
+            const h2v_batch sb{0, nullptr, zero_off, nullptr, nullptr};
+            return bs->push(sb, done);
+        }
+    };
+    std::vector<uint8_t> collect() {   // the oldest batch: one result per device, concatenated in device (= proof) order
+        std::vector<uint8_t> out;
+        out.reserve(sizes_.front());
+        for (auto &d : devs_) {
+            std::lock_guard<std::mutex> l(d->mu);
+            if (d->results.empty()) throw Error(H2V_E_ARG, "NodeStream: a device has no finished batch");
+            out.insert(out.end(), d->results.front().begin(), d->results.front().end());
+            d->results.pop_front();
+        }
+        sizes_.pop_front();
+        return out;
+    }
+    std::vector<std::unique_ptr<Dev>> devs_;
+    std::deque<uint64_t> sizes_;
 };
 
 }  // namespace h2v

@@ -1492,12 +1492,28 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     if (status_out) HIPCHK(hipMemcpyAsync(status_out, w->status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
     return H2V_OK;
 }
+// The batch coefficients must be unpredictable to whoever made the proofs: 32 bytes from the OS per call (getrandom; fails
+// closed).  A caller-given seed (H2V_RLC_SEED_GIVEN) is for TESTS and reproducible measurements only; even then every call
+// gets different coefficients - the process-wide call counter is mixed in - so that a service that copied a fixed seed
+// from a test or from bench.py does not hand provers a combination they can cancel against... if they can predict the
+// counter: a given seed is not a production setting.
+#include <sys/random.h>
+#include <atomic>
 static int rlc_seed(const h2v_rlc_opts *o, uint32_t seed[8]) {
-    if (o && (o->flags & H2V_RLC_SEED_GIVEN)) { memcpy(seed, o->seed, 32); return H2V_OK; }
-    FILE *f = fopen("/dev/urandom", "rb");
-    const bool ok = f && fread(seed, 1, 32, f) == 32;
-    if (f) fclose(f);
-    return ok ? H2V_OK : fail(H2V_E_DEVICE, "no OS randomness for the batch coefficients (/dev/urandom)");
+    if (o && (o->flags & H2V_RLC_SEED_GIVEN)) {
+        static std::atomic<uint64_t> calls{0};
+        const uint64_t k = calls.fetch_add(1);
+        memcpy(seed, o->seed, 32);
+        seed[5] ^= (uint32_t)k; seed[6] ^= (uint32_t)(k >> 32);
+        return H2V_OK;
+    }
+    size_t got = 0;
+    while (got < 32) {
+        const ssize_t r = getrandom((uint8_t *)seed + got, 32 - got, 0);
+        if (r <= 0) return fail(H2V_E_DEVICE, "no OS randomness for the batch coefficients (getrandom)");
+        got += (size_t)r;
+    }
+    return H2V_OK;
 }
 static int rlc_check_batch(const h2v_plan *p, const h2v_batch *b, const uint8_t *accept) {
     if (!p || !b || !accept) return fail(H2V_E_ARG, "null argument");

@@ -128,19 +128,19 @@ k_pip_digits(PipArgs2 a2) {
 }
 
 // One block of 1024 threads: off[] = exclusive prefix sum of cnt[] (nb buckets, + the total at off[nb]); order[] = bucket
-// ids by descending count (counting sort on min(count, 2047)); cls[] = the size classes; cnt[] is cleared (it becomes
+// ids by descending count (counting sort on min(count, 4095)); cls[] = the size classes; cnt[] is cleared (it becomes
 // the scatter cursors).
 extern "C" __global__ void __launch_bounds__(1024)
 k_pip_scan(PipArgs2 a2) {
     const PipArgs &a = a2.p[blockIdx.y];
     __shared__ uint32_t part[1024];
-    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t hist[4096];   // (T 2^7 = 2560 for the default chain T = 20 must be resolved: the class rule below)
     const uint32_t nb = a.W * a.NB, tid = threadIdx.x;
     const uint32_t per = (nb + 1023) / 1024, lo = tid * per, hi = lo + per < nb ? lo + per : nb;
     uint32_t sum = 0;
     for (uint32_t b = lo; b < hi; b++) sum += a.cnt[b];
     part[tid] = sum;
-    hist[tid] = 0; hist[tid + 1024] = 0;
+    hist[tid] = 0; hist[tid + 1024] = 0; hist[tid + 2048] = 0; hist[tid + 3072] = 0;
     __syncthreads();
     // inclusive scan of the 1024 partial sums (Hillis-Steele in place, a barrier on either side of the update)
     for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -154,20 +154,23 @@ k_pip_scan(PipArgs2 a2) {
         const uint32_t cv = a.cnt[b];
         a.off[b] = run;
         run += cv;
-        atomicAdd(&hist[cv < 2047u ? cv : 2047u], 1u);
+        atomicAdd(&hist[cv < 4095u ? cv : 4095u], 1u);
     }
     if (tid == 1023) a.off[nb] = part[1023];
     __syncthreads();
     if (tid == 0) {
         // hist[v] := number of buckets with count > v = the first rank of count v in descending order
         uint32_t acc = 0;
-        for (int v = 2047; v >= 0; v--) { const uint32_t hv = hist[v]; hist[v] = acc; acc += hv; }
+        for (int v = 4095; v >= 0; v--) { const uint32_t hv = hist[v]; hist[v] = acc; acc += hv; }
         // classes, largest buckets first: class k = counts in (T 2^(k-1), T 2^k] (k = 8: everything above T 2^7; k = 0:
         // 1 .. T); ranks [first, end) of the descending order, lanes from a multiple of 256 (a block holds one class)
         uint32_t lane = 0, first = 0;
         for (int k = PIP_N_CLASSES - 1; k >= 0; k--) {
             const uint32_t low = k == 0 ? 0u : (a.chain << (k - 1));       // the class holds counts > low
-            const uint32_t end = hist[low < 2047u ? low : 2046u];            // buckets with count > low
+            // buckets with count > low.  (A forced chain above 31 puts T 2^(k-1) beyond the histogram: those classes then
+            // start at 4095 entries - more entries per lane than T, never a lane short: the kernel below walks every
+            // logical block whatever the grid is.)
+            const uint32_t end = hist[low < 4095u ? low : 4094u];
             a.cls[3 * k] = first; a.cls[3 * k + 1] = end; a.cls[3 * k + 2] = lane;
             lane += (((end - first) << k) + 255u) & ~255u;
             first = end;
@@ -177,7 +180,7 @@ k_pip_scan(PipArgs2 a2) {
     __syncthreads();
     for (uint32_t b = lo; b < hi; b++) {
         const uint32_t cv = a.cnt[b];
-        const uint32_t pos = atomicAdd(&hist[cv < 2047u ? cv : 2047u], 1u);
+        const uint32_t pos = atomicAdd(&hist[cv < 4095u ? cv : 4095u], 1u);
         a.order[pos] = b;
         a.cnt[b] = 0;
     }
@@ -245,14 +248,19 @@ k_pip_accumulate(PipArgs2 a2) {
     const PipArgs &a = a2.p[blockIdx.y];
     __shared__ uint32_t red[43 * 256];   // partial sums of the block's lanes (dword d of thread t at red[d * 256 + t])
     const uint32_t tid = threadIdx.x;
-    const uint32_t g = blockIdx.x * 256 + tid;
-    if (blockIdx.x * 256 >= a.cls[3 * PIP_N_CLASSES]) return;   // (uniform: the grid is an upper bound)
+    // The grid is the host's ESTIMATE of the lanes the class rule hands out; the blocks walk the logical blocks, so an
+    // estimate that is short (round 2: counts between 2047 and T 2^7 were put in the 256-lane class by a clamped histogram,
+    // and batches of 53-62 k simple_mul proofs left their last buckets without a lane) costs time, never a bucket.
+    const uint32_t n_logical = (a.cls[3 * PIP_N_CLASSES] + 255u) >> 8;
+#pragma unroll 1
+    for (uint32_t blk = blockIdx.x; blk < n_logical; blk += gridDim.x) {
+    const uint32_t g = blk * 256 + tid;
     // the block's class k (lane ranges are 256-aligned and laid out from k = 8 down to 0; empty classes have no lanes)
     uint32_t k = 0;
 #pragma unroll 1
     for (int kk = PIP_N_CLASSES - 1; kk >= 0; kk--) {
         const uint32_t base = a.cls[3 * kk + 2], lanes = (a.cls[3 * kk + 1] - a.cls[3 * kk]) << kk;
-        if (blockIdx.x * 256 >= base && blockIdx.x * 256 < base + ((lanes + 255u) & ~255u)) k = (uint32_t)kk;
+        if (blk * 256 >= base && blk * 256 < base + ((lanes + 255u) & ~255u)) k = (uint32_t)kk;
     }
     const uint32_t lpb = 1u << k, rel = g - a.cls[3 * k + 2];
     const uint32_t rank = a.cls[3 * k] + (rel >> k), q = rel & (lpb - 1u);
@@ -308,6 +316,8 @@ k_pip_accumulate(PipArgs2 a2) {
             for (int k = 0; k < 14; k++) { dst[k] = acc.x.l[k]; dst[14 + k] = acc.y.l[k]; dst[28 + k] = acc.z.l[k]; }
         }
         dst[42] = inf ? 1u : 0u;
+    }
+    __syncthreads();   // (red[] is reused by the next logical block)
     }
 }
 

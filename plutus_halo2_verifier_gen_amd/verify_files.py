@@ -56,8 +56,11 @@ def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--vk", required=True, help="VerifyingKey JSON (vk.py) or a built-in circuit name")
     ap.add_argument("--vk-constants", help="generated verifier_key.ak / VKConstants.hs to take the constants from")
-    ap.add_argument("--kzg-params", help="kzg_params/kzg_params_{k} (src/kzg_params.rs): s_g2 is taken from its tail (wire.parse_kzg_params: "
-                                         "self-validating, layout unpinned) and must agree with the VK constants' when both are given")
+    ap.add_argument("--kzg-params", help="EXPERIMENTAL: kzg_params/kzg_params_{k} (src/kzg_params.rs): s_g2 is taken from its tail (wire.parse_kzg_params: "
+                                         "self-validating, layout unpinned - the reference holds no sample) and must agree with the key's s_g2 "
+                                         "(--vk-constants, or the vk.json's own)")
+    ap.add_argument("--trust-kzg-params", action="store_true",
+                    help="let the s_g2 read from --kzg-params REPLACE the key's instead of being checked against it")
     ap.add_argument("--proof", action="append", required=True)
     ap.add_argument("--public-inputs", action="append", required=True)
     ap.add_argument("--committed", action="append", default=[])
@@ -67,11 +70,15 @@ def main(argv=None) -> int:
     if a.vk_constants:
         vk = vk.with_constants(wire.load_vk_constants(a.vk_constants))
     if a.kzg_params:
+        # the file layout is guessed (six candidate encodings, accepted only when the element before last is the G2
+        # generator): by default the value is a CROSS-CHECK of the key's s_g2, never its source
         kp = wire.load_kzg_params(a.kzg_params)
-        if a.vk_constants and kp.s_g2 != vk.s_g2.lower():
-            raise wire.WireError("s_g2 of %s differs from the VK constants'" % a.kzg_params)
-        import dataclasses
-        vk = dataclasses.replace(vk, s_g2=kp.s_g2)
+        if kp.s_g2 != vk.s_g2.lower():
+            if a.vk_constants or not a.trust_kzg_params:
+                raise wire.WireError("s_g2 of %s differs from the key's (%s); --trust-kzg-params takes the file's" % (
+                    a.kzg_params, "VK constants" if a.vk_constants else "vk.json"))
+            import dataclasses
+            vk = dataclasses.replace(vk, s_g2=kp.s_g2)
     proofs = [wire.load_proof(p) for p in a.proof]
     pis = [wire.load_public_inputs(p) for p in a.public_inputs]
     cis = [wire.load_committed_inputs(p) for p in a.committed]

@@ -85,6 +85,24 @@ int main(int argc, char **argv) {
             for (auto &v : got) same = same && v == acc;
             std::printf("batch_stream_%s %d\n", rlc ? "rlc" : "per_proof", same ? 1 : 0);
         }
+        // the node-level host API: one process, a device list (the same GPU twice on a one-GPU box), contiguous shards,
+        // verdicts reassembled in order - blocking, then five batches streamed at depth 2; and a laned workspace
+        {
+            h2v::NodeStream node(blob.data(), blob.size(), {0, 0}, n, 2, false);
+            bool same = node.verify(batch) == acc;
+            std::vector<std::vector<uint8_t>> got;
+            std::vector<uint8_t> done;
+            for (int k = 0; k < 5; k++)
+                if (node.push(batch, &done)) got.push_back(done);
+            for (auto &v : node.drain()) got.push_back(v);
+            same = same && got.size() == 5;
+            for (auto &v : got) same = same && v == acc;
+            h2v::NodeStream node_rlc(blob.data(), blob.size(), {0, 0, 0}, n, 1, true);
+            same = same && node_rlc.verify(batch) == acc;
+            std::printf("node_stream %d\n", same ? 1 : 0);
+            h2v::Workspace laned(vk, n, 3, 2);     // three lanes, chunks of two proofs
+            std::printf("laned %d\n", h2v::verify_batch(vk, batch, laned.handle()) == acc ? 1 : 0);
+        }
         // a consumed guard must refuse a second use; a wrong instance count must be refused by prepare
         bool refused = false;
         try {

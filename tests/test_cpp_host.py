@@ -19,7 +19,7 @@ def driver(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("cpp") / "h2v_cpp_driver")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "h2v_cpp_driver.cpp"), "-o", out,
-                           "-L", PKG, "-lh2v_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+                           "-L", PKG, "-lh2v_hip", "-pthread", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
     return out
 
 
@@ -67,3 +67,5 @@ def test_cpp_prepare_verify_on_gpu(driver, tmp_path):
     assert lines["rlc_fell_back"] == "1"          # the corrupted proofs are caught only by the pairing
     assert lines["misuse_refused"] == "1"
     assert lines["batch_stream_per_proof"] == "1" and lines["batch_stream_rlc"] == "1"   # h2v::BatchStream, depth 3, seven batches
+    assert lines["node_stream"] == "1"     # h2v::NodeStream over the device list [0, 0] (per proof) and [0, 0, 0] (RLC)
+    assert lines["laned"] == "1"           # a laned workspace through the C++ wrapper

@@ -570,7 +570,9 @@ def test_exported_artefact_files_verify_on_gpu(be, circuits, tmp_path, capsys):
     with pytest.raises(wire.WireError, match="differs"):
         verify_files.main(args + ["--kzg-params", other])
     no_constants = [a for i, a in enumerate(args) if i not in (2, 3)]
-    assert verify_files.main(no_constants + ["--kzg-params", other]) == 1      # another trapdoor: nothing verifies
+    with pytest.raises(wire.WireError, match="differs"):                         # a guessed layout never replaces the key's s_g2 by itself
+        verify_files.main(no_constants + ["--kzg-params", other])
+    assert verify_files.main(no_constants + ["--kzg-params", other, "--trust-kzg-params"]) == 1      # another trapdoor: nothing verifies
     assert capsys.readouterr().out.count("reject") == 2
 
 

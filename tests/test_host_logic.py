@@ -612,3 +612,48 @@ def test_bucket_msm_recoding_model():
                 assert carry == 0
                 assert all(-NB <= d <= NB for d in digits)
                 assert sum(d << (w * c) for w, d in enumerate(digits)) == half
+
+
+def test_bucket_msm_lane_estimate_covers_the_size_classes():
+    """Integer model of the bucket MSM's size classes (csrc/h2v_pippenger.hpp: k_pip_scan) against the host's grid estimate
+    (csrc/h2v_capi.hip: pip_launch): a bucket of more than T 2^(k-1) entries gets 2^k lanes (k <= 8), every class is padded
+    to whole 256-lane blocks, and the launch has 2 n halves W / T + nb + 256 x 9 lanes.  Round 2's histogram stopped at
+    2047 entries, so for T = 20 the 256-lane class began at 2047 instead of 2560 and the estimate fell short for
+    530-625 k terms; with the histogram at 4096 it holds up to the API's limit (and the kernel now walks every logical
+    block whatever the grid is)."""
+    import math
+    T, HIST = 20, 4096
+
+    def shape(n, halves):
+        c = 10
+        while c > 4 and n * halves / (1 << (c - 1)) < 24.0:
+            c -= 1
+        return c, 1 << (c - 1), 128 // c + 1
+
+    def lanes_used(counts, hist_cap):
+        used = 0
+        for k in range(8, -1, -1):
+            low = 0 if k == 0 else T << (k - 1)
+            low_eff = min(low, hist_cap - 2) if low >= hist_cap - 1 else low
+            high = None if k == 8 else min(T << k, hist_cap - 2) if (T << k) >= hist_cap - 1 else (T << k)
+            members = sum(1 for cv in counts if cv > low_eff and (high is None or cv <= high))
+            used += ((members << k) + 255) & ~255
+        return used
+
+    rng = random.Random(5)
+    for n in (1000, 40966, 300000, 560000, 600000, 1 << 20, 3_000_000):
+        for halves in (1, 2):
+            c, NB, W = shape(n, halves)
+            entries = n * halves
+            counts = []
+            for w in range(W):
+                bits = min(c, 128 - w * c) if w * c < 128 else 0
+                live = NB if bits >= c else max(1, 1 << max(bits - 1, 0))      # the top window holds 128 mod c bits
+                mean = entries * (1 - 2.0 ** -bits if bits else 0) / live
+                for b in range(NB):
+                    counts.append(max(0, int(rng.gauss(mean, math.sqrt(mean) + 1))) if b < live else 0)
+            estimate = 2 * entries * W // T + W * NB + 256 * 9
+            estimate = (estimate + 255) // 256 * 256
+            assert lanes_used(counts, HIST) <= estimate, (n, halves)
+            if n in (560000, 600000) and halves == 2:
+                assert lanes_used(counts, 2048) > estimate       # the round-2 clamp: short by a few hundred blocks

@@ -45,11 +45,13 @@ def _bases(orc, k, seed):
     return pts, [bls.g1_compress(p) for p in pts]
 
 
-@pytest.mark.parametrize("n", [1, 63, 4096, 65536])
+@pytest.mark.parametrize("n", [1, 63, 4096, 65536, 600000])
 def test_bucket_msm_matches_the_naive_fold(be, orc, n):
     """h2v_probe_g1_msm_pippenger == orc.g1_msm (the reference's fold of scale + add).  The n terms reuse a small set of
     distinct bases (so equal points meet in the buckets: the complete-addition path), and include zero scalars, the
-    point at infinity, the scalars 1 and r - 1, opposite points with equal scalars and GLV edge values."""
+    point at infinity, the scalars 1 and r - 1, opposite points with equal scalars and GLV edge values.
+    600 000 terms: window buckets of 2047 .. 2560 entries, the range in which round 2's size classes handed out more lanes
+    than the launch had (k_pip_scan's histogram stopped at 2047; tests/test_host_logic.py has the integer model)."""
     rng = random.Random(n)
     k = min(n, 200)
     aff, comp = _bases(orc, k, 100 + n)
