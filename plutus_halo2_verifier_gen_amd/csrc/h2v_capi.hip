@@ -1374,14 +1374,27 @@ struct RlcWs {
     uint8_t *good = nullptr;
     PipWs R, L;
     uint32_t *sums = nullptr;   // er (36 dwords) then el (36): the two MSM results
-    uint32_t *misc = nullptr;   // [0..23] a dummy affine point, [24] status of the batch check, [25] skip flag, [26] its valid byte, [27] its accept byte
+    uint32_t *misc = nullptr;   // [0..23] a dummy affine point, [24] status of the batch check, [26] its valid byte, [27] its accept byte
+    uint32_t *flags = nullptr;  // [0] the batch check passed, [1 + g] group g (proofs 64 g ..) is final: cap / 64 + 2 dwords
+    // fall-back stage 1 (group checks, created by the first call with at least GRP_MIN_N proofs): term lists, sums and
+    // verdict buffers of the groups, the argument array of their 2 G bucket MSMs and ONE pool for those MSMs' buffers
+    struct Grp {
+        uint32_t n = 0, G = 0, stride = 0, max_n = 0, acc_blocks = 0;
+        const void *key = nullptr;
+        uint32_t *g_scal = nullptr, *g_idx = nullptr, *er_g = nullptr, *el_g = nullptr, *pts_g = nullptr, *status_g = nullptr;
+        uint8_t *valid_g = nullptr, *accept_g = nullptr, *pool = nullptr;
+        PipArgs *args_d = nullptr;
+        size_t cnt_bytes = 0, pool_bytes = 0;
+        uint32_t cap_G = 0;
+    } grp;
     static constexpr int NEV = 11;
     hipEvent_t ring[h2v_workspace::RING][NEV] = {};
     uint64_t calls = 0;
     uint32_t last_c = 0, last_W = 0, last_chain = 0, last_terms = 0;
 };
 static void rlc_release(RlcWs *r) {
-    void *ptrs[] = {r->r_scal, r->r_idx, r->l_scal, r->l_idx, r->vk_part, r->good, r->sums, r->misc};
+    void *ptrs[] = {r->r_scal, r->r_idx, r->l_scal, r->l_idx, r->vk_part, r->good, r->sums, r->misc, r->flags, r->grp.g_scal, r->grp.g_idx, r->grp.er_g,
+                    r->grp.el_g, r->grp.pts_g, r->grp.status_g, r->grp.valid_g, r->grp.accept_g, r->grp.pool, r->grp.args_d};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     pip_free(r->R); pip_free(r->L);
     for (auto &set : r->ring) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
@@ -1397,7 +1410,8 @@ static int rlc_ensure(h2v_workspace *w, const h2v_plan *p) {
               hipMalloc((void **)&r->l_scal, (size_t)w->cap * 32) == hipSuccess && hipMalloc((void **)&r->l_idx, (size_t)w->cap * 4) == hipSuccess &&
               hipMalloc((void **)&r->vk_part, blocks * (p->n_fix ? p->n_fix : 1) * 32) == hipSuccess && hipMalloc((void **)&r->good, w->cap) == hipSuccess &&
               hipMalloc((void **)&r->sums, 72 * 4) == hipSuccess && hipMalloc((void **)&r->misc, 32 * 4) == hipSuccess &&
-              hipMemset(r->misc, 0, 32 * 4) == hipSuccess;
+              hipMemset(r->misc, 0, 32 * 4) == hipSuccess && hipMalloc((void **)&r->flags, (blocks + 2) * 4) == hipSuccess &&
+              hipMemset(r->flags, 0, (blocks + 2) * 4) == hipSuccess;
     for (auto &set : r->ring) for (hipEvent_t &e : set) if (ok) ok = hipEventCreate(&e) == hipSuccess;
     if (ok) ok = pip_alloc(r->R, (uint32_t)nr, 2) == H2V_OK && pip_alloc(r->L, (uint32_t)w->cap, 1) == H2V_OK;
     if (!ok) { rlc_release(r); return fail(H2V_E_DEVICE, "RLC workspace allocation failed"); }
@@ -1406,6 +1420,104 @@ static int rlc_ensure(h2v_workspace *w, const h2v_plan *p) {
 }
 static uint64_t rlc_calls_of(const h2v_workspace *w) { return w->rlc ? w->rlc->calls : 0; }
 static bool rlc_supported(const h2v_plan *p) { return !p->d.ivc && p->n_var > 0 && p->n_fix > 0 && p->n_var + p->n_fix == p->d.n_terms; }
+
+// Fall-back stage 1: group checks (h2v_rlc.hpp: k_rlc_group_terms, k_pairing_rlc_groups).  Groups of 64 proofs; every group
+// is two small bucket MSMs (right: 64 n_var + n_fix terms, 255-bit scalars; left: 64 terms, 128-bit) with 7-bit windows
+// (64 buckets x 19 windows: ~20 entries per bucket on the right).  Batches below GRP_MIN_N proofs or above GRP_MAX_G groups
+// go straight to the per-proof kernels.  Everything here is enqueued behind the batch check and returns at once when it
+// passed.  H2V_RLC_GROUPS=0 switches the stage off (measurements).
+#define GRP_MIN_N 256u
+#define GRP_MAX_G 512u
+#define GRP_C 7u
+static bool rlc_groups_on(uint32_t n) {
+    static const int env = []() { const char *e = getenv("H2V_RLC_GROUPS"); return e ? atoi(e) : 1; }();
+    return env != 0 && n >= GRP_MIN_N && (n + 63) / 64 <= GRP_MAX_G;
+}
+static int rlc_groups_ensure(RlcWs *r, const h2v_plan *p, h2v_workspace *w, uint32_t n) {
+    RlcWs::Grp &g = r->grp;
+    const uint32_t G = (n + 63) / 64, slots = H2V_SLOTS(p->d);
+    if (g.n == n && g.key == (const void *)p->blob) return H2V_OK;
+    const uint32_t W = 128 / GRP_C + 1, NB = 1u << (GRP_C - 1), nb = W * NB, stride = 64 * p->n_var + p->n_fix;
+    if (G > g.cap_G) {
+        void *old[] = {g.g_scal, g.g_idx, g.er_g, g.el_g, g.pts_g, g.status_g, g.valid_g, g.accept_g, g.pool, g.args_d};
+        for (void *q : old) if (q) (void)hipFree(q);
+        g = RlcWs::Grp();
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t per_r = up((size_t)stride * PIP_PT_DW * 4) + up((size_t)stride * 2 * W * 2) + up((size_t)stride * 2 * W * 4),
+                     per_l = up((size_t)64 * PIP_PT_DW * 4) + up((size_t)64 * W * 2) + up((size_t)64 * W * 4),
+                     per_any = up((size_t)(nb + 1) * 4) + up((size_t)nb * 4) + up(PIP_CLS_DW * 4) + up((size_t)nb * PIP_PART_DW * 4) + up((size_t)W * PIP_PART_DW * 4);
+        g.cnt_bytes = (size_t)2 * G * up((size_t)nb * 4);
+        g.pool_bytes = g.cnt_bytes + (size_t)G * (per_r + per_l + 2 * per_any);
+        bool ok = hipMalloc((void **)&g.g_scal, (size_t)G * stride * 32) == hipSuccess && hipMalloc((void **)&g.g_idx, (size_t)G * stride * 4) == hipSuccess &&
+                  hipMalloc((void **)&g.er_g, (size_t)G * 144) == hipSuccess && hipMalloc((void **)&g.el_g, (size_t)G * 144) == hipSuccess &&
+                  hipMalloc((void **)&g.pts_g, (size_t)G * 96) == hipSuccess && hipMemset(g.pts_g, 0, (size_t)G * 96) == hipSuccess &&
+                  hipMalloc((void **)&g.status_g, (size_t)G * 4) == hipSuccess && hipMalloc((void **)&g.valid_g, G) == hipSuccess &&
+                  hipMemset(g.valid_g, 1, G) == hipSuccess && hipMalloc((void **)&g.accept_g, G) == hipSuccess &&
+                  hipMalloc((void **)&g.pool, g.pool_bytes) == hipSuccess && hipMalloc((void **)&g.args_d, (size_t)2 * G * sizeof(PipArgs)) == hipSuccess;
+        if (!ok) return fail(H2V_E_DEVICE, "hipMalloc(RLC group stage) failed");
+        g.cap_G = G;
+    }
+    // the argument array: problem 2 q = the right-hand sum of group q, 2 q + 1 its left-hand sum
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    std::vector<PipArgs> args(2 * (size_t)G);
+    uint8_t *cur = g.pool + g.cnt_bytes;
+    auto take = [&](size_t bytes) { uint8_t *q = cur; cur += up(bytes); return q; };
+    uint32_t max_n = 0, acc_blocks = 1;
+    for (uint32_t q = 0; q < G; q++) {
+        const uint32_t ng = n - q * 64 < 64 ? n - q * 64 : 64;
+        for (int side = 0; side < 2; side++) {
+            PipArgs a = {};
+            a.c = GRP_C; a.W = W; a.NB = NB; a.chain = 20;
+            a.pool0 = w->pts; a.n_pool0 = n * slots;
+            if (side == 0) {
+                a.n = ng * p->n_var + p->n_fix; a.halves = 2;
+                a.scal = g.g_scal + (size_t)q * stride * 8; a.pidx = g.g_idx + (size_t)q * stride; a.pool1 = p->d.vk_bases; a.out = g.er_g + (size_t)q * 36;
+            } else {
+                a.n = ng; a.halves = 1;
+                a.scal = r->l_scal + (size_t)q * 64 * 8; a.pidx = r->l_idx + (size_t)q * 64; a.pool1 = nullptr; a.out = g.el_g + (size_t)q * 36;
+            }
+            const uint32_t cap_n = side == 0 ? stride : 64;
+            a.cnt = (uint32_t *)(g.pool + (size_t)(2 * q + side) * up((size_t)nb * 4));
+            a.pts28 = (uint32_t *)take((size_t)cap_n * PIP_PT_DW * 4);
+            a.dig = (int16_t *)take((size_t)cap_n * a.halves * W * 2);
+            a.list = (uint32_t *)take((size_t)cap_n * a.halves * W * 4);
+            a.off = (uint32_t *)take((size_t)(nb + 1) * 4);
+            a.order = (uint32_t *)take((size_t)nb * 4);
+            a.cls = (uint32_t *)take(PIP_CLS_DW * 4);
+            a.partial = (uint32_t *)take((size_t)nb * PIP_PART_DW * 4);
+            a.wsum = (uint32_t *)take((size_t)W * PIP_PART_DW * 4);
+            args[2 * q + side] = a;
+            max_n = a.n > max_n ? a.n : max_n;
+            const uint64_t lanes = 2ull * a.n * a.halves * W / a.chain + nb + 256ull * PIP_N_CLASSES;
+            const uint32_t blocks = (uint32_t)((lanes + 255) / 256);
+            acc_blocks = blocks > acc_blocks ? blocks : acc_blocks;
+        }
+    }
+    if ((size_t)(cur - g.pool) > g.pool_bytes) return fail(H2V_E_DEVICE, "RLC group pool overrun");
+    HIPCHK(hipMemcpy(g.args_d, args.data(), args.size() * sizeof(PipArgs), hipMemcpyHostToDevice));   // (once per batch size)
+    g.n = n; g.G = G; g.stride = stride; g.max_n = max_n; g.acc_blocks = acc_blocks; g.key = (const void *)p->blob;
+    return H2V_OK;
+}
+static int rlc_groups_launch(RlcWs *r, const h2v_plan *p, h2v_workspace *w, uint32_t n, uint8_t *accept, const H2vDevPlan &d1, hipStream_t st) {
+    int rc = rlc_groups_ensure(r, p, w, n);
+    if (rc) return rc;
+    RlcWs::Grp &g = r->grp;
+    const uint32_t G = g.G, W = 128 / GRP_C + 1, NB = 1u << (GRP_C - 1);
+    RlcGroupArgs ga = {n, p->n_var, p->n_fix, (uint32_t)H2V_SLOTS(p->d), g.stride, p->d.terms, r->r_scal, r->r_idx, r->vk_part, g.g_scal, g.g_idx};
+    hipLaunchKernelGGL(k_rlc_group_terms, dim3(G), dim3(64), 0, st, ga, r->flags);
+    HIPCHK(hipMemsetAsync(g.pool, 0, g.cnt_bytes, st));
+    HIPCHK(hipMemsetAsync(g.status_g, 0, (size_t)G * 4, st));
+    hipLaunchKernelGGL(k_pip_digits_many, dim3((g.max_n + 255) / 256, 2 * G), dim3(256), 0, st, g.args_d, r->flags);
+    hipLaunchKernelGGL(k_pip_scan_many, dim3(1, 2 * G), dim3(1024), 0, st, g.args_d, r->flags);
+    hipLaunchKernelGGL(k_pip_scatter_many, dim3((g.max_n + 255) / 256, 2 * G), dim3(256), 0, st, g.args_d, r->flags);
+    hipLaunchKernelGGL(k_pip_accumulate_many, dim3(g.acc_blocks, 2 * G), dim3(256), 0, st, g.args_d, r->flags);
+    hipLaunchKernelGGL(k_pip_reduce_many, dim3(W, 2 * G), dim3(NB), (size_t)43 * NB * 4, st, g.args_d, r->flags);
+    hipLaunchKernelGGL(k_pip_combine_many, dim3(1, 2 * G), dim3(64), 0, st, g.args_d, r->flags);
+    hipLaunchKernelGGL(k_pairing_rlc_groups, dim3(G), dim3(64), COOP_LDS_BYTES(1), st, d1, g.pts_g, g.valid_g, g.er_g, g.el_g, g.status_g, g.accept_g, G, n,
+                       r->good, accept, r->flags);
+    HIPCHK(hipGetLastError());
+    return H2V_OK;
+}
 
 // One batch in RLC mode.  Phase 1 as in run_pipeline (the decompression launch builds no window tables), then the batch
 // check; the per-proof MSM + pairing kernels are queued behind it and return at once unless the batch check failed.
@@ -1466,18 +1578,23 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     // one pairing check over a one-proof view of the plan: el = L, er = R (both Jacobian), no per-proof points
     H2vDevPlan d1 = d;
     d1.n_points = 1; d1.n_ci = 0; d1.ivc = 0; d1.pi_point = 0;
-    uint32_t *st1 = r->misc + 24, *skip = r->misc + 25;
+    uint32_t *st1 = r->misc + 24, *skip = r->flags;
     uint8_t *valid1 = (uint8_t *)(r->misc + 26), *acc1 = (uint8_t *)(r->misc + 27);
-    HIPCHK(hipMemsetAsync(r->misc + 24, 0, 8, pm));            // status of the batch check, skip flag
+    HIPCHK(hipMemsetAsync(r->misc + 24, 0, 4, pm));            // status of the batch check
     HIPCHK(hipMemsetAsync(valid1, 1, 1, pm));
-    hipLaunchKernelGGL(k_pairing_rlc, dim3(1), dim3(64), COOP_LDS_BYTES(1), pm, d1, r->misc, valid1, r->sums, r->sums + 36, st1, acc1, n, r->good, accept, skip, w->rlc_fail_ptr);
+    const uint32_t n_groups = (n + 63) / 64;
+    hipLaunchKernelGGL(k_pairing_rlc, dim3(1), dim3(64), COOP_LDS_BYTES(1), pm, d1, r->misc, valid1, r->sums, r->sums + 36, st1, acc1, n, r->good, accept, skip,
+                       n_groups, w->rlc_fail_ptr);
     HIPCHK(hipEventRecord(ev[9], pm));
-    // fall-back, skipped on the device when the batch check passed: window tables, per-proof MSM, per-proof pairing - small
-    // grids that walk their logical blocks, so that finding out that they are not needed costs a few microseconds each
+    // fall-back, skipped on the device when the batch check passed.  Stage 1 finds the groups of 64 proofs that hold a failing
+    // proof (everything else is final); stage 2 - window tables, per-proof MSM, per-proof pairing - decides inside those
+    // groups.  Walking grids of one wave per SIMD: finding out that a launch is not needed costs a few microseconds, and a
+    // launch that IS needed has the whole chip.
+    if (rlc_groups_on(n) && (rc = rlc_groups_launch(r, p, w, n, accept, d1, pm))) return rc;
     const uint32_t cond_grid = (uint32_t)(msm_n_simd() / 4.0);
     {
         const uint32_t nb = (n * slots + 63) / 64;
-        hipLaunchKernelGGL(k_build_tables, dim3(nb < cond_grid ? nb : cond_grid), dim3(64), 0, pm, n * slots, w->pts, w->valid, w->pt_tab, skip);
+        hipLaunchKernelGGL(k_build_tables, dim3(nb < 4 * cond_grid ? nb : 4 * cond_grid), dim3(64), 0, pm, n * slots, w->pts, w->valid, w->pt_tab, skip, slots);
     }
     {
         H2vMsmArgs ma = {d.terms, 0, d.n_main_terms, d.n_terms, 0, slots, {d.n_main_terms, d.n_main_terms, d.n_main_terms}, {w->er, nullptr, nullptr},
@@ -1588,7 +1705,7 @@ extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, u
     if (!w || !w->rlc || w->rlc->calls == 0) return fail(H2V_E_ARG, "no RLC call was made with this workspace");
     RlcWs *r = w->rlc;
     HIPCHK(hipSetDevice(w->device));
-    if (batch_accepted) HIPCHK(hipMemcpy(batch_accepted, r->misc + 25, 4, hipMemcpyDeviceToHost));
+    if (batch_accepted) HIPCHK(hipMemcpy(batch_accepted, r->flags, 4, hipMemcpyDeviceToHost));
     if (tm) {
         if (calls_back >= h2v_workspace::RING || calls_back >= r->calls) return fail(H2V_E_ARG, "no such call in the event ring");
         hipEvent_t *ev = r->ring[(r->calls - 1 - calls_back) % h2v_workspace::RING];

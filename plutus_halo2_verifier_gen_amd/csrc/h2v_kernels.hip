@@ -890,6 +890,14 @@ k_g1_msm_merged(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /
 // entry points: the check costs the parity path's kernels nothing, not even a different register allocation.)  The grid
 // is small and walks the logical blocks in a loop: a launch that only has to find out that it is not needed should not
 // cost a thousand workgroup dispatches (40-50 us per skipped kernel on the RLC mode's critical path before).
+// skip[1 + g] != 0: group g (proofs 64 g .. 64 g + 63) passed its own check after the batch check failed (k_pairing_rlc_groups)
+// and needs no per-proof verdicts; a logical block is skipped when every group it touches passed
+H2V_DI bool msm_groups_passed(const uint32_t *__restrict__ skip, uint32_t bid, uint32_t per_block, uint32_t n) {
+    const uint32_t p0 = bid * per_block, p1 = (p0 + per_block < n ? p0 + per_block : n) - 1;
+    bool all = true;
+    for (uint32_t g = p0 >> 6; g <= (p1 >> 6); g++) all = all && skip[1 + g] != 0;
+    return all;
+}
 extern "C" __global__ void __launch_bounds__(512, 2)
 k_g1_msm_cond(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, const uint32_t *__restrict__ scalars,
               const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
@@ -897,6 +905,7 @@ k_g1_msm_cond(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, co
     if (ma.skip[0]) return;   // (uniform over the launch: before any barrier)
     const uint32_t n_blocks = (n + per_block - 1) / per_block;
     for (uint32_t bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
+        if (msm_groups_passed(ma.skip, bid, per_block, n)) continue;   // (uniform over the block)
         msm_body<2, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red, bid);
         __syncthreads();
     }
@@ -908,6 +917,7 @@ k_g1_msm_merged_cond(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_bl
     if (ma.skip[0]) return;
     const uint32_t n_blocks = (n + per_block - 1) / per_block;
     for (uint32_t bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
+        if (msm_groups_passed(ma.skip, bid, per_block, n)) continue;   // (uniform over the block)
         msm_body<1, false, true>(plan, ma, n, per_block, scalars, pts, tabws, red, bid);
         __syncthreads();
     }

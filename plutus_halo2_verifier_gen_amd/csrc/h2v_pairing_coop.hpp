@@ -644,8 +644,10 @@ k_pairing_coop(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, co
     if (skip && skip[0]) return;
     if (!skip) { pairing_coop_body<false>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg, blockIdx.x); return; }
     // conditional launch (fall-back of the RLC batch mode): a small grid walks the logical blocks
+    // skip[1 + g]: group g (proofs 64 g .. 64 g + 63) passed its own check (k_pairing_rlc_groups): its verdicts are final
     const uint32_t n_blocks = (n + COOP_GROUPS_PER_WAVE - 1) / COOP_GROUPS_PER_WAVE;
     for (uint32_t bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
+        if (skip[1 + ((bid * COOP_GROUPS_PER_WAVE) >> 6)]) continue;     // (COOP_GROUPS_PER_WAVE divides 64: one group per block)
         pairing_coop_body<false>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg, bid);
         __syncthreads();
     }
@@ -664,18 +666,40 @@ k_pairing_coop_narrow(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ 
                       uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
     pairing_coop_body<false, true>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg, blockIdx.x);
 }
-// The single pairing of the RLC batch mode with its epilogue fused in: batch check passed -> accept[i] = good_i for the whole
-// batch and *skip = 1 (the per-proof kernels queued behind return at once); failed -> *skip = 0 and accept[] is left to them.
+// The single pairing of the RLC batch mode with its epilogue fused in.  flags[0]: batch check passed -> accept[i] = good_i for
+// the whole batch, and the kernels queued behind return at once; failed -> accept[] is left to them.  flags[1 + g] for the
+// n_groups groups of 64 proofs start as the batch verdict; after a failed batch check k_pairing_rlc_groups replaces them
+// with the groups' own verdicts (where that stage runs), and the per-proof kernels skip the groups that passed.
 extern "C" __global__ void __launch_bounds__(64, 2)
 k_pairing_rlc(H2vDevPlan plan, const uint32_t *__restrict__ pts1, const uint8_t *__restrict__ valid1, const uint32_t *__restrict__ er_jac,
               const uint32_t *__restrict__ el_jac, uint32_t *__restrict__ status1, uint8_t *__restrict__ accept1,
-              uint32_t n_batch, const uint8_t *__restrict__ good, uint8_t *__restrict__ accept, uint32_t *__restrict__ skip,
-              uint32_t *__restrict__ fail_ctr) {
+              uint32_t n_batch, const uint8_t *__restrict__ good, uint8_t *__restrict__ accept, uint32_t *__restrict__ flags,
+              uint32_t n_groups, uint32_t *__restrict__ fail_ctr) {
     bool ok = false;
     pairing_coop_body<true>(plan, 1u, pts1, valid1, nullptr, er_jac, el_jac, status1, accept1, nullptr, 0u, &ok);
-    if (threadIdx.x == 0) skip[0] = ok ? 1u : 0u;
+    if (threadIdx.x == 0) flags[0] = ok ? 1u : 0u;
+    for (uint32_t g = threadIdx.x; g < n_groups; g += 64) flags[1 + g] = ok ? 1u : 0u;
     // (laned calls: one counter per call, shared by its chunks - how many batch checks of the call failed)
     if (threadIdx.x == 0 && !ok && fail_ctr) atomicAdd(fail_ctr, 1u);
     if (ok)
         for (uint32_t i = threadIdx.x; i < n_batch; i += 64) accept[i] = good[i];
+}
+// Fall-back, stage 1 (only after a failed batch check): one wave per GROUP of 64 proofs checks e(L_g, s_g2) == e(R_g, G2)
+// for the group's own sums (the bucket MSMs of h2v_pippenger.hpp, one small problem per group and side).  A group that
+// passes is final - accept[i] = good_i, flags[1 + g] = 1 - and only the groups that fail go on to the per-proof kernels:
+// one rejecting proof in 4096 costs 64 per-proof MSMs and pairings, not 4096.  Soundness per group as for the batch (the
+// same coefficients r_i: a failing proof survives its group's check with probability <= 2^-128).
+extern "C" __global__ void __launch_bounds__(64, 2)
+k_pairing_rlc_groups(H2vDevPlan plan, const uint32_t *__restrict__ pts_g, const uint8_t *__restrict__ valid_g, const uint32_t *__restrict__ er_g,
+                     const uint32_t *__restrict__ el_g, uint32_t *__restrict__ status_g, uint8_t *__restrict__ accept_g, uint32_t n_groups,
+                     uint32_t n_batch, const uint8_t *__restrict__ good, uint8_t *__restrict__ accept, uint32_t *__restrict__ flags) {
+    if (flags[0]) return;
+    const uint32_t g = blockIdx.x;
+    bool ok = false;
+    pairing_coop_body<true>(plan, n_groups, pts_g, valid_g, nullptr, er_g, el_g, status_g, accept_g, nullptr, g, &ok);
+    if (threadIdx.x == 0) flags[1 + g] = ok ? 1u : 0u;
+    if (ok) {
+        const uint32_t i = g * 64 + threadIdx.x;
+        if (i < n_batch) accept[i] = good[i];
+    }
 }

@@ -69,9 +69,7 @@ H2V_DI const uint32_t *pip_point_ptr(const PipArgs &a, uint32_t n) {
     return idx < a.n_pool0 ? a.pool0 + (size_t)idx * 24 : a.pool1 + (size_t)(idx - a.n_pool0) * 24;
 }
 
-extern "C" __global__ void __launch_bounds__(256)
-k_pip_digits(PipArgs2 a2) {
-    const PipArgs &a = a2.p[blockIdx.y];
+static __device__ __forceinline__ void pip_digits_impl(const PipArgs &a) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= a.n) return;
     const uint32_t *pp = pip_point_ptr(a, n);
@@ -130,9 +128,7 @@ k_pip_digits(PipArgs2 a2) {
 // One block of 1024 threads: off[] = exclusive prefix sum of cnt[] (nb buckets, + the total at off[nb]); order[] = bucket
 // ids by descending count (counting sort on min(count, 4095)); cls[] = the size classes; cnt[] is cleared (it becomes
 // the scatter cursors).
-extern "C" __global__ void __launch_bounds__(1024)
-k_pip_scan(PipArgs2 a2) {
-    const PipArgs &a = a2.p[blockIdx.y];
+static __device__ __forceinline__ void pip_scan_impl(const PipArgs &a) {
     __shared__ uint32_t part[1024];
     __shared__ uint32_t hist[4096];   // (T 2^7 = 2560 for the default chain T = 20 must be resolved: the class rule below)
     const uint32_t nb = a.W * a.NB, tid = threadIdx.x;
@@ -186,9 +182,7 @@ k_pip_scan(PipArgs2 a2) {
     }
 }
 
-extern "C" __global__ void __launch_bounds__(256)
-k_pip_scatter(PipArgs2 a2) {
-    const PipArgs &a = a2.p[blockIdx.y];
+static __device__ __forceinline__ void pip_scatter_impl(const PipArgs &a) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= a.n) return;
 #pragma unroll 1
@@ -243,9 +237,7 @@ H2V_DN void pip_sum_slice(G1J28 &acc_out, bool &inf_out, const uint32_t *__restr
     inf_out = inf;
 }
 
-extern "C" __global__ void __launch_bounds__(256, 2)
-k_pip_accumulate(PipArgs2 a2) {
-    const PipArgs &a = a2.p[blockIdx.y];
+static __device__ __forceinline__ void pip_accumulate_impl(const PipArgs &a) {
     __shared__ uint32_t red[43 * 256];   // partial sums of the block's lanes (dword d of thread t at red[d * 256 + t])
     const uint32_t tid = threadIdx.x;
     // The grid is the host's ESTIMATE of the lanes the class rule hands out; the blocks walk the logical blocks, so an
@@ -327,9 +319,7 @@ k_pip_accumulate(PipArgs2 a2) {
 //   suffix scan  S_t = sum_{u >= t} B_u   (Hillis-Steele, log2 NB rounds)      and      T = sum_t S_t = sum_j j B_j
 // with the values of the other threads read from LDS (dword d of thread t at red[d * NB + t]: conflict-free) and the
 // thread's own value in registers.  All additions are complete.  Thread 0 then applies the window's weight 2^(c w).
-extern "C" __global__ void __launch_bounds__(512)
-k_pip_reduce(PipArgs2 a2) {
-    const PipArgs &a = a2.p[blockIdx.y];
+static __device__ __forceinline__ void pip_reduce_impl(const PipArgs &a) {
     extern __shared__ uint32_t red[];
     const uint32_t w = blockIdx.x, t = threadIdx.x, NB = a.NB;
     if (w >= a.W) return;                       // (uniform per block: the grid covers the wider of the two MSMs)
@@ -394,9 +384,7 @@ k_pip_reduce(PipArgs2 a2) {
 }
 
 // sum of the W weighted window values (one wave, tree through LDS) -> canonical Jacobian coordinates
-extern "C" __global__ void __launch_bounds__(64)
-k_pip_combine(PipArgs2 a2) {
-    const PipArgs &a = a2.p[blockIdx.y];
+static __device__ __forceinline__ void pip_combine_impl(const PipArgs &a) {
     __shared__ uint32_t red[43 * 64];
     const uint32_t t = threadIdx.x;
     G1J28 val;
@@ -436,3 +424,22 @@ k_pip_combine(PipArgs2 a2) {
         for (int k = 0; k < 12; k++) { a.out[k] = r.x.v[k]; a.out[12 + k] = r.y.v[k]; a.out[24 + k] = r.z.v[k]; }
     }
 }
+
+// ---- kernel entry points.  Two forms of every phase: the arguments of up to two MSMs by value (the batch check of the RLC
+// mode: right- and left-hand sum side by side), or any number of MSMs from an argument array in device memory (blockIdx.y
+// picks one; the group checks of the RLC fall-back: 2 x ceil(n / 64) small MSMs in one launch per phase), which return at
+// once when *skip != 0 (the batch check passed: there is nothing to localise).
+#define PIP_ENTRY(kname, impl, ...)                                                                  \
+    extern "C" __global__ void __launch_bounds__(__VA_ARGS__) kname(PipArgs2 a2) { impl(a2.p[blockIdx.y]); }       \
+    extern "C" __global__ void __launch_bounds__(__VA_ARGS__) kname##_many(const PipArgs *__restrict__ args, const uint32_t *__restrict__ skip) { \
+        if (skip && skip[0]) return;                                                                 \
+        const PipArgs a = args[blockIdx.y];                                                          \
+        impl(a);                                                                                     \
+    }
+PIP_ENTRY(k_pip_digits, pip_digits_impl, 256)
+PIP_ENTRY(k_pip_scan, pip_scan_impl, 1024)
+PIP_ENTRY(k_pip_scatter, pip_scatter_impl, 256)
+PIP_ENTRY(k_pip_accumulate, pip_accumulate_impl, 256, 2)
+PIP_ENTRY(k_pip_reduce, pip_reduce_impl, 512)
+PIP_ENTRY(k_pip_combine, pip_combine_impl, 64)
+#undef PIP_ENTRY

@@ -122,14 +122,44 @@ k_rlc_vk_sum(RlcArgs a, uint32_t n_blocks) {
 // fall-back path only: the MSM window tables of every per-proof point, which the RLC mode's decompression launch skips
 extern "C" __global__ void __launch_bounds__(64)
 k_build_tables(uint32_t n_points, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, uint32_t *__restrict__ pt_tab,
-               const uint32_t *__restrict__ skip) {
+               const uint32_t *__restrict__ skip, uint32_t slots) {
     if (skip && skip[0]) return;
     for (uint32_t g = blockIdx.x * 64 + threadIdx.x; g < n_points; g += gridDim.x * 64) {   // (small grid: see k_g1_msm_cond)
+        if (skip && skip[1 + ((g / slots) >> 6)]) continue;   // the point's group of 64 proofs passed its own check
         if (!valid[g]) continue;
         G1A p;
 #pragma unroll
         for (int k = 0; k < 12; k++) { p.x.v[k] = pts[(size_t)g * 24 + k]; p.y.v[k] = pts[(size_t)g * 24 + 12 + k]; }
         if (g1a_is_inf(p)) continue;
         g1_build_window_tables_glv(pt_tab + (size_t)g * 448, p);
+    }
+}
+
+// Fall-back, stage 1 (after a failed batch check): the term list of every GROUP of 64 proofs - group g is block g of
+// k_rlc_prepare - for its own right-hand bucket MSM: the group's slice of the batch's per-proof terms, then the VK bases
+// with the group's own scalar sums (vk_part[g], still in Montgomery form).  stride = 64 n_var + n_fix terms per group.
+struct RlcGroupArgs {
+    uint32_t n, n_var, n_fix, slots, stride;
+    const uint32_t *terms, *r_scal, *r_idx, *vk_part;
+    uint32_t *g_scal, *g_idx;
+};
+extern "C" __global__ void __launch_bounds__(64)
+k_rlc_group_terms(RlcGroupArgs a, const uint32_t *__restrict__ skip) {
+    if (skip[0]) return;
+    const uint32_t g = blockIdx.x, lo = g * 64, ng = a.n - lo < 64 ? a.n - lo : 64, nt = ng * a.n_var;
+    const size_t src = (size_t)lo * a.n_var, dst = (size_t)g * a.stride;
+    for (uint32_t j = threadIdx.x; j < nt; j += 64) {
+#pragma unroll
+        for (int l = 0; l < 8; l++) a.g_scal[(dst + j) * 8 + l] = a.r_scal[(src + j) * 8 + l];
+        a.g_idx[dst + j] = a.r_idx[src + j];
+    }
+    for (uint32_t f = threadIdx.x; f < a.n_fix; f += 64) {
+        Fr p, c;
+#pragma unroll
+        for (int l = 0; l < 8; l++) p.v[l] = a.vk_part[((size_t)g * a.n_fix + f) * 8 + l];
+        fr_from_mont(c, p);
+#pragma unroll
+        for (int l = 0; l < 8; l++) a.g_scal[(dst + nt + f) * 8 + l] = c.v[l];
+        a.g_idx[dst + nt + f] = a.n * a.slots + a.terms[2 * (a.n_var + f) + 1];
     }
 }

@@ -177,6 +177,61 @@ def test_rlc_mixed_batch_and_status(be, circuits):
     assert list(got2) == batch2.expected and not fb2 and 0 < sum(got2) < n
 
 
+@pytest.mark.parametrize("name,n", [("simple_mul", 4096), ("lookup_table", 1000), ("sha256", 300)])
+@pytest.mark.parametrize("n_rej", [1, 2, 41])
+def test_rlc_fallback_localises_rejects(be, circuits, name, n, n_rej):
+    """A failed batch check is followed by GROUP checks (64 proofs per group: one small bucket MSM per side and one pairing
+    per group) and the per-proof kernels only run inside the groups that fail.  1, 2 and 41 rejecting proofs at random
+    positions - corruptions only the pairing catches, mixed with some that are caught before it -, full groups and a ragged
+    last one (1000, 300 proofs), MSM block sizes that do and do not divide a group (16 / 34 / 60 terms): the vector is
+    the construction's and the oracle's, whatever the seed; status words are zero exactly for the accepted proofs."""
+    import torch
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits[name]
+    n_pi = vk.n_public_inputs
+    good = synth.forge_batch(vk, td, n, seed=51, plan=pl, workers=8, ci_identity=(name == "sha256"))
+    rng = random.Random(1000 * n_rej + n)
+    victims = rng.sample(range(n), n_rej)
+    pre = set(rng.sample(range(n), 3)) - set(victims)        # rejected before the pairing: take no part in any combination
+    proofs = [good.proof(i) for i in range(n)]
+    insts = [good.instances[32 * n_pi * i:32 * n_pi * (i + 1)] for i in range(n)]
+    expected = [1] * n
+    for i in victims:
+        proofs[i], insts[i] = synth.corrupt(pl, proofs[i], insts[i], AT_PAIRING[rng.randrange(3)], rng)
+        expected[i] = 0
+    for i in pre:
+        proofs[i], insts[i] = synth.corrupt(pl, proofs[i], insts[i], "noncanonical_scalar", rng)
+        expected[i] = 0
+    off = [0]
+    for p_ in proofs:
+        off.append(off[-1] + len(p_))
+    pb, ib = b"".join(proofs), b"".join(insts)
+    ws = be.Workspace(dp, n)
+    for seed in (b"\x21" * 32, None):
+        got, fell_back = dp.verify_batch_rlc(pb, off, ib, good.committed, ws=ws, seed=seed)
+        assert list(got) == expected and fell_back
+    # the oracle on the groups that hold a reject (and one clean group)
+    groups = sorted({i // 64 for i in victims} | {i // 64 for i in pre} | {0})[:6]
+    for g in groups:
+        lo, hi = 64 * g, min(n, 64 * g + 64)
+        sub_off = [o - off[lo] for o in off[lo:hi + 1]]
+        want = ov.verify_batch(pb[off[lo]:off[hi]], sub_off, ib[32 * n_pi * lo:32 * n_pi * hi],
+                               good.committed[48 * lo:48 * hi] if good.committed else None, threads=16)
+        assert list(want) == expected[lo:hi]
+    # device-resident form: status words
+    dev = torch.device("cuda", 0)
+    up = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) if b else None
+    d_p, d_i, d_c = up(pb), up(ib), up(good.committed)
+    d_off = torch.tensor(off, dtype=torch.int64).to(dev)
+    acc = torch.zeros(n, dtype=torch.uint8, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    dp.verify_batch_rlc_device(n, d_p.data_ptr(), d_off.data_ptr(), d_i.data_ptr(), d_c.data_ptr() if d_c is not None else None,
+                               acc.data_ptr(), st.data_ptr(), ws=ws, seed=b"\x22" * 32)
+    torch.cuda.synchronize()
+    assert acc.cpu().tolist() == expected and [int(x == 0) for x in st.cpu().tolist()] == expected
+    ws.close()
+
+
 def test_rlc_duplicate_proofs_and_small_batches(be, circuits):
     """The same proof many times in one batch (equal points with different coefficients meet in the buckets), batches of
     1 and 2 proofs, and a recursive plan (no batch form: runs per proof behind the same entry point)."""
