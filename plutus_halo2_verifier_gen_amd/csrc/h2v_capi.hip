@@ -1502,7 +1502,7 @@ static int rlc_groups_launch(RlcWs *r, const h2v_plan *p, h2v_workspace *w, uint
     int rc = rlc_groups_ensure(r, p, w, n);
     if (rc) return rc;
     RlcWs::Grp &g = r->grp;
-    const uint32_t G = g.G, W = 128 / GRP_C + 1, NB = 1u << (GRP_C - 1);
+    const uint32_t G = g.G;
     RlcGroupArgs ga = {n, p->n_var, p->n_fix, (uint32_t)H2V_SLOTS(p->d), g.stride, p->d.terms, r->r_scal, r->r_idx, r->vk_part, g.g_scal, g.g_idx};
     hipLaunchKernelGGL(k_rlc_group_terms, dim3(G), dim3(64), 0, st, ga, r->flags);
     HIPCHK(hipMemsetAsync(g.pool, 0, g.cnt_bytes, st));
@@ -1511,8 +1511,9 @@ static int rlc_groups_launch(RlcWs *r, const h2v_plan *p, h2v_workspace *w, uint
     hipLaunchKernelGGL(k_pip_scan_many, dim3(1, 2 * G), dim3(1024), 0, st, g.args_d, r->flags);
     hipLaunchKernelGGL(k_pip_scatter_many, dim3((g.max_n + 255) / 256, 2 * G), dim3(256), 0, st, g.args_d, r->flags);
     hipLaunchKernelGGL(k_pip_accumulate_many, dim3(g.acc_blocks, 2 * G), dim3(256), 0, st, g.args_d, r->flags);
-    hipLaunchKernelGGL(k_pip_reduce_many, dim3(W, 2 * G), dim3(NB), (size_t)43 * NB * 4, st, g.args_d, r->flags);
-    hipLaunchKernelGGL(k_pip_combine_many, dim3(1, 2 * G), dim3(64), 0, st, g.args_d, r->flags);
+    const uint32_t Wg = 128 / GRP_C + 1;
+    hipLaunchKernelGGL(k_pip_wsum_many, dim3((2 * G * Wg * 4 + 63) / 64), dim3(64), 0, st, g.args_d, 2 * G, Wg, r->flags);
+    hipLaunchKernelGGL(k_pip_horner_many, dim3(2 * G), dim3(64), 0, st, g.args_d, r->flags);
     hipLaunchKernelGGL(k_pairing_rlc_groups, dim3(G), dim3(64), COOP_LDS_BYTES(1), st, d1, g.pts_g, g.valid_g, g.er_g, g.el_g, g.status_g, g.accept_g, G, n,
                        r->good, accept, r->flags);
     HIPCHK(hipGetLastError());

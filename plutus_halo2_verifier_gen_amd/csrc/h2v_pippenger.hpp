@@ -443,3 +443,113 @@ PIP_ENTRY(k_pip_accumulate, pip_accumulate_impl, 256, 2)
 PIP_ENTRY(k_pip_reduce, pip_reduce_impl, 512)
 PIP_ENTRY(k_pip_combine, pip_combine_impl, 64)
 #undef PIP_ENTRY
+
+// Bucket sums -> result for MANY SMALL MSMs (the group checks of the RLC fall-back), two launches.
+//   k_pip_wsum_many    a QUAD of lanes per (MSM, window), densely packed (16 windows per wave).  Lane s of the quad takes
+//                      the buckets t in [s NB/4, (s+1) NB/4) and the running-sum rule - running += B_t, total += running,
+//                      from the top down - gives  T_s = sum (t - lo_s + 1) B_t  and  U_s = sum B_t;  lane 0 of the quad
+//                      puts the window together:  S = sum_j j B_j = sum_s T_s + (NB/4) (U_1 + 2 U_2 + 3 U_3).
+//                      2 NB/4 + 9 complete additions and log2(NB/4) doublings deep, no tree.
+//   k_pip_horner_many  one wave per MSM folds the W window sums from the top window down, acc = 2^c acc + S_w: c (W - 1)
+//                      doublings in all (each spread over three lanes of a quad), where weighting every window by itself
+//                      (k_pip_reduce) costs c W^2 / 2.
+// Few lanes and long chains - wrong for one big MSM, right for hundreds side by side: for 128 MSMs of 19 windows x 64
+// buckets the tree kernels issued more field multiplications than the bucket accumulation itself.
+H2V_DN void pip_acc_add_ool(G1J28 &acc, bool &inf, const G1J28 &q) { g1j28_acc_add(acc, inf, q, false); }
+#define PIP_LDS_PUT(buf, stride, idx, val, flag)                                                  \
+    do {                                                                                          \
+        if (!(flag)) {                                                                            \
+            _Pragma("unroll") for (int k = 0; k < 14; k++) {                                      \
+                (buf)[k * (stride) + (idx)] = (val).x.l[k]; (buf)[(14 + k) * (stride) + (idx)] = (val).y.l[k]; (buf)[(28 + k) * (stride) + (idx)] = (val).z.l[k]; \
+            }                                                                                     \
+        }                                                                                         \
+        (buf)[42 * (stride) + (idx)] = (flag) ? 1u : 0u;                                          \
+    } while (0)
+#define PIP_LDS_ADD(buf, stride, idx, acc, acc_inf)                                               \
+    do {                                                                                          \
+        if ((buf)[42 * (stride) + (idx)] == 0) {                                                  \
+            G1J28 v_;                                                                             \
+            _Pragma("unroll") for (int k = 0; k < 14; k++) {                                      \
+                v_.x.l[k] = (buf)[k * (stride) + (idx)]; v_.y.l[k] = (buf)[(14 + k) * (stride) + (idx)]; v_.z.l[k] = (buf)[(28 + k) * (stride) + (idx)]; \
+            }                                                                                     \
+            pip_acc_add_ool(acc, acc_inf, v_);                                                    \
+        }                                                                                         \
+    } while (0)
+extern "C" __global__ void __launch_bounds__(64)
+k_pip_wsum_many(const PipArgs *__restrict__ args, uint32_t n_problems, uint32_t w_max, const uint32_t *__restrict__ skip) {
+    if (skip && skip[0]) return;
+    __shared__ uint32_t tot_s[43 * 64], run_s[43 * 64];
+    const uint32_t tid = threadIdx.x, seg = tid & 3u, pw = (blockIdx.x * 64 + tid) >> 2;
+    const uint32_t prob = pw / w_max, w = pw % w_max;
+    const bool live = prob < n_problems && w < args[prob < n_problems ? prob : 0].W;
+    const PipArgs a = args[live ? prob : 0];
+    const uint32_t nbs = a.NB >> 2;                          // buckets per segment (NB >= 4: c >= 3)
+    G1J28 run, tot;
+    bool run_inf = true, tot_inf = true;
+    if (live) {
+#pragma unroll 1
+        for (int t = (int)((seg + 1) * nbs) - 1; t >= (int)(seg * nbs); t--) {
+            const uint32_t b = w * a.NB + (uint32_t)t;
+            if (a.off[b + 1] != a.off[b]) {                  // (an empty bucket had no lane: nothing was written for it)
+                const uint32_t *src = a.partial + (size_t)b * PIP_PART_DW;
+                if (!src[42]) {
+                    G1J28 v;
+#pragma unroll
+                    for (int k = 0; k < 14; k++) { v.x.l[k] = src[k]; v.y.l[k] = src[14 + k]; v.z.l[k] = src[28 + k]; }
+                    pip_acc_add_ool(run, run_inf, v);
+                }
+            }
+            if (!run_inf) pip_acc_add_ool(tot, tot_inf, run);
+        }
+    }
+    PIP_LDS_PUT(tot_s, 64, tid, tot, tot_inf);
+    PIP_LDS_PUT(run_s, 64, tid, run, run_inf);
+    __syncthreads();
+    if (live && seg == 0) {
+        // U_1 + 2 U_2 + 3 U_3 = U_3 + (U_3 + U_2) + (U_3 + U_2 + U_1)
+        G1J28 v, acc;
+        bool v_inf = true, acc_inf = true;
+#pragma unroll 1
+        for (int q = 3; q >= 1; q--) {
+            PIP_LDS_ADD(run_s, 64, tid + q, v, v_inf);
+            if (!v_inf) pip_acc_add_ool(acc, acc_inf, v);
+        }
+        if (!acc_inf)
+            for (uint32_t m = nbs; m > 1; m >>= 1) g1j28_dbl_ool(acc, acc);    // x NB/4 (odd group order: never infinity)
+#pragma unroll 1
+        for (int q = 0; q < 4; q++) PIP_LDS_ADD(tot_s, 64, tid + q, acc, acc_inf);
+        uint32_t *dst = a.wsum + (size_t)w * PIP_PART_DW;
+        if (!acc_inf) {
+#pragma unroll
+            for (int k = 0; k < 14; k++) { dst[k] = acc.x.l[k]; dst[14 + k] = acc.y.l[k]; dst[28 + k] = acc.z.l[k]; }
+        }
+        dst[42] = acc_inf ? 1u : 0u;
+    }
+}
+#undef PIP_LDS_PUT
+#undef PIP_LDS_ADD
+extern "C" __global__ void __launch_bounds__(64)
+k_pip_horner_many(const PipArgs *__restrict__ args, const uint32_t *__restrict__ skip) {
+    if (skip && skip[0]) return;
+    const PipArgs a = args[blockIdx.x];
+    // every lane of the wave runs the same fold on the same values (the doublings need whole quads in step)
+    G1J28 acc;
+    bool inf = true;
+#pragma unroll 1
+    for (int t = (int)a.W - 1; t >= 0; t--) {
+        if (!inf) g1j28_dbl_n_coop3(acc, a.c);                // odd group order: never infinity
+        const uint32_t *src = a.wsum + (size_t)t * PIP_PART_DW;
+        if (!src[42]) {
+            G1J28 v;
+#pragma unroll
+            for (int k = 0; k < 14; k++) { v.x.l[k] = src[k]; v.y.l[k] = src[14 + k]; v.z.l[k] = src[28 + k]; }
+            pip_acc_add_ool(acc, inf, v);
+        }
+    }
+    if (threadIdx.x == 0) {
+        G1J r;
+        g1j28_to_g1j(r, acc, inf);
+#pragma unroll
+        for (int k = 0; k < 12; k++) { a.out[k] = r.x.v[k]; a.out[12 + k] = r.y.v[k]; a.out[24 + k] = r.z.v[k]; }
+    }
+}
