@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--hint", type=int, default=0, help="h2v_workspace_hint_in_flight value (default: the steps in flight); the counter passes of "
                                                      "tools/scripts/profile_round.sh run one step at a time with the shapes of the timed run")
+    ap.add_argument("--no-alone", action="store_true", help="skip the one-step-at-a-time pass (with --timed-only: the profiled command launches the timed steps only)")
     ap.add_argument("--timed-only", action="store_true",
                     help="launch nothing but warm-up + the timed steps (no in-flight probe, no one-step pass, no RLC secondary, no reject "
                          "dataset, no CPU baseline): the form profiled under rocprofv3, whose per-kernel averages then cover the same "
@@ -429,7 +430,7 @@ def main():
     # shapes (the in-flight hint of the timed run), the host synchronises after every step - and `roofline` / `int_roofline`
     # are computed from ITS durations; the overlapped ones are reported beside them.
     alone = None
-    if inflight > 1 or args.timed_only:
+    if (inflight > 1 or args.timed_only) and not args.no_alone:
         saved_hint = args.hint
         args.hint = args.hint or inflight
         r1 = streams_run(args.mode, 1, 6, 2, False, sync_every_step=True)
@@ -562,6 +563,7 @@ def main():
                     "avg_launch_ms": round(kernel_ms[k] / launches, 4),
                     "duration_is": "the kernel's own (one step at a time, same launch shape)" if alone else "from the timed steps (one step in flight)",
                     "avg_launch_ms_in_the_timed_steps": round(kernel_ms_overlapped[k] / launches, 4), "launches_per_step": launches,
+                    "duration_fits_in_step": bool(kernel_ms[k] / launches <= elapsed / args.steps * 1e3 * 1.05),
                     "algorithmic_bytes_per_launch": bytes_per_launch[k] // launches,
                     "note": "integer-issue bound (see int_roofline): ~10^5 multiply-adds per 128-byte MSM term"}
 
@@ -578,8 +580,11 @@ def main():
             dominant = max(("g1_decompress", "transcript_combiner", "bucket_accumulate", "rlc_prepare", "bucket_sort"), key=kernel_ms.get)
         else:
             dominant = max(kernel_ms, key=kernel_ms.get)
-            # what feeds `roofline` must be a duration the step can contain
-            assert kernel_ms[dominant] / launches <= elapsed / args.steps * 1e3 * 1.05 or not alone, (kernel_ms, elapsed / args.steps * 1e3)
+            # what feeds `roofline` must be a duration the step can contain - for batches that fill the chip (the BASELINE
+            # headline).  The small shares (64-128 proofs) are chains of lone waves: six of them in flight finish a step in
+            # less time than one kernel's own chain takes, and the line says so instead (roofline.duration_fits_in_step)
+            fits = kernel_ms[dominant] / launches <= elapsed / args.steps * 1e3 * 1.05
+            assert fits or not alone or B < 2048, (kernel_ms, elapsed / args.steps * 1e3)
         result = {
             "metric": "halo2_proofs_verified_per_sec",
             "value": round(B_total * args.steps / elapsed, 2),

@@ -730,7 +730,12 @@ static int msm_terms_per_lane(uint32_t in_flight_hint) {
 static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const uint32_t *scalars, const uint32_t *pts,
                                  uint32_t *tabws, hipStream_t st, uint32_t in_flight_hint = 1) {
     const int tpl = msm_terms_per_lane(in_flight_hint);
-    if (tpl > 1 && ma.pt_tab && !ma.skip && ma.grp_end[0] == ma.n_terms && ma.n_terms >= (uint32_t)tpl && ma.n_terms <= 256u * tpl) {
+    // (only launches of at least a quarter of a wave per SIMD at one lane per term: below that the launch is a chain of lone
+    //  waves whatever else is in flight, and the two-lanes-per-term ladder is the shortest chain - sha256 shape x 128 with six
+    //  shares in flight: MSM 2.5 ms -> 1.4 ms alone)
+    const bool fills = (double)n * ma.n_terms / 64.0 >= msm_n_simd() / 4.0;
+    static const bool tpl_forced = getenv("H2V_MSM_TPL") != nullptr;
+    if (tpl > 1 && (fills || tpl_forced) && ma.pt_tab && !ma.skip && ma.grp_end[0] == ma.n_terms && ma.n_terms >= (uint32_t)tpl && ma.n_terms <= 256u * tpl) {
         const uint32_t lpp = (ma.n_terms + tpl - 1) / tpl, bs = 256;
         const uint32_t per_block = bs / lpp, blocks = (n + per_block - 1) / per_block;
         if (tpl == 2) hipLaunchKernelGGL(k_g1_msm_multi2, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);

@@ -1,30 +1,41 @@
 #!/bin/bash
 # One profile set on the GPU box (run through gpurun from the repo root):
 #   tools/scripts/profile_round.sh TAG WORKLOAD BATCH MODE [extra bench.py flags]
-# e.g. tools/scripts/profile_round.sh r02_v24 simple_mul 4096 per-proof
+# e.g. tools/scripts/profile_round.sh r03_v40 simple_mul 4096 per-proof
 # writes, under gpurun_out/ (copy the ones to keep into profiles/):
-#   TAG_bench.json                the bench line of the default-length run (CPU baseline included)
-#   TAG_bench_under_rocprof.json  the line of the profiled run (--timed-only: the same launches rocprofv3 averages over)
-#   TAG_kernel_stats.csv          rocprofv3 --kernel-trace --stats of that command
-#   TAG_pmc_summary.txt           mean counters per launch, from separate --pmc passes (tools/pmc_summary.py); the first
-#                                 line records what was profiled - bench.py only attaches traffic from a matching file
+#   TAG_kernel_stats.csv          rocprofv3 --kernel-trace --stats of the TIMED steps (bench.py --timed-only --no-alone: the
+#                                 library's lanes keep the steps in flight, so these averages are overlapped durations)
+#   TAG_kernel_stats_alone.csv    the same kernels ONE STEP AT A TIME with the launch shapes of the timed run
+#                                 (--pipeline streams --inflight 1 --hint N): each kernel's own duration - what `roofline` uses
+#   TAG_pmc_summary.txt           mean counters per launch from separate --pmc passes of that one-step-at-a-time command
+#                                 (tools/pmc_summary.py); its first line records what was profiled, and bench.py only
+#                                 attaches `traffic` from a file whose workload / batch / mode match
+#   TAG_bench.json                the bench line of the default-length run (CPU baseline included), taken LAST, with the
+#                                 PMC summary already in profiles/ on the box, so that roofline.traffic is never null
 TAG=$1; WL=$2; BATCH=$3; MODE=$4; shift 4
 ARGS="--workload $WL --batch $BATCH --mode $MODE --no-rlc-secondary $*"
 O=gpurun_out
 mkdir -p $O
-timeout -k 10 400 python bench.py $ARGS > $O/b_$TAG.log 2>&1; grep "^{" $O/b_$TAG.log | tail -1 > $O/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-# the profiled command: the steps-in-flight count the run above settled on, and nothing but warm-up + timed steps, so
-# that rocprofv3's per-kernel averages and the line's event-timed kernel_ms cover the same launches
-INF=$(python -c "import json,sys; print(json.load(open('$O/${TAG}_bench.json'))['config']['steps_in_flight'])")
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py $ARGS --steps 60 --warmup 5 --inflight $INF --timed-only > $O/prof_$TAG.log 2>&1
-grep "^{" $O/prof_$TAG.log | tail -1 > $O/${TAG}_bench_under_rocprof.json
+# 1. a first line, only to learn the steps in flight / the hint of the timed run
+timeout -k 10 300 python bench.py $ARGS --no-cpu-baseline --steps 10 > $O/b0_$TAG.log 2>&1; grep "^{" $O/b0_$TAG.log | tail -1 > $O/${TAG}_bench0.json
+INF=$(python -c "import json,sys; print(json.load(open('$O/${TAG}_bench0.json'))['config']['steps_in_flight'])")
+# 2. the timed steps under rocprofv3 (nothing but warm-up + timed steps)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py $ARGS --steps 60 --warmup 5 --timed-only --no-alone > $O/prof_$TAG.log 2>&1
+cp $O/prof_$TAG/*/*kernel_stats.csv $O/${TAG}_kernel_stats.csv
+# 3. one step at a time, same launch shapes: the kernels' own durations
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profa_$TAG -- python3 bench.py $ARGS --steps 20 --warmup 3 --timed-only --no-alone --pipeline streams --inflight 1 --hint $INF > $O/profa_$TAG.log 2>&1
+cp $O/profa_$TAG/*/*kernel_stats.csv $O/${TAG}_kernel_stats_alone.csv
+# 4. counters, separate passes, same one-step-at-a-time command
 for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
   n=$(echo $c | cut -d" " -f1)
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${TAG}_$n -- python3 bench.py $ARGS --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 --hint $INF > $O/pmc_${TAG}_$n.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${TAG}_$n -- python3 bench.py $ARGS --steps 2 --warmup 1 --timed-only --no-alone --pipeline streams --inflight 1 --hint $INF > $O/pmc_${TAG}_$n.log 2>&1 || exit 1
 done
-{ echo "# workload=$WL batch=$BATCH mode=$MODE tag=$TAG (rocprofv3 --pmc, separate passes; bench.py $ARGS --steps 2 --warmup 1 --inflight 1 --hint $INF)"; python tools/pmc_summary.py $O/pmc_${TAG}_*; } > $O/${TAG}_pmc_summary.txt
-grep -E "INSTS_VALU|FETCH|WRITE_SIZE|WAIT_ANY|WAVE_CYCLES" $O/${TAG}_pmc_summary.txt
-cat $O/prof_$TAG/*/*kernel_stats.csv | head -12
-cp $O/prof_$TAG/*/*kernel_stats.csv $O/${TAG}_kernel_stats.csv
+{ echo "# workload=$WL batch=$BATCH mode=$MODE tag=$TAG (rocprofv3 --pmc, separate passes; bench.py $ARGS --steps 2 --warmup 1 --timed-only --no-alone --pipeline streams --inflight 1 --hint $INF)"; python tools/pmc_summary.py $O/pmc_${TAG}_*; } > $O/${TAG}_pmc_summary.txt
+cp $O/${TAG}_pmc_summary.txt profiles/${TAG}_pmc_summary.txt    # (on the box: the final line below reads it)
+# 5. the line
+timeout -k 10 400 python bench.py $ARGS > $O/b_$TAG.log 2>&1; grep "^{" $O/b_$TAG.log | tail -1 > $O/${TAG}_bench.json
+grep -E "INSTS_VALU|FETCH|WRITE_SIZE" $O/${TAG}_pmc_summary.txt
+head -8 $O/${TAG}_kernel_stats.csv | cut -d, -f1-5
+head -8 $O/${TAG}_kernel_stats_alone.csv | cut -d, -f1-5
 cut -c1-300 $O/${TAG}_bench.json
