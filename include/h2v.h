@@ -77,6 +77,16 @@ typedef struct {
  * h2v_plan_load: parse + validate the plan blob (plutus_halo2_verifier_gen_amd.plan.compile_plan(vk).to_bytes())
  * and upload it to `device`.  Immutable after load; may be shared by threads (each with its own workspace). */
 int h2v_plan_load(const uint8_t *plan, size_t len, int device, h2v_plan **out);
+/* (round 3) The plan compiler behind the boundary: a verifying-key description - the JSON form frozen as docs/vk_schema.json
+ * ("h2v-vk/1": what `extract_circuit` reads out of a midnight_proofs VerifyingKey + ParamsVerifierKZG,
+ * /root/reference/src/plutus_gen/extraction/mod.rs:31-232, instantiation_data.rs:26-41; the serde exporter is in
+ * INTEGRATION.md) - to the blob h2v_plan_load takes.  Host-only (no GPU needed), byte-identical with
+ * plutus_halo2_verifier_gen_amd.plan.compile_plan(vk).to_bytes().  *blob_out is malloc'ed: release it with h2v_blob_free.
+ * A description the reference itself could not emit a verifier for (Selector / Instance / Challenge nodes, a permutation
+ * column without a query at the current rotation, commitments that are not G1 points ...) is H2V_E_ARG with the reason in
+ * h2v_last_error(). */
+int h2v_plan_compile(const char *vk_json, size_t len, uint8_t **blob_out, size_t *blob_len);
+void h2v_blob_free(uint8_t *blob);
 void h2v_plan_free(h2v_plan *plan);
 /* plan facts: proof length in bytes, public inputs per proof, committed instances per proof (0/1), MSM terms T */
 int h2v_plan_info(const h2v_plan *plan, uint32_t *proof_len, uint32_t *n_public_inputs, uint32_t *n_committed,

@@ -11,8 +11,10 @@
 //     h2v::Guard guard = h2v::prepare(vk, {}, {instance_scalars_le32}, t);                   // throws h2v::Error on misuse
 //     guard.verify();                                                                        // throws h2v::VerifyError
 //
-// `VerifyingKey` wraps a plan blob produced by plutus_halo2_verifier_gen_amd.plan.compile_plan(vk).to_bytes()
-// (the counterpart of extract_circuit, /root/reference/src/plutus_gen/extraction/mod.rs:31).
+// `VerifyingKey` wraps a plan: VerifyingKey::from_json(description) compiles one behind the C-ABI (h2v_plan_compile, the
+// counterpart of extract_circuit, /root/reference/src/plutus_gen/extraction/mod.rs:31; the description is the JSON of
+// docs/vk_schema.json), or it takes a blob made earlier (plutus_halo2_verifier_gen_amd.plan.compile_plan(vk).to_bytes()
+// gives the same bytes).
 #pragma once
 #include <condition_variable>
 #include <cstdint>
@@ -45,6 +47,19 @@ inline void check(int rc) {
 class VerifyingKey {  // VerifyingKey<F, KZGCommitmentScheme<Bls12>> + ParamsVerifierKZG for this path
   public:
     VerifyingKey(const uint8_t *plan_blob, size_t len, int device = 0) { check(h2v_plan_load(plan_blob, len, device, &p_)); }
+    /// from the verifying-key description (JSON, docs/vk_schema.json): h2v_plan_compile + h2v_plan_load, no Python in the loop
+    static std::vector<uint8_t> compile(const std::string &vk_json) {
+        uint8_t *blob = nullptr;
+        size_t n = 0;
+        check(h2v_plan_compile(vk_json.data(), vk_json.size(), &blob, &n));
+        std::vector<uint8_t> out(blob, blob + n);
+        h2v_blob_free(blob);
+        return out;
+    }
+    static std::unique_ptr<VerifyingKey> from_json(const std::string &vk_json, int device = 0) {
+        const std::vector<uint8_t> blob = compile(vk_json);
+        return std::unique_ptr<VerifyingKey>(new VerifyingKey(blob.data(), blob.size(), device));
+    }
     VerifyingKey(const VerifyingKey &) = delete;
     VerifyingKey &operator=(const VerifyingKey &) = delete;
     ~VerifyingKey() { h2v_plan_free(p_); }

@@ -146,6 +146,13 @@ def vk_desc(vk: dict, omega: int, omega_inv: int, barycentric_weight: int) -> by
         for inner in vk["recursion_vks"]:
             bases += [bytes.fromhex(h) for h in inner["fixed_commitments"] + inner["permutation_commitments"]]
         out += struct.pack("<II", 1, len(bases)) + b"".join(bases)
+    phases, chal = vk.get("advice_column_phase"), vk.get("challenge_phase")
+    if phases is not None or chal:
+        if vk.get("recursion_vks") is None:
+            out += struct.pack("<II", 0, 0)      # (the phase section follows the recursion section)
+        phases = phases if phases is not None else [0] * vk["num_advice_columns"]
+        out += struct.pack("<I", len(phases)) + bytes(phases)
+        out += struct.pack("<I", len(chal or [])) + bytes(chal or [])
     return bytes(out)
 
 

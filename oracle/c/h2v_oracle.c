@@ -124,6 +124,9 @@ struct orc_vk {
     int has_rec;
     uint32_t n_rec_bases;
     g1a *rec_bases;
+    /* multi-phase circuits: phase of every advice column / challenge (extraction_steps/proof.rs:22-46); NULL = one phase */
+    uint8_t *adv_phase, *chal_phase;
+    uint32_t n_challenges, max_phase;
     /* derived */
     uint32_t chunk_len, n_chunks, n_splits;
     int n_queries; query *queries;
@@ -292,6 +295,20 @@ orc_vk *orc_vk_parse(const uint8_t *desc, size_t len) {
         /* not enough public inputs to support recursion: aiken.rs:702 (nb_vks + F + 10; nb_vks >= 1) */
         if (vk->has_rec && vk->n_pi < 1 + vk->n_rec_bases + 10) goto fail;
     }
+    if (r.pos < r.len) { /* optional phase section */
+        uint32_t na = rd_u32(&r);
+        if (r.err || na != vk->n_adv_cols) goto fail;
+        b = rd_bytes(&r, na);
+        if (!b && na) goto fail;
+        vk->adv_phase = (uint8_t *)calloc(na + 1, 1);
+        for (uint32_t i = 0; i < na; i++) { vk->adv_phase[i] = b[i]; if (b[i] > vk->max_phase) vk->max_phase = b[i]; }
+        vk->n_challenges = rd_u32(&r);
+        if (r.err || vk->n_challenges > 4096) goto fail;
+        b = rd_bytes(&r, vk->n_challenges);
+        if (!b && vk->n_challenges) goto fail;
+        vk->chal_phase = (uint8_t *)calloc(vk->n_challenges + 1, 1);
+        for (uint32_t i = 0; i < vk->n_challenges; i++) vk->chal_phase[i] = b[i];
+    }
     if (vk->n_perm_comm != vk->n_perm_cols) goto fail;
     /* every expression index must exist */
     for (int i = 0; i < vk->pool.cnt; i++) {
@@ -331,7 +348,7 @@ void orc_vk_free(orc_vk *vk) {
     free(vk->lk_in); free(vk->lk_tab); free(vk->lk_nin); free(vk->lk_ntab);
     for (uint32_t i = 0; i < vk->n_trash; i++) if (vk->tr_exprs) free(vk->tr_exprs[i]);
     free(vk->tr_sel); free(vk->tr_exprs); free(vk->tr_n);
-    free(vk->perm_cols); free(vk->fixed_comm); free(vk->perm_comm); free(vk->rec_bases);
+    free(vk->perm_cols); free(vk->fixed_comm); free(vk->perm_comm); free(vk->rec_bases); free(vk->adv_phase); free(vk->chal_phase);
     free(vk->queries); free(vk->cd); free(vk->sets); free(vk->sort_order);
     free(vk);
 }
@@ -538,7 +555,14 @@ int orc_verify(const orc_vk *vk, const uint8_t *proof, size_t proof_len, const u
 #define RD_SCALAR(dst) do { if (!tr_read_scalar(&tr, (dst), &canonical)) REJECT(ORC_REJ_SHORT); if (!canonical) bad_scalar = 1; } while (0)
     /* P2 proof read / squeeze order: extraction_steps/proof.rs:13-143 */
     fr theta, beta, gamma, trash, y, x, x1, x2, x3, x4;
-    for (i = 0; i < vk->n_adv_cols; i++) RD_POINT(&adv_c[i]);
+    /* per phase: the advice commitments of that phase, then one squeeze per challenge of that phase (proof.rs:22-46);
+     * the challenge values are not used by any expression (languages/aiken.rs:150-156: a panic) */
+    for (uint32_t phase = 0; phase <= vk->max_phase; phase++) {
+        for (i = 0; i < vk->n_adv_cols; i++)
+            if ((vk->adv_phase ? vk->adv_phase[i] : 0) == phase) RD_POINT(&adv_c[i]);
+        for (i = 0; i < vk->n_challenges; i++)
+            if (vk->chal_phase[i] == phase) { fr unused; tr_squeeze(&tr, &unused); }
+    }
     tr_squeeze(&tr, &theta);
     for (i = 0; i < L; i++) { RD_POINT(&lk_pin[i]); RD_POINT(&lk_ptab[i]); }
     tr_squeeze(&tr, &beta);

@@ -60,7 +60,7 @@ def _rlc_opts(seed, one_stream: bool = False):
 
 
 EXPORTS = [
-    "h2v_plan_load", "h2v_plan_free", "h2v_plan_info", "h2v_workspace_create", "h2v_workspace_free",
+    "h2v_plan_load", "h2v_plan_free", "h2v_plan_info", "h2v_plan_compile", "h2v_blob_free", "h2v_workspace_create", "h2v_workspace_free",
     "h2v_workspace_timings", "h2v_workspace_hint_in_flight", "h2v_workspace_create_lanes", "h2v_workspace_defer_joins",
     "h2v_workspace_join", "h2v_workspace_lanes",
     "h2v_verify_batch", "h2v_verify_batch_submit", "h2v_verify_batch_wait", "h2v_verify_batch_device", "h2v_verify_batch_rlc", "h2v_verify_batch_rlc_device",
@@ -93,6 +93,8 @@ def lib():
         L.h2v_build_id.restype = C.c_char_p
         L.h2v_plan_load.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         L.h2v_plan_free.argtypes = [C.c_void_p]
+        L.h2v_plan_compile.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.h2v_blob_free.argtypes = [C.c_void_p]
         L.h2v_plan_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4
         L.h2v_workspace_create.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         L.h2v_workspace_free.argtypes = [C.c_void_p]
@@ -128,6 +130,17 @@ def lib():
 def check(rc: int):
     if rc != H2V_OK:
         raise H2VError("h2v error %d: %s" % (rc, (lib().h2v_last_error() or b"").decode()))
+
+
+def plan_compile(vk_json: str) -> bytes:
+    """h2v_plan_compile: the C++ plan compiler behind the C-ABI (host-only; byte-identical with plan.compile_plan)."""
+    raw = vk_json.encode()
+    out, n = C.c_void_p(), C.c_size_t()
+    check(lib().h2v_plan_compile(raw, len(raw), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        lib().h2v_blob_free(out)
 
 
 def device_count() -> int:

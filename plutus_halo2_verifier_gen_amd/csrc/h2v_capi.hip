@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "h2v_kernels.hip"
+#include "h2v_plancc.hpp"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) {
@@ -39,6 +40,27 @@ extern "C" int h2v_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+
+// ---------------------------------------------------------------------------------------------- plan compiler
+// VerifyingKey description (JSON, docs/vk_schema.json) -> plan blob, on the host: no GPU is needed for this call.
+extern "C" int h2v_plan_compile(const char *vk_json, size_t len, uint8_t **blob_out, size_t *blob_len) {
+    if (!vk_json || !blob_out || !blob_len) return fail(H2V_E_ARG, "null argument");
+    *blob_out = nullptr; *blob_len = 0;
+    try {
+        const h2vplan::VK vk = h2vplan::parse_vk(vk_json, len);
+        const std::vector<uint8_t> blob = h2vplan::compile_plan(vk);
+        uint8_t *out = (uint8_t *)malloc(blob.size());
+        if (!out) return fail(H2V_E_DEVICE, "out of memory");
+        memcpy(out, blob.data(), blob.size());
+        *blob_out = out; *blob_len = blob.size();
+        return H2V_OK;
+    } catch (const h2vplan::CompileError &e) {
+        return fail(H2V_E_ARG, std::string("verifying-key description: ") + e.what());
+    } catch (const std::exception &e) {
+        return fail(H2V_E_ARG, std::string("plan compiler: ") + e.what());
+    }
+}
+extern "C" void h2v_blob_free(uint8_t *blob) { free(blob); }
 
 struct h2v_plan {
     int device = 0;

@@ -328,7 +328,18 @@ def compile_plan(vk: VerifyingKey, lanes: Optional[int] = None, legacy_no_trash_
         pis.append(r)
 
     # ---- P2: proof read order (proof.rs:13-143)
-    adv_pts = [read_point("a%d" % (i + 1)) for i in range(vk.num_advice_columns)]
+    # advice commitments phase by phase, every phase followed by the squeezes of its challenges (proof.rs:22-46); the
+    # challenges themselves are never used (no expression may name one), they only advance the transcript
+    adv_phase = vk.advice_column_phase or [0] * vk.num_advice_columns
+    chal_phase = vk.challenge_phase or []
+    adv_pts: List[Optional[int]] = [None] * vk.num_advice_columns
+    for phase in range((max(adv_phase) if adv_phase else 0) + 1):
+        for i in range(vk.num_advice_columns):
+            if adv_phase[i] == phase:
+                adv_pts[i] = read_point("a%d" % (i + 1))
+        for ph in chal_phase:
+            if ph == phase:
+                squeeze()
     theta = squeeze()
     lk_pin, lk_ptab = [], []
     for i in range(L):
@@ -856,7 +867,7 @@ def _schedule_cost(bundles) -> float:
     for bun in bundles:
         ops = {r[0] for r in bun if r is not None}
         t = _COST_BUNDLE
-        for op in ops:
+        for op in sorted(ops):   # (a fixed order: the sum is floating point, and csrc/h2v_plancc.hpp must reproduce it bit for bit)
             if op == OP_MUL:
                 t += _COST_MUL
             elif op == OP_INV:

@@ -63,6 +63,13 @@ class VerifyingKey:
     recursion_vks: Optional[list] = None
     # the JSON form of this object is frozen as docs/vk_schema.json ("h2v-vk/1"); a change of meaning bumps the number
     schema_version: int = 1
+    # multi-phase circuits (cs.advice_column_phase() / cs.challenge_phase(), extraction_steps/proof.rs:22-46): the phase of
+    # every advice column and of every challenge.  The proof carries the advice commitments phase by phase, each phase
+    # followed by the squeezes of its challenges (the challenges only advance the transcript: an expression that used one
+    # is a panic in the reference, languages/aiken.rs:150-156).  None = one phase, no challenges (optional fields of the
+    # schema: a description without them means exactly that).
+    advice_column_phase: Optional[List[int]] = None
+    challenge_phase: Optional[List[int]] = None
 
     # ---- derived (instantiation_data.rs:84-103)
     @property
@@ -185,6 +192,18 @@ def validate(vk: "VerifyingKey", strict_rotations: bool = False) -> None:
         raise VKError("cs_degree must be at least 3 (chunk length cs_degree - 2)")
     if vk.n_committed_instances not in (0, 1):
         raise VKError("the reference supports 0 or 1 committed instance columns (extraction/mod.rs:41-55)")
+    if vk.advice_column_phase is not None:
+        ph = vk.advice_column_phase
+        if len(ph) != vk.num_advice_columns or any((not isinstance(x, int)) or x < 0 or x > 255 for x in ph):
+            raise VKError("advice_column_phase: one phase (0..255) per advice column")
+        if vk.num_advice_columns and set(range(max(ph) + 1)) - set(ph) - set(vk.challenge_phase or []):
+            pass   # (an empty phase is legal: the reference iterates 0..=max_phase and simply emits nothing for it)
+    if vk.challenge_phase is not None:
+        if any((not isinstance(x, int)) or x < 0 or x > 255 for x in vk.challenge_phase):
+            raise VKError("challenge_phase: one phase (0..255) per challenge")
+        top = max(vk.advice_column_phase or [0]) if (vk.advice_column_phase or vk.num_advice_columns) else 0
+        if any(x > top for x in vk.challenge_phase):
+            raise VKError("a challenge of a phase beyond the last advice phase is never squeezed (proof.rs:24-29 iterates 0..=max advice phase)")
     if not (0 <= vk.transcript_repr < bls.R):
         raise VKError("transcript_repr is not a canonical scalar")
     for name, qs, ncols in (("advice", vk.advice_queries, vk.num_advice_columns), ("fixed", vk.fixed_queries, vk.num_fixed_columns),
@@ -648,6 +667,18 @@ def trashcan_mix_vk(seed: int = 0x48325637):
                       trash_exprs=(2, 1))
 
 
+def phased_vk(seed: int = 0x48325638):
+    """A multi-phase circuit: advice columns in three phases and challenges squeezed after phases 0 and 1
+    (extraction_steps/proof.rs:22-46: per phase, that phase's advice commitments, then that phase's challenges) - otherwise
+    a small chip mix with a lookup and a trashcan."""
+    adv = [[0, 1]] * 2 + [[0]] * 3
+    vk, td = _shaped_vk("phased", seed, k=8, degree=5, n_adv=5, n_fix=6, n_cc=4, lookup_arg_exprs=[2], gate_exprs=3,
+                        gate_ops={"mul": 14, "add": 11, "neg": 2}, adv_rot_sets=adv, n_pi=2, n_ci=0, trash_exprs=(2,))
+    vk.advice_column_phase = [0, 1, 0, 2, 1]
+    vk.challenge_phase = [0, 1, 1]
+    return vk, td
+
+
 def ivc_vk(seed: int = 0x48325636):
     """IVC-shaped circuit (examples/ivc.rs, src/circuits/ivc_circuit.rs): a small chip mix whose public inputs carry
     the verifying-key hash, the collapsed accumulator of the previous step and the fixed-base scalars
@@ -676,4 +707,5 @@ BUILDERS = {
     "secp256k1": secp256k1_vk,
     "ivc": ivc_vk,
     "trashcan_mix": trashcan_mix_vk,
+    "phased": phased_vk,
 }

@@ -2,7 +2,7 @@
 // (examples/simple_mul.rs:97-104): init_from_bytes -> prepare -> verify, one proof at a time, then the same proofs
 // through verify_batch.
 //
-// usage: h2v_cpp_driver <plan.bin> <batch.bin>
+// usage: h2v_cpp_driver <plan.bin | vk.json> <batch.bin>      (vk.json: the key description is compiled behind the C-ABI)
 // batch.bin: u32 n, u32 n_pi, u32 has_ci, then per proof: u32 len, bytes, n_pi * 32 B instances, [48 B committed]
 // prints "single <bits>" and "batch <bits>", or "error <code> <text>" (exit 2) when the library cannot run.
 #include <cstdio>
@@ -28,7 +28,13 @@ static uint32_t rd32(const std::vector<uint8_t> &b, size_t &o) {
 int main(int argc, char **argv) {
     if (argc != 3) { std::fprintf(stderr, "usage: %s plan.bin batch.bin\n", argv[0]); return 64; }
     try {
-        const std::vector<uint8_t> blob = slurp(argv[1]), bb = slurp(argv[2]);
+        std::vector<uint8_t> blob = slurp(argv[1]);
+        const std::vector<uint8_t> bb = slurp(argv[2]);
+        const std::string arg1 = argv[1];
+        if (arg1.size() > 5 && arg1.substr(arg1.size() - 5) == ".json") {      // JSON -> plan, no Python in the loop
+            blob = h2v::VerifyingKey::compile(std::string(blob.begin(), blob.end()));
+            std::printf("compiled_plan_bytes %zu\n", blob.size());
+        }
         h2v::VerifyingKey vk(blob.data(), blob.size(), 0);
         size_t o = 0;
         const uint32_t n = rd32(bb, o), n_pi = rd32(bb, o), has_ci = rd32(bb, o);

@@ -35,6 +35,7 @@ def _write_case(tmp_path, n=6, corrupt=(1, 4)):
     for i in range(n):
         blob += struct.pack("<I", len(proofs[i])) + bytes(proofs[i]) + b.instances[96 * i:96 * i + 96]
     (tmp_path / "plan.bin").write_bytes(pl.to_bytes())
+    (tmp_path / "vk.json").write_text(vk.to_json())
     (tmp_path / "batch.bin").write_bytes(blob)
     return str(tmp_path / "plan.bin"), str(tmp_path / "batch.bin"), "".join("0" if i in corrupt else "1" for i in range(n))
 
@@ -57,11 +58,17 @@ def test_cpp_header_builds_and_fails_loudly_without_gpu(driver, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_prepare_verify_on_gpu(driver, tmp_path):
+@pytest.mark.parametrize("source", ["plan.bin", "vk.json"])
+def test_cpp_prepare_verify_on_gpu(driver, tmp_path, source):
+    """source = vk.json: the driver goes JSON -> h2v_plan_compile -> h2v_plan_load -> verify with no Python in the loop"""
     plan, batch, want = _write_case(tmp_path)
+    if source == "vk.json":
+        plan = os.path.join(os.path.dirname(plan), "vk.json")
     r = subprocess.run([driver, plan, batch], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = dict(l.split(" ", 1) for l in r.stdout.strip().splitlines())
+    if source == "vk.json":
+        assert int(lines["compiled_plan_bytes"]) == os.path.getsize(os.path.join(os.path.dirname(plan), "plan.bin"))
     assert lines["single"] == want and lines["batch"] == want
     assert lines["rlc"] == want and lines["stream0"] == want and lines["stream1"] == want
     assert lines["rlc_fell_back"] == "1"          # the corrupted proofs are caught only by the pairing

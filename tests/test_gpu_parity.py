@@ -308,7 +308,7 @@ TRACE_NAMES = ["theta", "beta", "gamma", "trash", "y", "x", "x1", "x2", "x3", "x
                "l_last", "l_0", "active_rows", "h_eval", "vanishing_s", "f_eval", "v"]
 
 
-@pytest.mark.parametrize("name", ["simple_mul", "lookup_table", "atms_with_lookups", "sha256", "secp256k1", "ivc", "trashcan_mix"])
+@pytest.mark.parametrize("name", ["simple_mul", "lookup_table", "atms_with_lookups", "sha256", "secp256k1", "ivc", "trashcan_mix", "phased"])
 def test_end_to_end_vs_oracle(be, circuits, name):
     from plutus_halo2_verifier_gen_amd import synth
     vk, td, pl, dp, ov = circuits[name]
