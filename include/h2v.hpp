@@ -207,7 +207,7 @@ class BatchStream {
     bool push(const h2v_batch &batch, std::vector<uint8_t> *done = nullptr) {
         Workspace &w = *ws_[next_ % ws_.size()];
         bool have = false;
-        if (next_ >= ws_.size()) {
+        if (next_ - collected_ >= ws_.size()) {   // every workspace holds a batch: collect the oldest (it is this one's)
             std::vector<uint8_t> acc = w.wait();
             if (done) *done = std::move(acc);
             have = true;

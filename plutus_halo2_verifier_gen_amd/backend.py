@@ -348,7 +348,7 @@ class BatchStream:
         d = len(self.wss)
         w = self.wss[self._next % d]
         out = None
-        if self._next >= d:
+        if self._next - self._collected >= d:     # every workspace holds a batch: collect the oldest (it is this one's)
             out = w.wait(self._n[self._collected % d])
             self._collected += 1
         self.plan.submit(host_batch, w, rlc=self.rlc, seed=self.seed)

@@ -224,10 +224,20 @@ def test_in_flight_hint_changes_the_shape_not_the_verdicts(be, circuits):
         a5 = dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws5)
         a8 = dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws8)
         assert list(a1) == list(a5) == list(a8) == batch.expected
-        assert ws1.timings().msm_lanes_per_term in (1, 2, 3) and ws5.timings().msm_lanes_per_term in (18, 3)
+        # (a 96-proof launch is a chain of lone waves whatever else is in flight: it keeps the two-lanes-per-term ladder)
+        assert ws1.timings().msm_lanes_per_term in (1, 2, 3) and ws5.timings().msm_lanes_per_term in (1, 2, 3)
         with pytest.raises(be.H2VError):
             ws5.hint_in_flight(0)
         ws1.close(); ws5.close(); ws8.close()
+    # from a quarter of a wave per SIMD up (simple_mul: 1024 proofs x 16 terms = 256 waves) the hint selects two terms per lane
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    batch = synth.forge_batch(vk, td, 1024, seed=65, plan=pl, workers=8)
+    batch = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.05, seed=66, kinds=list(synth.CORRUPTIONS))
+    ws = be.Workspace(dp, 1024)
+    ws.hint_in_flight(5)
+    assert list(dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws)) == batch.expected
+    assert ws.timings().msm_lanes_per_term == 18
+    ws.close()
     # the split launch (per-proof terms two per lane beside the fixed-base lanes) needs a batch that does not fit one wave per SIMD
     vk, td, pl, dp, ov = circuits["atms_with_lookups"]
     batch = synth.forge_batch(vk, td, 2048, seed=63, plan=pl, workers=8)

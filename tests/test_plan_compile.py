@@ -9,7 +9,6 @@ import pytest
 
 from plutus_halo2_verifier_gen_amd import backend, bls12_381 as bls, plan as PL, vk as V
 
-os.environ.setdefault("H2V_NO_TORCH_PRELOAD", "1")
 
 
 @pytest.mark.parametrize("name", sorted(V.BUILDERS))
