@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo = rehearsal of the N > 1 code path on a box with one GPU "
                          "(every rank on the device H2V_BENCH_DEVICE names, accept bytes gathered through host memory)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the accept gather out (rehearsals: what the collective costs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rlc-secondary", action="store_true", help="per-proof runs: skip the extra measurement of the RLC mode")
     ap.add_argument("--cpu-sample", type=int, default=1024)
@@ -415,9 +416,9 @@ def main():
     inflight_probe = None
     if args.pipeline == "streams":
         inflight, inflight_probe = pick_inflight(args.mode, inflight_candidates)
-        run = streams_run(args.mode, inflight, args.steps, args.warmup, True)
+        run = streams_run(args.mode, inflight, args.steps, args.warmup, not args.no_gather)
     else:
-        run = lanes_run(args.mode, args.steps, args.warmup, True)
+        run = lanes_run(args.mode, args.steps, args.warmup, not args.no_gather)
         inflight = run.in_flight
     elapsed, accept = run.el, run.accept
     k_steps = min(args.steps, 48)
