@@ -117,6 +117,13 @@ int h2v_workspace_create_lanes(const h2v_plan *plan, uint64_t max_batch, uint32_
  * `stream` argument before it. */
 int h2v_workspace_defer_joins(h2v_workspace *ws, int defer);
 int h2v_workspace_join(h2v_workspace *ws, void *stream);
+/* Launch-shape options of a workspace (round 3: what used to be reachable through environment variables only; results never
+ * depend on them - tests/test_gpu_parity.py::test_workspace_options_change_the_shape_not_the_verdicts).  value 0 = the
+ * launcher's own choice (DESIGN.md sections 4.1, 4.2, 6). */
+#define H2V_OPT_MSM_TERMS_PER_LANE 1u /* per-proof MSM: 1 .. 4 terms per lane on one accumulator (shared doublings) */
+#define H2V_OPT_PAIRING_ENGINE 2u     /* lanes per proof of the pairing kernel: 16 (narrow), 32, 64 (wide), 1 (the one-lane cross-check kernel) */
+#define H2V_OPT_STREAMS 3u            /* -1 auto, 0: three library streams per call, 1: everything on the caller's stream, 2: + one side stream */
+int h2v_workspace_set_option(h2v_workspace *ws, uint32_t option, int32_t value);
 /* lanes and chunk size of a workspace (1 lane = not laned) */
 int h2v_workspace_lanes(const h2v_workspace *ws, uint32_t *n_lanes, uint32_t *chunk);
 /* (new) Tuning hint: the caller keeps n_in_flight batches in flight on this device (each on its own workspace).  From 4 up

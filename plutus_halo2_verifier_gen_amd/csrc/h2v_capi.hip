@@ -114,6 +114,7 @@ struct h2v_workspace {
     uint8_t ring_pipes[RING] = {}, ring_split[RING] = {}, ring_lpt[RING] = {}, ring_pair[RING] = {};
     uint64_t calls = 0;
     struct RlcWs *rlc = nullptr;   // buffers of the RLC batch mode, created by its first call
+    int opt_msm_tpl = 0, opt_pairing = 0;   // h2v_workspace_set_option: 0 = the launcher's choice
     int one_stream_mode = -1;      // lanes: 1 = the whole pipeline on the stream it is given (-1: decided from the hint)
     // ---- lanes (h2v_workspace_create_lanes): a laned workspace owns no kernel buffers of its own, only n_lanes ordinary
     // workspaces of `chunk` proofs and one library-owned stream per lane.  A verify call is cut into chunks that go round
@@ -494,6 +495,7 @@ static int ensure_lane(h2v_workspace *w, uint32_t l) {
     lw->one_stream_mode = 2;            // the pipeline on the lane's stream, the decompression beside it on one side stream
     if (const char *e = getenv("H2V_LANE_ONE_STREAM")) lw->one_stream_mode = atoi(e);   // experiment knob, read per creation
     lw->in_flight_hint = w->in_flight_hint > w->n_lanes ? w->in_flight_hint : w->n_lanes;
+    lw->opt_msm_tpl = w->opt_msm_tpl; lw->opt_pairing = w->opt_pairing;
     if (make_stream(&w->lane_st[l]) != hipSuccess || hipEventCreateWithFlags(&w->lane_ev[l], hipEventDisableTiming) != hipSuccess)
         return fail(H2V_E_DEVICE, "lane stream / event creation failed");
     return H2V_OK;
@@ -528,6 +530,21 @@ extern "C" int h2v_workspace_create(const h2v_plan *p, uint64_t max_batch, h2v_w
     // simple_mul: 8192 proofs in one launch per kernel 5.6 ms per 4096 against 5.9 in two chunks; 20480: 5.3 against 4.7)
     if (max_batch >= 4ull * default_chunk(p->d)) return h2v_workspace_create_lanes(p, max_batch, 0, 0, out);
     return ws_create_for(p->d, p->device, max_batch, false, out);
+}
+extern "C" int h2v_workspace_set_option(h2v_workspace *ws, uint32_t option, int32_t value) {
+    if (!ws) return fail(H2V_E_ARG, "null argument");
+    auto apply = [&](h2v_workspace *w) {
+        if (option == H2V_OPT_MSM_TERMS_PER_LANE) w->opt_msm_tpl = value;
+        else if (option == H2V_OPT_PAIRING_ENGINE) w->opt_pairing = value;
+        else if (option == H2V_OPT_STREAMS) w->one_stream_mode = value;
+    };
+    if (option == H2V_OPT_MSM_TERMS_PER_LANE) { if (value < 0 || value > 4) return fail(H2V_E_ARG, "terms per lane: 0 (auto) .. 4"); }
+    else if (option == H2V_OPT_PAIRING_ENGINE) { if (value != 0 && value != 1 && value != 16 && value != 32 && value != 64) return fail(H2V_E_ARG, "pairing engine: 0 (auto), 16, 32, 64 lanes per proof, or 1 (the one-lane cross-check kernel)"); }
+    else if (option == H2V_OPT_STREAMS) { if (value < -1 || value > 2) return fail(H2V_E_ARG, "streams: -1 (auto), 0 (three), 1 (the caller's), 2 (the caller's + one for the decompression)"); }
+    else return fail(H2V_E_ARG, "unknown option");
+    apply(ws);
+    for (uint32_t l = 0; l < (uint32_t)h2v_workspace::MAXL; l++) if (ws->lane[l] && option != H2V_OPT_STREAMS) apply(ws->lane[l]);
+    return H2V_OK;
 }
 extern "C" int h2v_workspace_lanes(const h2v_workspace *ws, uint32_t *n_lanes, uint32_t *chunk) {
     if (!ws) return fail(H2V_E_ARG, "null argument");
@@ -745,8 +762,13 @@ static uint32_t launch_msm_ladders(const H2vDevPlan &d, const H2vMsmArgs &ma, ui
 // Without the variable the caller's hint decides (h2v_workspace_hint_in_flight): a caller that keeps >= 4 batches in flight is
 // bound by the instructions issued, not by chain length, and two terms per lane issue 26 % fewer multiply-adds per proof
 // (measured, simple_mul x 4096: 5 in flight 5.12 -> 4.66 ms per step; with 3 in flight 5.04 -> 5.01).
+// launch-shape options of the workspace a call runs on (h2v_workspace_set_option): the launchers below run on the calling
+// host thread, inside run_pipeline / run_rlc, which set this for their duration
+struct LaunchOptions { int msm_tpl = 0, pairing = 0; };
+static thread_local LaunchOptions g_opts;
 static int msm_terms_per_lane(uint32_t in_flight_hint) {
     static const int v = []() { const char *e = getenv("H2V_MSM_TPL"); const int t = e ? atoi(e) : 0; return t >= 1 && t <= 4 ? t : 0; }();
+    if (g_opts.msm_tpl >= 1 && g_opts.msm_tpl <= 4) return g_opts.msm_tpl;
     return v ? v : (in_flight_hint >= 4 ? 2 : 1);
 }
 static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const uint32_t *scalars, const uint32_t *pts,
@@ -756,7 +778,7 @@ static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint
     //  waves whatever else is in flight, and the two-lanes-per-term ladder is the shortest chain - sha256 shape x 128 with six
     //  shares in flight: MSM 2.5 ms -> 1.4 ms alone)
     const bool fills = (double)n * ma.n_terms / 64.0 >= msm_n_simd() / 4.0;
-    static const bool tpl_forced = getenv("H2V_MSM_TPL") != nullptr;
+    const bool tpl_forced = getenv("H2V_MSM_TPL") != nullptr || g_opts.msm_tpl > 0;
     if (tpl > 1 && (fills || tpl_forced) && ma.pt_tab && !ma.skip && ma.grp_end[0] == ma.n_terms && ma.n_terms >= (uint32_t)tpl && ma.n_terms <= 256u * tpl) {
         const uint32_t lpp = (ma.n_terms + tpl - 1) / tpl, bs = 256;
         const uint32_t per_block = bs / lpp, blocks = (n + per_block - 1) / per_block;
@@ -829,8 +851,9 @@ static uint32_t launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, c
     static const int env_wide = []() { const char *e = getenv("H2V_PAIRING_WIDE"); return e ? atoi(e) : -1; }();
     static const int env_narrow = []() { const char *e = getenv("H2V_PAIRING_NARROW"); return e ? atoi(e) : -1; }();
     // impl 2 / 3 (probe): the narrow / the wide kernel whatever n
-    const bool wide = !skip && impl != 2 && (impl == 3 || (env_wide >= 0 ? env_wide != 0 : (double)n <= wide_up_to));
-    const bool narrow = !skip && !wide && (impl == 2 || env_narrow > 0 || (env_narrow < 0 && prefer_narrow));
+    if (impl == 1 && g_opts.pairing) impl = g_opts.pairing == 1 ? 0 : g_opts.pairing == 16 ? 2 : g_opts.pairing == 64 ? 3 : 4;   // 4: the two-proofs-per-wave engine
+    const bool wide = !skip && impl != 2 && impl != 4 && (impl == 3 || (env_wide >= 0 ? env_wide != 0 : (double)n <= wide_up_to));
+    const bool narrow = !skip && !wide && impl != 4 && (impl == 2 || env_narrow > 0 || (env_narrow < 0 && prefer_narrow));
     if (impl == 0) { hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg); return 1; }
     else if (wide) hipLaunchKernelGGL(k_pairing_coop_wide, dim3(n), dim3(64), COOP_LDS_BYTES(1), st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
     else if (narrow) hipLaunchKernelGGL(k_pairing_coop_narrow, dim3((n + 3) / 4), dim3(64), COOP_LDS_BYTES(COOP_GROUPS_NARROW), st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
@@ -863,6 +886,8 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
 static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst,
                         const uint8_t *ci, uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st,
                         h2v_timings *tm, bool want_trace) {
+    g_opts.msm_tpl = w->opt_msm_tpl; g_opts.pairing = w->opt_pairing;
+    struct Reset { ~Reset() { g_opts = LaunchOptions(); } } reset_opts;
     const uint32_t slots = H2V_SLOTS(d);
     const uint32_t vm_blocks = (n + 63) / 64;
     const uint32_t dec_blocks = (n * slots + 63) / 64;

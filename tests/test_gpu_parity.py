@@ -249,6 +249,42 @@ def test_in_flight_hint_changes_the_shape_not_the_verdicts(be, circuits):
     ws.close()
 
 
+def test_workspace_options_change_the_shape_not_the_verdicts(be, circuits):
+    """h2v_workspace_set_option: the launch shapes that round 2 could only force through environment variables (terms per lane
+    of the per-proof MSM, the pairing engine, the streams of a call) - every combination gives the construction's vector, the
+    reported shape is the requested one, and bad values are refused."""
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits["lookup_table"]
+    n = 130
+    batch = synth.forge_batch(vk, td, n, seed=81, plan=pl, workers=4)
+    batch = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.3, seed=82, kinds=list(synth.CORRUPTIONS))
+    ws = be.Workspace(dp, n)
+    W = be.Workspace
+    for tpl, lpt_code in ((1, None), (2, 18), (3, 19), (4, 20), (0, None)):
+        for engine in (16, 32, 64, 1, 0):
+            for streams in (0, 1, 2, -1):
+                ws.set_option(W.OPT_MSM_TERMS_PER_LANE, tpl)
+                ws.set_option(W.OPT_PAIRING_ENGINE, engine)
+                ws.set_option(W.OPT_STREAMS, streams)
+                got = dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws)
+                assert list(got) == batch.expected, (tpl, engine, streams)
+                tm = ws.timings()
+                if lpt_code:
+                    assert tm.msm_lanes_per_term == lpt_code
+                if engine:
+                    assert tm.pairing_lanes_per_proof == engine
+    for opt, bad in ((W.OPT_MSM_TERMS_PER_LANE, 5), (W.OPT_PAIRING_ENGINE, 8), (W.OPT_STREAMS, 3), (99, 0)):
+        with pytest.raises(be.H2VError):
+            ws.set_option(opt, bad)
+    ws.close()
+    # a laned workspace hands the option to its lanes
+    lw = be.Workspace(dp, n, lanes=2, chunk=50)
+    lw.set_option(W.OPT_PAIRING_ENGINE, 64)
+    assert list(dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=lw)) == batch.expected
+    assert lw.timings().pairing_lanes_per_proof == 64
+    lw.close()
+
+
 def test_quad_cooperative_addition_in_every_lane(be):
     """The quad-cooperative mixed addition (forced MSM shape H2V_MSM_LPT=8) against the one-lane one and the big-integer
     model, in EVERY lane of the quad: with its DPP broadcasts left to the optimiser, lane 0 alone came out wrong
