@@ -585,7 +585,8 @@ def main():
             # headline).  The small shares (64-128 proofs) are chains of lone waves: six of them in flight finish a step in
             # less time than one kernel's own chain takes, and the line says so instead (roofline.duration_fits_in_step)
             fits = kernel_ms[dominant] / launches <= elapsed / args.steps * 1e3 * 1.05
-            assert fits or not alone or B < 2048, (kernel_ms, elapsed / args.steps * 1e3)
+            # (a forced fixed-base split reports the SPAN of its two concurrent MSM launches: not a kernel's own duration)
+            assert fits or not alone or B < 2048 or msm_lpt == 3, (kernel_ms, elapsed / args.steps * 1e3)
         result = {
             "metric": "halo2_proofs_verified_per_sec",
             "value": round(B_total * args.steps / elapsed, 2),
