@@ -102,7 +102,7 @@ def pmc_traffic(kernel, workload, batch, mode):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=60, help="timed steps (default 60: a batch spends ~25 ms in the pipeline, so short runs mostly measure filling and draining it)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="simple_mul", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="proofs per GPU (weak) / in total (strong); default: the workload's BASELINE size")

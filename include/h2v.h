@@ -106,7 +106,7 @@ void h2v_workspace_free(h2v_workspace *ws);
  * Verdicts never depend on n_lanes or chunk (tests/test_gpu_parity.py::test_verdicts_do_not_depend_on_the_chunking); in
  * RLC mode every chunk is its own batch check.
  *   n_lanes = 0 / chunk = 0: the library's choice for this plan (chunk = the batch that gives every kernel one wave per
- *   SIMD: 4096 proofs for 16 MSM terms, 1024 for 60; 5 lanes per-proof).  h2v_workspace_create(plan, max_batch) itself
+ *   SIMD: 4096 proofs for 16 MSM terms, 1024 for 60; 16 lanes, of which the per-proof mode cycles through 6).  h2v_workspace_create(plan, max_batch) itself
  *   returns a laned workspace when max_batch >= 2 x that chunk.  n_lanes <= 16. */
 int h2v_workspace_create_lanes(const h2v_plan *plan, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk, h2v_workspace **out);
 /* Deferred joins (laned workspaces): with defer = 1 a device-resident verify call returns without making the caller's stream

@@ -484,7 +484,7 @@ static uint32_t default_chunk(const H2vDevPlan &d) {
 // batch): per-proof mode, each lane's pipeline on the lane's stream with the decompression beside it on a side stream:
 // 4 lanes 4.60, 5: 4.35, 6: 4.31, 11: 4.72; everything on the lane's stream: 5: 4.64, 8: 4.26, 11: 4.43 (five caller-owned
 // workspaces on fifteen streams, round 2's bench: 4.50); RLC mode (one stream per lane): 8 lanes 1.65, 11: 1.54, 16: 1.47.
-#define H2V_DEFAULT_LANES 11u
+#define H2V_DEFAULT_LANES 16u
 #define H2V_PER_PROOF_LANES 6u
 static int ensure_lane(h2v_workspace *w, uint32_t l) {
     if (w->lane[l]) return H2V_OK;
@@ -607,14 +607,14 @@ static int ws_fits(const h2v_workspace *w, const h2v_plan *p, uint64_t n, bool w
 // the process-wide setting is (measured, default environment: 5 lanes 5.79 -> 4.34 ms per batch).  Every queue also gets
 // its own scratch arena, sized for the kernel with the largest private segment (a process that had created 47 of them
 // died with HSA_STATUS_ERROR_OUT_OF_RESOURCES at the next launch), so the library owns a fixed POOL of such streams per
-// device - H2V_QUEUE_POOL, default 12 - and hands them out round robin: workspaces share them (a stream is an ordering
+// device - H2V_QUEUE_POOL, default 16 (24 measured slower: 4.97 against 4.30 ms per batch) - and hands them out round robin: workspaces share them (a stream is an ordering
 // domain, sharing one only adds order), they are never destroyed, and the mask names every CU.  Pool streams have the
 // default flags, i.e. they are ordered with the legacy NULL stream: callers that defer joins should not submit on the
 // NULL stream.  H2V_STREAM_CUMASK=0: plain non-blocking streams of the runtime's own pool instead.
 #include <mutex>
 static hipError_t make_stream(hipStream_t *s) {
     static const int cumask = []() { const char *e = getenv("H2V_STREAM_CUMASK"); return e ? atoi(e) : 1; }();
-    static const size_t pool_cap = []() { const char *e = getenv("H2V_QUEUE_POOL"); const int v = e ? atoi(e) : 12; return (size_t)(v < 1 ? 1 : v > 32 ? 32 : v); }();
+    static const size_t pool_cap = []() { const char *e = getenv("H2V_QUEUE_POOL"); const int v = e ? atoi(e) : 16; return (size_t)(v < 1 ? 1 : v > 32 ? 32 : v); }();
     static std::mutex mu;
     static std::vector<hipStream_t> pool[16];
     static size_t next[16] = {};
