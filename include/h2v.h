@@ -144,8 +144,10 @@ int h2v_verify_batch(const h2v_plan *plan, const h2v_batch *batch, uint8_t *acce
 /* Asynchronous host-buffer form, for callers that stream batches: _submit copies the caller's buffers into pinned staging
  * memory of `ws` (they may be reused at once), enqueues ONE upload, the verification (per proof, or the RLC batch mode with
  * H2V_SUBMIT_RLC - see below) and the download of accept[] on the workspace's own stream, and returns; _wait blocks until
- * that batch is done and copies its accept bytes out.  One batch at a time per workspace: alternate two workspaces and the
- * upload of batch k+1 runs beside the kernels of batch k.  h2v_verify_batch is _submit + _wait. */
+ * that batch is done and copies its accept bytes out.  An ordinary workspace holds one batch at a time (alternate two and
+ * the upload of batch k+1 runs beside the kernels of batch k); a LANED workspace (h2v_workspace_create_lanes) holds as many as
+ * the mode has lanes - every batch gets a staging slot of its own - and _wait collects the OLDEST: one workspace is a
+ * whole stream of host batches.  h2v_verify_batch is _submit + _wait. */
 #define H2V_SUBMIT_RLC 1u
 struct h2v_rlc_opts_s;
 int h2v_verify_batch_submit(const h2v_plan *plan, const h2v_batch *batch, h2v_workspace *ws, uint32_t flags,

@@ -167,6 +167,7 @@ class Workspace {
     Workspace &operator=(const Workspace &) = delete;
     ~Workspace() { h2v_workspace_free(w_); }
     h2v_workspace *handle() const { return w_; }
+    const VerifyingKey &vk() const { return vk_; }
     /// tuning hint (h2v_workspace_hint_in_flight): the caller keeps n batches in flight, one workspace each; never changes results
     void hint_in_flight(uint32_t n) { check(h2v_workspace_hint_in_flight(w_, n)); }
     void submit(const h2v_batch &batch, bool rlc = false) {
@@ -188,46 +189,51 @@ class Workspace {
     uint64_t n_ = 0;
 };
 
-// A verifier that keeps `depth` batches in flight (one workspace each, h2v_workspace_hint_in_flight(depth)): push() hands a
-// batch over (its host buffers may be reused at once) and returns the accept vector of the batch pushed `depth` calls
-// earlier, if there is one; drain() collects the rest in order.  depth 5 (per proof) / 11 (RLC) reach the device-resident
-// throughput on one MI355X (tools/bench_host_path.py).  Every batch must fit `max_batch`.
+// A verifier that keeps up to `depth` host-buffer batches in flight on ONE laned workspace (`depth` lanes, one chunk per
+// batch): push() hands a batch over (its host buffers may be reused at once) and, once `depth` batches are in flight,
+// returns the accept vector of the OLDEST; drain() collects the rest in order.  depth 6 (per proof) / 11-16 (RLC) reach the
+// device-resident throughput on one MI355X (tools/bench_host_path.py).  Every batch must fit `max_batch`.  (Round 2 needed
+// `depth` workspaces for this.)
 class BatchStream {
   public:
-    BatchStream(const VerifyingKey &vk, uint64_t max_batch, unsigned depth, bool rlc = false) : rlc_(rlc) {
+    BatchStream(const VerifyingKey &vk, uint64_t max_batch, unsigned depth, bool rlc = false)
+        : depth_(depth), rlc_(rlc), ws_(vk, max_batch, depth == 0 ? 1u : depth, (uint32_t)max_batch) {
         if (depth == 0) throw Error(H2V_E_ARG, "BatchStream: depth must be at least 1");
-        for (unsigned k = 0; k < depth; k++) {
-            ws_.emplace_back(new Workspace(vk, max_batch));   // (a throwing constructor leaves the earlier ones to the vector)
-            ws_.back()->hint_in_flight(depth);
-        }
     }
     BatchStream(const BatchStream &) = delete;
     BatchStream &operator=(const BatchStream &) = delete;
-    /// returns true and fills `done` when the batch pushed depth calls earlier has been collected
+    /// returns true and fills `done` when the oldest batch in flight has been collected (`depth` were in flight)
     bool push(const h2v_batch &batch, std::vector<uint8_t> *done = nullptr) {
-        Workspace &w = *ws_[next_ % ws_.size()];
         bool have = false;
-        if (next_ - collected_ >= ws_.size()) {   // every workspace holds a batch: collect the oldest (it is this one's)
-            std::vector<uint8_t> acc = w.wait();
+        if (sizes_.size() >= depth_) {
+            std::vector<uint8_t> acc = collect();
             if (done) *done = std::move(acc);
             have = true;
-            collected_++;
         }
-        w.submit(batch, rlc_);
-        next_++;
+        check(h2v_verify_batch_submit(ws_.vk().handle(), &batch, ws_.handle(), rlc_ ? H2V_SUBMIT_RLC : 0u, nullptr));
+        sizes_.push_back(batch.n);
         return have;
     }
     /// accept vectors of the batches still in flight, oldest first
     std::vector<std::vector<uint8_t>> drain() {
         std::vector<std::vector<uint8_t>> out;
-        for (; collected_ < next_; collected_++) out.push_back(ws_[collected_ % ws_.size()]->wait());
+        while (!sizes_.empty()) out.push_back(collect());
         return out;
     }
 
   private:
-    std::vector<std::unique_ptr<Workspace>> ws_;
-    uint64_t next_ = 0, collected_ = 0;
+    std::vector<uint8_t> collect() {
+        std::vector<uint8_t> accept(sizes_.front() ? sizes_.front() : 1);
+        int fb = 0;
+        check(h2v_verify_batch_wait(ws_.handle(), accept.data(), &fb));
+        accept.resize(sizes_.front());
+        sizes_.pop_front();
+        return accept;
+    }
+    unsigned depth_;
     bool rlc_;
+    Workspace ws_;
+    std::deque<uint64_t> sizes_;
 };
 
 // Every GPU of one node behind one object, in ONE process (proofs are independent, so a batch is

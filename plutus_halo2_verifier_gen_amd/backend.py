@@ -336,48 +336,37 @@ class Workspace:
 
 # ---- primitive probes (GPU parity tests)
 class BatchStream:
-    """Keeps `depth` batches in flight on `depth` workspaces (h2v_workspace_hint_in_flight(depth)) through
-    h2v_verify_batch_submit / _wait: push() hands a host batch over and returns the (accept bytes, fell_back) of the batch
-    pushed `depth` calls earlier, or None; drain() returns the rest, oldest first.  The counterpart of h2v::BatchStream."""
+    """Keeps up to `depth` host-buffer batches in flight on ONE laned workspace (h2v_workspace_create_lanes with `depth`
+    lanes, one chunk per batch) through h2v_verify_batch_submit / _wait: push() hands a host batch over and returns the
+    (accept bytes, fell_back) of the OLDEST batch once `depth` are in flight, or None; drain() returns the rest, oldest
+    first.  The counterpart of h2v::BatchStream.  (Round 2 needed `depth` workspaces for this.)"""
 
     def __init__(self, plan: "DevicePlan", max_batch: int, depth: int, rlc: bool = False, seed: bytes = None):
         if depth < 1:
             raise H2VError("BatchStream: depth must be at least 1")
-        self.plan, self.rlc, self.seed = plan, rlc, seed
-        self.wss = [Workspace(plan, max_batch) for _ in range(depth)]
-        for w in self.wss:
-            w.hint_in_flight(depth)
-        self._n = []          # proofs of the batch each workspace holds
-        self._next = self._collected = 0
+        self.plan, self.rlc, self.seed, self.depth = plan, rlc, seed, depth
+        self.ws = Workspace(plan, max_batch, lanes=depth, chunk=max_batch)
+        self._n = []          # proofs of the batches in flight, oldest first
 
     def push(self, host_batch, n: int):
         """host_batch: DevicePlan.host_batch(...)[0]; n: its number of proofs"""
-        d = len(self.wss)
-        w = self.wss[self._next % d]
         out = None
-        if self._next - self._collected >= d:     # every workspace holds a batch: collect the oldest (it is this one's)
-            out = w.wait(self._n[self._collected % d])
-            self._collected += 1
-        self.plan.submit(host_batch, w, rlc=self.rlc, seed=self.seed)
-        if len(self._n) < d:
-            self._n.append(n)
-        else:
-            self._n[self._next % d] = n
-        self._next += 1
+        if len(self._n) >= self.depth:     # every lane holds a batch: collect the oldest
+            out = self.ws.wait(self._n.pop(0))
+        self.plan.submit(host_batch, self.ws, rlc=self.rlc, seed=self.seed)
+        self._n.append(n)
         return out
 
     def drain(self):
-        d = len(self.wss)
         out = []
-        while self._collected < self._next:
-            out.append(self.wss[self._collected % d].wait(self._n[self._collected % d]))
-            self._collected += 1
+        while self._n:
+            out.append(self.ws.wait(self._n.pop(0)))
         return out
 
     def close(self):
-        for w in self.wss:
-            w.close()
-        self.wss = []
+        if self.ws is not None:
+            self.ws.close()
+            self.ws = None
 
 
 def probe_field(op: int, a_list, b_list, device: int = 0):

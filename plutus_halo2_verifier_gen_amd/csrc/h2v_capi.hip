@@ -129,6 +129,19 @@ struct h2v_workspace {
     uint32_t lanes_per_proof = 0;           // lanes the per-proof mode cycles through (the RLC mode uses all n_lanes)
     uint64_t next_lane = 0;                 // round-robin position (persists across calls: consecutive calls interleave)
     H2vDevPlan lane_plan{};                 // the creating plan's shape: lanes are created when first used
+    // host-buffer batches in flight on a laned workspace (h2v_verify_batch_submit / _wait): a ring of staging slots, each
+    // with its own pinned block, device block and accept buffers; uploads on `hs`, downloads on `hs_down`
+    struct HostSlot {
+        uint8_t *in_block = nullptr, *h_block = nullptr, *h_accept = nullptr, *d_accept = nullptr;
+        size_t in_cap = 0, acc_cap = 0;
+        hipEvent_t ev = nullptr;
+        uint64_t n = 0, call = 0;
+        bool rlc = false;
+    };
+    static constexpr int MAXH = 16;
+    HostSlot hslot[MAXH];
+    uint64_t h_head = 0, h_tail = 0;
+    hipStream_t hs_down = nullptr;
     uint32_t *rlc_fail = nullptr;           // RING counters: failed batch checks among the chunks of a call (RLC mode)
     uint32_t *rlc_fail_ptr = nullptr;       // (a lane: where its batch check reports a failure; set by the parent per call)
     // per call (ring): number of chunks, first lane, and every lane's call counters when the call had been enqueued -
@@ -400,6 +413,15 @@ static void rlc_release(struct RlcWs *r);
 static hipError_t make_stream(hipStream_t *s);
 static void ws_release(h2v_workspace *w) {
     (void)hipSetDevice(w->device);
+    if (w->hs_down) (void)hipStreamSynchronize(w->hs_down);
+    for (auto &sl : w->hslot) {
+        if (sl.in_block) (void)hipFree(sl.in_block);
+        if (sl.d_accept) (void)hipFree(sl.d_accept);
+        if (sl.h_block) (void)hipHostFree(sl.h_block);
+        if (sl.h_accept) (void)hipHostFree(sl.h_accept);
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+        sl = h2v_workspace::HostSlot();
+    }
     for (uint32_t l = 0; l < (uint32_t)h2v_workspace::MAXL; l++) {
         if (w->lane_st[l]) { (void)hipStreamSynchronize(w->lane_st[l]); }
         if (w->lane[l]) { ws_release(w->lane[l]); delete w->lane[l]; w->lane[l] = nullptr; }
@@ -1050,6 +1072,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
 static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
                    uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, const uint32_t seed[8], bool one_stream_opt);
 static uint64_t rlc_calls_of(const h2v_workspace *w);
+static const uint32_t *rlc_flags_of(const h2v_workspace *w);
 // A call on a laned workspace: chunks of at most w->chunk proofs, round robin through the lanes (continuing where the
 // previous call stopped).  Chunk c runs on its lane's own stream(s) behind everything the caller had enqueued on `st`
 // before the call and behind the lane's earlier chunks.  Nothing else orders the chunks: the kernels of neighbouring
@@ -1057,7 +1080,8 @@ static uint64_t rlc_calls_of(const h2v_workspace *w);
 // and an explicit stagger - chunk c waiting for phase 1 of chunk c - 1 - measured 10-20 % slower.  rlc: every chunk is
 // its own batch check.
 static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
-                     uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, bool rlc, const uint32_t *seed, bool force_join) {
+                     uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, bool rlc, const uint32_t *seed, bool force_join,
+                     bool never_join = false) {
     const H2vDevPlan &d = p->d;
     const uint32_t L = rlc ? w->n_lanes : (w->lanes_per_proof < w->n_lanes ? w->lanes_per_proof : w->n_lanes);
     const uint32_t nch = (n + w->chunk - 1) / w->chunk;
@@ -1092,6 +1116,7 @@ static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const
         w->lring_calls[slot][l] = w->lane[l] ? w->lane[l]->calls : 0;
         w->lring_rlc_calls[slot][l] = w->lane[l] ? rlc_calls_of(w->lane[l]) : 0;
     }
+    if (never_join) return H2V_OK;
     if (!w->defer_joins || force_join) return lanes_join(w, st);
     return H2V_OK;
 }
@@ -1255,19 +1280,117 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
 static bool rlc_supported(const h2v_plan *p);
 static int rlc_seed(const h2v_rlc_opts *o, uint32_t seed[8]);
 
+extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, uint32_t *batch_accepted, h2v_rlc_timings *tm);
+// Host-buffer batches on a LANED workspace: as many in flight as the mode has lanes, on ONE workspace.  Every batch gets a
+// staging slot of its own (pinned block + device block + accept buffers); uploads run in order on `hs`, the chunks on
+// the lanes, and the downloads on `hs_down`, each behind the lanes its batch ran on.  h2v_verify_batch_wait collects the
+// OLDEST batch.
+static int submit_laned(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws, bool rlc, const uint32_t *seed) {
+    const uint32_t depth = rlc ? ws->n_lanes : (ws->lanes_per_proof < ws->n_lanes ? ws->lanes_per_proof : ws->n_lanes);
+    if (ws->h_head - ws->h_tail >= depth || ws->h_head - ws->h_tail >= (uint64_t)h2v_workspace::MAXH)
+        return fail(H2V_E_ARG, "as many batches in flight as this workspace has lanes: call h2v_verify_batch_wait first");
+    if (!ws->hs_down) HIPCHK(make_stream(&ws->hs_down));
+    h2v_workspace::HostSlot &sl = ws->hslot[ws->h_head % h2v_workspace::MAXH];
+    if (!sl.ev) HIPCHK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    const uint64_t n = b->n;
+    sl.n = n; sl.rlc = rlc;
+    if (n) {
+        const uint64_t total = b->proof_off[n];
+        for (uint64_t i = 0; i < n; i++)
+            if (b->proof_off[i + 1] < b->proof_off[i]) return fail(H2V_E_ARG, "proof offsets must be non-decreasing");
+        auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const size_t o_inst = up16((n + 1) * 8), o_ci = o_inst + up16(n * p->d.n_pi * 32), o_proofs = o_ci + up16(n * p->d.n_ci * 48),
+                     need = o_proofs + up16(total + 64);
+        if (need > sl.in_cap) {     // (the slot is free: its previous batch has been collected)
+            if (sl.in_block) (void)hipFree(sl.in_block);
+            if (sl.h_block) (void)hipHostFree(sl.h_block);
+            sl.in_block = nullptr; sl.h_block = nullptr; sl.in_cap = 0;
+            const size_t cap = need + need / 4;
+            if (hipMalloc((void **)&sl.in_block, cap) != hipSuccess || hipHostMalloc((void **)&sl.h_block, cap, hipHostMallocDefault) != hipSuccess)
+                return fail(H2V_E_DEVICE, "staging allocation failed");
+            sl.in_cap = cap;
+        }
+        if (n > sl.acc_cap) {
+            if (sl.h_accept) (void)hipHostFree(sl.h_accept);
+            if (sl.d_accept) (void)hipFree(sl.d_accept);
+            sl.h_accept = nullptr; sl.d_accept = nullptr; sl.acc_cap = 0;
+            const size_t cap = n + n / 4 + 64;     // (+ the verdict word behind the accept bytes)
+            if (hipHostMalloc((void **)&sl.h_accept, cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&sl.d_accept, cap) != hipSuccess)
+                return fail(H2V_E_DEVICE, "staging allocation failed");
+            sl.acc_cap = cap;
+        }
+        memcpy(sl.h_block, b->proof_off, (n + 1) * 8);
+        if (p->d.n_pi) memcpy(sl.h_block + o_inst, b->instances, n * p->d.n_pi * 32);
+        if (p->d.n_ci) memcpy(sl.h_block + o_ci, b->committed, n * 48);
+        memcpy(sl.h_block + o_proofs, b->proofs, total);
+        memset(sl.h_block + o_proofs + total, 0, 64);
+        HIPCHK(hipMemcpyAsync(sl.in_block, sl.h_block, need, hipMemcpyHostToDevice, ws->hs));
+        int rc = run_laned(p, (uint32_t)n, sl.in_block + o_proofs, (const uint64_t *)sl.in_block, sl.in_block + o_inst, sl.in_block + o_ci, sl.d_accept, nullptr,
+                           ws, ws->hs, rlc, seed, false, true);
+        if (rc == H2V_OK) {
+            // the download waits for the lanes this call's chunks ran on (their events as recorded just now)
+            const int slot = (int)((ws->calls - 1) % h2v_workspace::RING);
+            sl.call = ws->calls - 1;
+            const uint32_t nch = ws->lring_chunks[slot], mod = ws->lring_mod[slot], first = ws->lring_first[slot];
+            for (uint32_t c = 0; c < nch && c < mod; c++)
+                if (hipStreamWaitEvent(ws->hs_down, ws->lane_ev[(first + c) % mod], 0) != hipSuccess) rc = fail(H2V_E_DEVICE, "stream wait failed");
+            if (rc == H2V_OK && hipMemcpyAsync(sl.h_accept, sl.d_accept, n, hipMemcpyDeviceToHost, ws->hs_down) != hipSuccess) rc = fail(H2V_E_DEVICE, "download of accept[] failed");
+            // (RLC: how many of the call's batch checks failed comes back the same way - a synchronous copy in _wait would go
+            //  through the legacy NULL stream, which every pool stream is ordered with: it would drain all batches in flight)
+            if (rc == H2V_OK && rlc && hipMemcpyAsync(sl.h_accept + ((n + 7) & ~(uint64_t)7), ws->rlc_fail + slot, 4, hipMemcpyDeviceToHost, ws->hs_down) != hipSuccess)
+                rc = fail(H2V_E_DEVICE, "download of the batch verdict failed");
+        }
+        if (rc) {
+            const std::string e = g_err;
+            (void)hipStreamSynchronize(ws->hs);
+            for (uint32_t l = 0; l < ws->n_lanes; l++) if (ws->lane_st[l]) (void)hipStreamSynchronize(ws->lane_st[l]);
+            (void)hipStreamSynchronize(ws->hs_down);
+            return fail(rc, e);
+        }
+    }
+    HIPCHK(hipEventRecord(sl.ev, ws->hs_down));
+    ws->h_head++;
+    ws->pending = true;
+    return H2V_OK;
+}
+static int wait_laned(h2v_workspace *ws, uint8_t *accept, int *fell_back) {
+    if (ws->h_head == ws->h_tail) return fail(H2V_E_ARG, "no batch in flight on this workspace");
+    h2v_workspace::HostSlot &sl = ws->hslot[ws->h_tail % h2v_workspace::MAXH];
+    HIPCHK(hipEventSynchronize(sl.ev));
+    if (sl.n) memcpy(accept, sl.h_accept, sl.n);
+    if (fell_back) {
+        *fell_back = 0;
+        if (sl.rlc && sl.n) {
+            uint32_t failed = 0;
+            memcpy(&failed, sl.h_accept + ((sl.n + 7) & ~(uint64_t)7), 4);
+            *fell_back = failed ? 1 : 0;
+        }
+    }
+    ws->h_tail++;
+    ws->pending = ws->h_head != ws->h_tail;
+    return H2V_OK;
+}
+
 // Asynchronous host-buffer form: packs + uploads the batch, enqueues the verification (per-proof, or the RLC batch mode
 // with H2V_SUBMIT_RLC) and the download of accept[] on the workspace's stream, and returns.  The caller's buffers may be
 // reused as soon as this returns (they were copied into pinned memory).  One batch at a time per workspace: alternate two
 // workspaces to overlap the upload of batch k+1 with the kernels of batch k.
 extern "C" int h2v_verify_batch_submit(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws, uint32_t flags, const h2v_rlc_opts *opts) {
     if (!p || !b || !ws) return fail(H2V_E_ARG, "null argument");
-    if (ws->pending) return fail(H2V_E_ARG, "the workspace already has a batch in flight: call h2v_verify_batch_wait first");
+    if (ws->pending && !ws->n_lanes) return fail(H2V_E_ARG, "the workspace already has a batch in flight: call h2v_verify_batch_wait first");
     if (b->n && (!b->proofs || !b->proof_off)) return fail(H2V_E_ARG, "null proofs / offsets");
     if (b->n && p->d.n_pi && !b->instances) return fail(H2V_E_ARG, "plan has public inputs but instances == NULL");
     if (b->n && p->d.n_ci && !b->committed) return fail(H2V_E_ARG, "plan has a committed instance but committed == NULL");
     HIPCHK(hipSetDevice(p->device));
     int rc = host_stream(ws);
     if (rc) return rc;
+    if (ws->n_lanes) {
+        if (b->n && (rc = ws_fits(ws, p, b->n, false))) return rc;
+        const bool rlc_l = (flags & H2V_SUBMIT_RLC) && rlc_supported(p);
+        uint32_t seed_l[8] = {};
+        if (rlc_l && (rc = rlc_seed(opts, seed_l))) return rc;
+        return submit_laned(p, b, ws, rlc_l, seed_l);
+    }
     ws->pending_n = b->n;
     ws->pending_rlc = false;
     if (b->n) {
@@ -1286,6 +1409,8 @@ extern "C" int h2v_verify_batch_submit(const h2v_plan *p, const h2v_batch *b, h2
         }
         ws->pending_rlc = rlc;
         if (rc == H2V_OK && hipMemcpyAsync(ws->h_accept, ws->accept, b->n, hipMemcpyDeviceToHost, ws->hs) != hipSuccess) rc = fail(H2V_E_DEVICE, "download of accept[] failed");
+        if (rc == H2V_OK && rlc && ws->rlc && hipMemcpyAsync(ws->h_accept + ((b->n + 7) & ~(uint64_t)7), rlc_flags_of(ws), 4, hipMemcpyDeviceToHost, ws->hs) != hipSuccess)
+            rc = fail(H2V_E_DEVICE, "download of the batch verdict failed");
         if (rc) {
             // the upload from the pinned block and some kernels may already be enqueued: nothing of this workspace may be
             // reused before they have drained
@@ -1303,6 +1428,7 @@ extern "C" int h2v_verify_batch_submit(const h2v_plan *p, const h2v_batch *b, h2
 // in RLC mode and the batch check failed, so that the per-proof kernels produced accept[].
 extern "C" int h2v_verify_batch_wait(h2v_workspace *ws, uint8_t *accept, int *fell_back) {
     if (!ws || !accept) return fail(H2V_E_ARG, "null argument");
+    if (ws->n_lanes) { HIPCHK(hipSetDevice(ws->device)); return wait_laned(ws, accept, fell_back); }
     if (!ws->pending) return fail(H2V_E_ARG, "no batch in flight on this workspace");
     HIPCHK(hipSetDevice(ws->device));
     ws->pending = false;
@@ -1310,11 +1436,10 @@ extern "C" int h2v_verify_batch_wait(h2v_workspace *ws, uint8_t *accept, int *fe
     if (ws->pending_n) memcpy(accept, ws->h_accept, ws->pending_n);
     if (fell_back) {
         *fell_back = 0;
-        if (ws->pending_rlc && ws->pending_n) {
-            uint32_t ok = 1;
-            int rc = h2v_workspace_rlc_result(ws, 0, &ok, nullptr);
-            if (rc) return rc;
-            *fell_back = ok ? 0 : 1;
+        if (ws->pending_rlc && ws->pending_n) {     // the batch verdict came back with the accept bytes (1 = passed)
+            uint32_t passed = 1;
+            memcpy(&passed, ws->h_accept + ((ws->pending_n + 7) & ~(uint64_t)7), 4);
+            *fell_back = passed ? 0 : 1;
         }
     }
     return H2V_OK;
@@ -1471,6 +1596,7 @@ static int rlc_ensure(h2v_workspace *w, const h2v_plan *p) {
     return H2V_OK;
 }
 static uint64_t rlc_calls_of(const h2v_workspace *w) { return w->rlc ? w->rlc->calls : 0; }
+static const uint32_t *rlc_flags_of(const h2v_workspace *w) { return w->rlc->flags; }
 static bool rlc_supported(const h2v_plan *p) { return !p->d.ivc && p->n_var > 0 && p->n_fix > 0 && p->n_var + p->n_fix == p->d.n_terms; }
 
 // Fall-back stage 1: group checks (h2v_rlc.hpp: k_rlc_group_terms, k_pairing_rlc_groups).  Groups of 64 proofs; every group

@@ -150,6 +150,17 @@ def test_batch_stream_keeps_batches_in_flight(be, circuits):
         got += bs.drain()
         assert [list(a) for a, _fb in got] == [b.expected for b in batches], rlc
         bs.close()
+    # the stream is ONE laned workspace: as many host batches in flight as it has lanes, the next submit is refused
+    ws = be.Workspace(dp, 128, lanes=2, chunk=128)
+    hb, k_ = dp.host_batch(batches[0].proofs, batches[0].proof_off, batches[0].instances, batches[0].committed)
+    dp.submit(hb, ws)
+    dp.submit(hb, ws)
+    with pytest.raises(be.H2VError, match="in flight"):
+        dp.submit(hb, ws)
+    assert list(ws.wait(batches[0].n)[0]) == batches[0].expected and list(ws.wait(batches[0].n)[0]) == batches[0].expected
+    with pytest.raises(be.H2VError, match="no batch"):
+        ws.wait(1)
+    ws.close()
 
 
 @pytest.mark.parametrize("name", ["simple_mul", "trashcan_mix", "ivc"])
