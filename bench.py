@@ -379,7 +379,7 @@ def main():
             best = int(t.item())
         return best, seen
 
-    PP_KEYS = ["transcript_combiner", "g1_decompress", "g1_msm", "pairing"]
+    PP_KEYS = ["transcript_combiner", "g1_decompress", "g1_msm", "g1_msm_fixed", "pairing"]
     RLC_KEYS = ["transcript_combiner", "g1_decompress", "rlc_prepare", "bucket_sort", "bucket_accumulate", "bucket_reduce", "pairing"]
 
     def kernel_times(run, mode, k_steps):
@@ -396,18 +396,22 @@ def main():
                     acc[nm] += v
                 span += tm.total_ms
                 info = {"msm_terms": tm.msm_terms, "window_bits": tm.window_bits, "windows_per_glv_half": tm.windows, "max_entries_per_lane": tm.max_chain}
-            return {k: v / k_steps for k, v in acc.items()}, span / k_steps, dict(launches=1, msm_lpt=0, pair_lanes=64, rlc_shape=info, all_batch_ok=all_ok)
+            return {k: v / k_steps for k, v in acc.items()}, span / k_steps, dict(launches=1, msm_lpt=0, pair_lanes=64, rlc_shape=info, all_batch_ok=all_ok, var_lpt=0)
         acc = {k: 0.0 for k in PP_KEYS}
-        span, launches, msm_lpt, pair_lanes = 0.0, 1, 2, 32
+        span, launches, msm_lpt, pair_lanes, var_lpt = 0.0, 1, 2, 32, 0
         for j in range(k_steps):
             tm = run.timings(j)
             launches = max(1, tm.launches)
             msm_lpt = tm.msm_lanes_per_term or 2
+            var_lpt = tm.msm_var_lanes_per_term
             pair_lanes = tm.pairing_lanes_per_proof or 32
-            for nm, v in zip(PP_KEYS, [tm.transcript_combiner_ms, tm.g1_decompress_ms, tm.g1_msm_ms, tm.pairing_ms]):
+            for nm, v in zip(PP_KEYS, [tm.transcript_combiner_ms, tm.g1_decompress_ms, tm.g1_msm_ms, tm.g1_msm_fixed_ms, tm.pairing_ms]):
                 acc[nm] += v
             span += tm.total_ms
-        return {k: v / k_steps for k, v in acc.items()}, span / k_steps, dict(launches=launches, msm_lpt=msm_lpt, pair_lanes=pair_lanes, rlc_shape=None, all_batch_ok=None)
+        if msm_lpt != 3:
+            acc.pop("g1_msm_fixed")     # (one MSM kernel: no fixed-base launch beside it)
+        return {k: v / k_steps for k, v in acc.items()}, span / k_steps, dict(launches=launches, msm_lpt=msm_lpt, pair_lanes=pair_lanes, rlc_shape=None,
+                                                                                all_batch_ok=None, var_lpt=var_lpt)
 
     gather_state = {"ok": None}
     if args.timed_only:
@@ -424,6 +428,7 @@ def main():
     k_steps = min(args.steps, 48)
     kernel_ms_overlapped, batch_latency_ms, shape = kernel_times(run, args.mode, k_steps)
     launches, msm_lpt, pair_lanes, rlc_shape, all_batch_ok = shape["launches"], shape["msm_lpt"], shape["pair_lanes"], shape["rlc_shape"], shape["all_batch_ok"]
+    var_lpt = shape["var_lpt"]
     steps_ok = run.all_steps_ok
     run.close()
     # The kernels' OWN durations: with several steps in flight the event-timed durations above include what the kernels lose
@@ -440,7 +445,12 @@ def main():
         alone = {"ms_per_step": r1.el / 6 * 1e3, "msm_lpt": shape1["msm_lpt"], "pair_lanes": shape1["pair_lanes"]}
         if shape1["msm_lpt"] != msm_lpt or shape1["pair_lanes"] != pair_lanes:
             alone["note"] = "launch shapes differ from the timed run's"
-        msm_lpt, pair_lanes = shape1["msm_lpt"], shape1["pair_lanes"]
+        msm_lpt, pair_lanes, var_lpt = shape1["msm_lpt"], shape1["pair_lanes"], shape1["var_lpt"]
+        for k_ in list(kernel_ms_overlapped):      # (same kernels in both passes)
+            if k_ not in kernel_ms:
+                kernel_ms_overlapped.pop(k_)
+        for k_ in kernel_ms:
+            kernel_ms_overlapped.setdefault(k_, 0.0)
         r1.close()
     else:
         kernel_ms = kernel_ms_overlapped
@@ -521,38 +531,46 @@ def main():
             }
             msm_key = "bucket_accumulate"
         else:
-            tpl = msm_lpt - 16 if msm_lpt in (18, 19, 20) else 1     # several terms per lane (H2V_MSM_TPL): shared doublings
-            quad = msm_lpt if msm_lpt == 8 else 0                # a quad per GLV half (small launches of few terms)
+            # msm_lpt == 3: the MSM ran as TWO kernels - ladders over the n_var per-proof terms (shape var_lpt) and, beside
+            # them, the fixed-base kernel over the n_fix VK-base terms (65 mixed additions per base, no doubling)
+            split = msm_lpt == 3
+            shape = var_lpt if split else msm_lpt
+            T_lad = T - n_fix_terms if split else T
+            tpl = shape - 16 if shape in (18, 19, 20) else 1     # several terms per lane (shared doublings)
+            quad = shape if shape == 8 else 0                    # a quad per GLV half (small launches of few terms)
 
             def shape_names(lpt_code, lanes):   # the kernels behind the launcher's reported shapes
-                return {"g1_msm": {18: "k_g1_msm_multi2", 19: "k_g1_msm_multi3", 20: "k_g1_msm_multi4", 3: "k_g1_msm_fixed", 1: "k_g1_msm_merged", 8: "k_g1_msm_quad"}.get(lpt_code, "k_g1_msm"),
+                return {"g1_msm": {18: "k_g1_msm_multi2", 19: "k_g1_msm_multi3", 20: "k_g1_msm_multi4", 1: "k_g1_msm_merged", 8: "k_g1_msm_quad"}.get(lpt_code, "k_g1_msm"),
+                        "g1_msm_fixed": "k_g1_msm_fixed",
                         "g1_decompress": dec_name, "transcript_combiner": vm_name,
                         "pairing": {16: "k_pairing_coop_narrow", 64: "k_pairing_coop_wide", 1: "k_pairing_check"}.get(lanes, "k_pairing_coop")}
-            kname = shape_names(msm_lpt, pair_lanes)
+            kname = shape_names(shape, pair_lanes)
             # lanes per coefficient 1 / 2 / 4 (narrow / normal / wide engine): a lane multiplies 1/nq of a coefficient's terms and reduces once
             nq = {16: 1, 64: 4}.get(pair_lanes, 2)
             pairing_lane = sum(calls * ((terms // nq) * 196 + 196) for calls, terms in ((35, 12), (63, 8), (315, 4), (136, 6)))
             bytes_per_launch = {
-                "g1_msm": B * (128 * T + 144),
+                "g1_msm": B * (128 * T_lad + 144),
+                "g1_msm_fixed": B * (128 * n_fix_terms + 144),
                 "g1_decompress": B * slots * (48 + 96 + 1),
                 "transcript_combiner": B * (pl.proof_len + 32 * pl.n_pi + 48 * pl.n_ci + 32 * T + 4),
                 "pairing": B * (96 + 144 + 1 + 4) + 2 * 68 * 192,
             }
-            # per MSM lane: 32 windows of 4 doublings + one mixed addition per GLV half the lane carries (tables are built
+            # per ladder lane: 32 windows of 4 doublings + one mixed addition per GLV half the lane carries (tables are built
             # ahead); the launcher reports whether a term ran on two lanes (one half each) or on one (both halves)
-            msm_fixed = msm_lpt == 3   # fixed-base mode: VK-base terms cost 65 mixed additions and no doubling
-            lpt = 1 if (msm_fixed or tpl > 1) else 2 if quad == 8 else msm_lpt
+            lpt = 1 if tpl > 1 else 2 if quad == 8 else (shape if shape in (1, 2) else 2)
             msm_halves = 2 // lpt
             msm_lane = 128 * MAD_DBL + (32 * msm_halves - 1) * MAD_MADD
             mads = {
-                "g1_msm": (B * (T - n_fix_terms) * msm_lane + B * n_fix_terms * 65 * MAD_MADD + B * (T - 1) * MAD_ADD + B * 3 * MAD_MUL) if msm_fixed
-                          else (B * -(-T // tpl) * 128 * MAD_DBL + B * T * 66 * MAD_MADD + B * (-(-T // tpl) - 1) * MAD_ADD + B * 3 * MAD_MUL) if tpl > 1
-                          else (B * T * 8 * 33 * 18 * MAD_MUL + B * (lpt * T - 1) * MAD_ADD + B * 3 * MAD_MUL) if quad  # every lane of a quad runs each level's multiplication
-                          else B * T * lpt * msm_lane + B * (lpt * T - 1) * MAD_ADD + B * 3 * MAD_MUL,
+                "g1_msm": (B * -(-T_lad // tpl) * 128 * MAD_DBL + B * T_lad * 66 * MAD_MADD + B * (-(-T_lad // tpl) - 1) * MAD_ADD + B * 3 * MAD_MUL) if tpl > 1
+                          else (B * T_lad * 8 * 33 * 18 * MAD_MUL + B * (lpt * T_lad - 1) * MAD_ADD + B * 3 * MAD_MUL) if quad  # every lane of a quad runs each level's multiplication
+                          else B * T_lad * lpt * msm_lane + B * (lpt * T_lad - 1) * MAD_ADD + B * 3 * MAD_MUL,
+                "g1_msm_fixed": B * n_fix_terms * 65 * MAD_MADD + B * n_fix_terms * MAD_ADD,
                 "pairing": B * (1 if pair_lanes == 1 else pair_lanes) * pairing_lane,
                 "g1_decompress": B * slots * (377 * MAD_SQR + 86 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD + tab_point),
                 "transcript_combiner": B * sum(128 for ins in pl.instrs if ins[0] == PL.OP_MUL),
             }
+            if not split:
+                bytes_per_launch.pop("g1_msm_fixed"); mads.pop("g1_msm_fixed")
             msm_key = "g1_msm"
 
         def roof(k):
@@ -585,8 +603,7 @@ def main():
             # headline).  The small shares (64-128 proofs) are chains of lone waves: six of them in flight finish a step in
             # less time than one kernel's own chain takes, and the line says so instead (roofline.duration_fits_in_step)
             fits = kernel_ms[dominant] / launches <= elapsed / args.steps * 1e3 * 1.05
-            # (a forced fixed-base split reports the SPAN of its two concurrent MSM launches: not a kernel's own duration)
-            assert fits or not alone or B < 2048 or msm_lpt == 3, (kernel_ms, elapsed / args.steps * 1e3)
+            assert fits or not alone or B < 2048, (kernel_ms, elapsed / args.steps * 1e3)
         result = {
             "metric": "halo2_proofs_verified_per_sec",
             "value": round(B_total * args.steps / elapsed, 2),
@@ -610,6 +627,7 @@ def main():
                            args.scaling, "RCCL" if args.dist_backend == "nccl" else "gloo (rehearsal)")) if world > 1 else "1 GPU"},
             "roofline": roof(dominant),
             "msm_roofline": roof(msm_key),
+            "msm_fixed_roofline": roof("g1_msm_fixed") if "g1_msm_fixed" in kernel_ms else None,
             "int_roofline": int_roof(dominant),
             "msm_int_roofline": int_roof(msm_key),
             "kernel_ms": {kname[k]: round(v, 4) for k, v in kernel_ms.items()},
@@ -620,7 +638,7 @@ def main():
                                   "achieved": round(sum(mads.values()) / (elapsed / args.steps) / 1e12, 3), "peak": round(IMAD_PEAK_TOPS, 2) if IMAD_PEAK_TOPS else None,
                                   "unit": "T lane-mad/s", "frac": round(sum(mads.values()) / (elapsed / args.steps) / 1e12 / IMAD_PEAK_TOPS, 4) if IMAD_PEAK_TOPS else None},
             "batch_latency_ms": round(batch_latency_ms, 4),
-            "pipelines_per_step": launches, "msm_lanes_per_term": msm_lpt, "pairing_lanes_per_proof": pair_lanes if args.mode == "per-proof" else None,
+            "pipelines_per_step": launches, "msm_lanes_per_term": msm_lpt, "msm_ladder_shape_of_a_split": var_lpt if msm_lpt == 3 else None, "pairing_lanes_per_proof": pair_lanes if args.mode == "per-proof" else None,
             "all_accepted": ok_all if timed_expected is None else None,
             "verdicts_as_expected_every_checked_step": ok_all,
             "gathered_accept_vectors_all_ones": gather_state["ok"],

@@ -71,6 +71,11 @@ typedef struct {
     uint32_t msm_lanes_per_term;
     uint32_t pairing_lanes_per_proof;   /* 32: two proofs per wave; 64: the wide engine (small launches); 16: the narrow one (four
                                          * proofs per wave: fewest instructions, for full chips); 1: the one-lane cross-check kernel */
+    /* (round 3) msm_lanes_per_term == 3: the MSM ran as TWO kernels side by side - g1_msm_ms is the ladder launch over the
+     * per-proof terms (its shape: msm_var_lanes_per_term, coded like msm_lanes_per_term), g1_msm_fixed_ms the fixed-base
+     * launch over the VK-base terms; 0 otherwise */
+    float g1_msm_fixed_ms;
+    uint32_t msm_var_lanes_per_term;
 } h2v_timings;
 
 /* ---- plan (VerifyingKey) lifecycle -------------------------------------------------------------------------

@@ -28,7 +28,8 @@ class Batch(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("transcript_combiner_ms", C.c_float), ("g1_decompress_ms", C.c_float), ("g1_msm_ms", C.c_float),
                 ("pairing_ms", C.c_float), ("total_ms", C.c_float), ("launches", C.c_uint32),
-                ("msm_lanes_per_term", C.c_uint32), ("pairing_lanes_per_proof", C.c_uint32)]
+                ("msm_lanes_per_term", C.c_uint32), ("pairing_lanes_per_proof", C.c_uint32),
+                ("g1_msm_fixed_ms", C.c_float), ("msm_var_lanes_per_term", C.c_uint32)]
 
 
 class RlcOpts(C.Structure):

@@ -109,9 +109,9 @@ struct h2v_workspace {
     // ring of per-call, per-chunk event sets: [0]/[1] around the transcript+combiner kernel, [2]/[3] around the
     // decompression kernel's square-root half (side stream), [4]/[5] around the MSM, [5]/[6] around the pairing kernel,
     // [7]/[8] around the decompression kernel's subgroup half (third stream)
-    static constexpr int RING = 64, NEV = 9;
+    static constexpr int RING = 64, NEV = 12;   // (+ [9]/[10] around the fixed-base MSM launch, [11] the end of the ladder launch beside it)
     hipEvent_t ring[RING][MAXP][NEV] = {};
-    uint8_t ring_pipes[RING] = {}, ring_split[RING] = {}, ring_lpt[RING] = {}, ring_pair[RING] = {};
+    uint8_t ring_pipes[RING] = {}, ring_split[RING] = {}, ring_lpt[RING] = {}, ring_pair[RING] = {}, ring_var[RING] = {};
     uint64_t calls = 0;
     struct RlcWs *rlc = nullptr;   // buffers of the RLC batch mode, created by its first call
     int opt_msm_tpl = 0, opt_pairing = 0;   // h2v_workspace_set_option: 0 = the launcher's choice
@@ -819,15 +819,21 @@ static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint
 // pair up on SIMDs even when there would be room for all of them alone.  So the rule is: split (one base per lane) only
 // when the single launch cannot have one wave per SIMD and most terms are VK bases.  H2V_MSM_FIX = k forces a split with k bases per lane, 0 forbids it.
 struct MsmSplit { bool on; MsmShape var, fix; uint32_t k; };
-static MsmSplit msm_split_shape(const H2vDevPlan &d, uint32_t n, const MsmShape &single) {
+static MsmSplit msm_split_shape(const H2vDevPlan &d, uint32_t n, const MsmShape &single, uint32_t in_flight_hint = 1) {
     static const int env_fix = []() { const char *e = getenv("H2V_MSM_FIX"); return e ? atoi(e) : -1; }();
     static const uint32_t env_bs = []() { const char *e = getenv("H2V_MSM_BS"); return e ? (uint32_t)atoi(e) : 0u; }();
     MsmSplit out = {false, {}, {}, 0};
     if (!d.fix_tab || !d.n_fix || !d.n_var || d.ivc || env_fix == 0) return out;
     // (and only when the VK bases are the majority of the terms: with 9 of 34 the MSM gained 0.8 ms and the pairing kernel
     // that followed the three launches lost as much of its own placement; with 6 of 16 at 8192 proofs the split was slower)
-    if (env_fix < 0 && (single.waves <= msm_n_simd() || d.n_fix < d.n_var)) return out;
-    const uint32_t k = env_fix > 0 ? (uint32_t)(env_fix > 4 ? 4 : env_fix) : 1u;
+    // A caller that keeps the chip full (hint >= 4: the lanes) is bound by the instructions issued: the VK-base terms then
+    // ALWAYS go through the all-window tables, two bases per lane (65 mixed additions each and no doubling, where a ladder
+    // lane shares 128 doublings between two terms) - measured with six batches in flight, ms per batch: simple_mul x 4096
+    // 4.39 -> 4.30, sha256 shape x 1024 2.67 -> 2.56, atms x 2048 4.43 -> 4.21, lookup_table x 2048 and secp256k1 x 512
+    // unchanged (+-1 %); launches below a quarter of a wave per SIMD keep the single ladder launch (sha256 x 128: 1.17 -> 1.26).
+    const bool in_flight = in_flight_hint >= 4 && d.n_fix >= 2 && (double)n * d.n_main_terms / 64.0 >= msm_n_simd() / 4.0;
+    if (env_fix < 0 && !in_flight && (single.waves <= msm_n_simd() || d.n_fix < d.n_var)) return out;
+    const uint32_t k = env_fix > 0 ? (uint32_t)(env_fix > 4 ? 4 : env_fix) : in_flight ? 2u : 1u;
     const uint32_t lanes = (d.n_fix + k - 1) / k;
     MsmShape fx = {1, 512, 1e300, 0};
     msm_try_shape(fx, 1, lanes, k * 800.0, n, 0.0, env_bs);
@@ -1027,7 +1033,7 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
                             d.ivc ? w->fold_pts + (size_t)lo * 96 : nullptr, d.ivc ? w->fold_scal + (size_t)lo * 32 : nullptr,
                             d.ivc ? w->el2 + (size_t)lo * 36 : nullptr, d.ivc ? w->er2 + (size_t)lo * 36 : nullptr};
         const MsmShape single = msm_ladder_shape(d.ivc ? d.n_terms : d.n_main_terms, m, 0.0, true);
-        const MsmSplit split = w->er_fix ? msm_split_shape(d, m, single) : MsmSplit{false, {}, {}, 0};
+        const MsmSplit split = w->er_fix ? msm_split_shape(d, m, single, w->in_flight_hint) : MsmSplit{false, {}, {}, 0};
         if (split.on) {
             // per-proof terms as ladders on the main stream; the VK-base terms beside them on the side stream (free since
             // the square roots finished), which first waits for the combiner's scalars; a one-lane-per-proof kernel adds
@@ -1038,10 +1044,16 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
                              d.fix_tab, split.k, (d.n_fix + split.k - 1) / split.k};
             HIPCHK(hipStreamWaitEvent(ps, ev[1], 0));
             const uint32_t pbf = split.fix.bs / mf.n_fixl;
+            HIPCHK(hipEventRecord(ev[9], ps));
             hipLaunchKernelGGL(k_g1_msm_fixed, dim3((m + pbf - 1) / pbf), dim3(split.fix.bs), (size_t)split.fix.bs * 172, ps, d, mf, m, pbf, scal_k, pts_k, (uint32_t *)nullptr);
+            HIPCHK(hipEventRecord(ev[10], ps));
             HIPCHK(hipEventRecord(w->ev_fix[k], ps));
-            if (msm_terms_per_lane(w->in_flight_hint) > 1) (void)launch_msm_range(d, mv, m, scal_k, pts_k, nullptr, pm, w->in_flight_hint);   // (several terms per lane)
-            else (void)launch_msm_ladders(d, mv, m, split.var, scal_k, pts_k, nullptr, pm);
+            if (ps == pm) HIPCHK(hipEventRecord(ev[4], pm));   // (one stream: the ladder launch starts behind the fixed-base one)
+            uint32_t var_code;
+            if (msm_terms_per_lane(w->in_flight_hint) > 1) var_code = launch_msm_range(d, mv, m, scal_k, pts_k, nullptr, pm, w->in_flight_hint);   // (several terms per lane)
+            else var_code = launch_msm_ladders(d, mv, m, split.var, scal_k, pts_k, nullptr, pm);
+            HIPCHK(hipEventRecord(ev[11], pm));
+            w->ring_var[slot] = (uint8_t)var_code;
             HIPCHK(hipStreamWaitEvent(pm, w->ev_fix[k], 0));
             hipLaunchKernelGGL(k_g1_sum_pairs, dim3((m + 63) / 64), dim3(64), 0, pm, m, er_k, erf_k);
             w->ring_lpt[slot] = 3;
@@ -1185,7 +1197,8 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
             int rc = h2v_workspace_timings(lw, (uint32_t)(lw->calls - 1 - idx), &t1);
             if (rc) return rc;
             tm->transcript_combiner_ms += t1.transcript_combiner_ms; tm->g1_decompress_ms += t1.g1_decompress_ms;
-            tm->g1_msm_ms += t1.g1_msm_ms; tm->pairing_ms += t1.pairing_ms;
+            tm->g1_msm_ms += t1.g1_msm_ms; tm->pairing_ms += t1.pairing_ms; tm->g1_msm_fixed_ms += t1.g1_msm_fixed_ms;
+            tm->msm_var_lanes_per_term = t1.msm_var_lanes_per_term;
             tm->msm_lanes_per_term = t1.msm_lanes_per_term; tm->pairing_lanes_per_proof = t1.pairing_lanes_per_proof;
             hipEvent_t *ev = lw->ring[idx % h2v_workspace::RING][0];
             if (!first) first = ev[2];
@@ -1219,7 +1232,17 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
             HIPCHK(hipEventElapsedTime(&b2, ev[7], ev[8]));
             if (b2 > b) b = b2;
         }
-        HIPCHK(hipEventElapsedTime(&c, ev[4], ev[5]));
+        if (w->ring_lpt[slot] == 3) {
+            // split MSM: the ladder launch over the per-proof terms ([4] .. [11]) and, beside it on another stream, the
+            // fixed-base launch over the VK-base terms ([9] .. [10]) - two kernels, two durations
+            float fx;
+            HIPCHK(hipEventElapsedTime(&c, ev[4], ev[11]));
+            HIPCHK(hipEventElapsedTime(&fx, ev[9], ev[10]));
+            tm->g1_msm_fixed_ms += fx;
+            tm->msm_var_lanes_per_term = w->ring_var[slot];
+        } else {
+            HIPCHK(hipEventElapsedTime(&c, ev[4], ev[5]));
+        }
         HIPCHK(hipEventElapsedTime(&e, ev[5], ev[6]));
         tm->transcript_combiner_ms += a; tm->g1_decompress_ms += b; tm->g1_msm_ms += c; tm->pairing_ms += e;
         if (k > 0) { HIPCHK(hipEventElapsedTime(&t0, w->ring[slot][0][2], ev[2])); }

@@ -240,14 +240,18 @@ def test_in_flight_hint_changes_the_shape_not_the_verdicts(be, circuits):
         with pytest.raises(be.H2VError):
             ws5.hint_in_flight(0)
         ws1.close(); ws5.close(); ws8.close()
-    # from a quarter of a wave per SIMD up (simple_mul: 1024 proofs x 16 terms = 256 waves) the hint selects two terms per lane
+    # from a quarter of a wave per SIMD up (simple_mul: 1024 proofs x 16 terms = 256 waves) the hint selects the split MSM, and
+    # its ladder launch (10 per-proof terms: 2048 proofs for the same quarter) runs two terms per lane
     vk, td, pl, dp, ov = circuits["simple_mul"]
-    batch = synth.forge_batch(vk, td, 1024, seed=65, plan=pl, workers=8)
+    batch = synth.forge_batch(vk, td, 2048, seed=65, plan=pl, workers=8)
     batch = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.05, seed=66, kinds=list(synth.CORRUPTIONS))
-    ws = be.Workspace(dp, 1024)
+    ws = be.Workspace(dp, 2048)
     ws.hint_in_flight(5)
     assert list(dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws)) == batch.expected
-    assert ws.timings().msm_lanes_per_term == 18
+    # (two kernels side by side for a caller that keeps the chip full: two-terms-per-lane ladders over the per-proof terms,
+    #  the fixed-base kernel over the VK bases)
+    tm = ws.timings()
+    assert tm.msm_lanes_per_term == 3 and tm.msm_var_lanes_per_term == 18 and tm.g1_msm_fixed_ms > 0
     ws.close()
     # the split launch (per-proof terms two per lane beside the fixed-base lanes) needs a batch that does not fit one wave per SIMD
     vk, td, pl, dp, ov = circuits["atms_with_lookups"]
