@@ -361,12 +361,24 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
         bool tail_ok = nv < n_terms;
         for (uint32_t k = nv; k < n_terms; k++) tail_ok = tail_ok && rd32(patched.data() + w[H2V_HW_OFF_TERMS] + 8 * k) == H2V_TERM_VK_BASE;
         if (tail_ok) {
-            const size_t fix_bytes = (size_t)n_bases * 65 * 224 * 4;
-            bool okf = hipMalloc(&p->fix_tab, fix_bytes + 16) == hipSuccess && hipMemset(p->fix_tab, 0, fix_bytes + 16) == hipSuccess;
+            // window width of the tables: 12 bits (22 additions per VK term in every proof, 5 MB per base) unless that would
+            // take more than 2 GB; H2V_FIX_C = 4 / 8 / 12 forces it (tests run all three)
+            static const int env_c = []() { const char *e = getenv("H2V_FIX_C"); return e ? atoi(e) : 0; }();
+            uint32_t fc = (size_t)n_bases * 22 * 2048 * 112 <= ((size_t)2 << 30) ? 12u : 8u;
+            if (env_c == 4 || env_c == 8 || env_c == 12) fc = (uint32_t)env_c;
+            const uint32_t fW = fc == 4 ? 65u : fc == 8 ? 33u : 22u, fE = 1u << (fc - 1);
+            const size_t fix_bytes = (size_t)n_bases * fW * fE * 28 * 4;
+            void *wbase = nullptr;
+            bool okf = hipMalloc(&p->fix_tab, fix_bytes + 16) == hipSuccess && hipMemset(p->fix_tab, 0, fix_bytes + 16) == hipSuccess &&
+                       hipMalloc(&wbase, (size_t)n_bases * fW * 96 + 16) == hipSuccess;
             if (okf) {
-                hipLaunchKernelGGL(k_vk_fixed_tables, dim3((n_bases * 65 + 63) / 64), dim3(64), 0, nullptr, d.vk_bases, n_bases, (uint32_t *)p->fix_tab);
+                hipLaunchKernelGGL(k_vk_fixed_window_bases, dim3((n_bases * fW + 63) / 64), dim3(64), 0, nullptr, d.vk_bases, n_bases, fc, fW, (uint32_t *)wbase);
+                const uint64_t entries = (uint64_t)n_bases * fW * fE;
+                hipLaunchKernelGGL(k_vk_fixed_tables, dim3((uint32_t)((entries + 63) / 64)), dim3(64), 0, nullptr, (const uint32_t *)wbase, n_bases * fW, fc, (uint32_t *)p->fix_tab);
                 okf = hipDeviceSynchronize() == hipSuccess;
             }
+            if (wbase) (void)hipFree(wbase);
+            d.fix_c = fc; d.fix_W = fW;
             if (!okf) {
                 if (p->fix_tab) (void)hipFree(p->fix_tab);
                 (void)hipFree(p->vk_tab);

@@ -659,10 +659,11 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
     bool lad_inf = true;
     if (FIX && active && fix_lane) {
         // The accumulator of one base is [a]V with a = the signed-digit prefix read so far (most significant window first),
-        // a multiple of 16^(w+1); adding [d 16^w]V is exceptional iff a -+ d 16^w = 0 mod r.  As integers |a -+ d 16^w| <
-        // 2^257, so that means a -+ d 16^w in {0, +-r, +-2r}: 0 is excluded by the digits' size unless a = d = 0, and
-        // r, 2r are not = -+d 16^w modulo 16^(w+1) except for w = 0, where a + d_0 would be the whole scalar = r or 2r,
-        // not a canonical one.  So the 65 additions of a base are unchecked; sums of different bases meet in complete ones.
+        // a multiple of B^(w+1), B = 2^c; adding [d B^w]V is exceptional iff a -+ d B^w = 0 mod r.  As integers |a -+ d B^w| <
+        // 2^265, so that means a -+ d B^w = m r with |m| small: 0 is excluded by the digits' size (|d| <= B/2 < B) unless
+        // a = d = 0, and m r is not = -+d B^w modulo B^(w+1) for w > 0 (r is odd: m r = 0 mod B^w needs B^w | m), while for
+        // w = 0 a + d_0 is the whole scalar, which is canonical (< r) and not 0 here.  So the additions of a base are
+        // unchecked (c = 4: 65, c = 8: 33, c = 12: 22 of them); sums of different bases meet in complete ones.
         const uint32_t f0 = sub * ma.fix_k;
 #pragma unroll 1
         for (uint32_t j = 0; j < ma.fix_k; j++) {
@@ -677,23 +678,28 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
 #pragma unroll
             for (int k = 0; k < 8; k++) { sc[k] = sp[k]; any_s |= sc[k]; }
             if (any_b == 0 || any_s == 0) continue;
-            int8_t dg[65];
+            // signed c-bit digits, least significant first (c = plan.fix_c: 4, 8 or 12; W windows; the last window takes the
+            // carry: for c = 4 / 8 it is a window of its own, for c = 12 the top window holds 4 bits and has the room)
+            const uint32_t c = plan.fix_c, W = plan.fix_W, E = 1u << (c - 1), mask = (1u << c) - 1u;
+            int16_t dg[65];
             uint32_t carry = 0;
 #pragma unroll 1
-            for (int q = 0; q < 64; q++) {
-                uint32_t d = ((sc[q >> 3] >> (4 * (q & 7))) & 15u) + carry;
-                carry = d > 8 ? 1u : 0u;
-                dg[q] = (int8_t)(carry ? (int)d - 16 : (int)d);
+            for (uint32_t q = 0; q < W; q++) {
+                const uint32_t bit = q * c, word = bit >> 5, sh = bit & 31;
+                uint64_t two = 0;
+                if (word < 8) two = (uint64_t)sc[word] | (word + 1 < 8 ? (uint64_t)sc[word + 1] << 32 : 0ull);
+                uint32_t d = ((uint32_t)(two >> sh) & mask) + carry;
+                carry = d > E ? 1u : 0u;
+                dg[q] = (int16_t)(carry ? (int)d - (int)(mask + 1u) : (int)d);
             }
-            dg[64] = (int8_t)carry;
             G1J28 acc;
             bool acc_inf = true;
-            const uint32_t *tabb = ma.fix_tab + (size_t)idx * 65 * 224;
+            const uint32_t *tabb = ma.fix_tab + (size_t)idx * W * E * 28;
 #pragma unroll 1
-            for (int q = 64; q >= 0; q--) {
+            for (int q = (int)W - 1; q >= 0; q--) {
                 const int d = dg[q];
                 if (d == 0) continue;
-                const uint32_t *ent = tabb + q * 224 + ((d < 0 ? -d : d) - 1) * 28;
+                const uint32_t *ent = tabb + ((size_t)q * E + (uint32_t)((d < 0 ? -d : d) - 1)) * 28;
                 F28 qx, qy;
 #pragma unroll
                 for (int k = 0; k < 14; k++) { qx.l[k] = ent[k]; qy.l[k] = ent[14 + k]; }
@@ -1324,26 +1330,64 @@ k_vk_tables(const uint32_t *__restrict__ vk_bases, uint32_t n, uint32_t *__restr
     g1_build_window_tables_glv(vk_tab + (size_t)b * 448, base);
 }
 
-// all-window tables of the VK bases for the fixed-base MSM lanes: thread (b, w) writes [1..8] (16^w V_b), affine, at
-// fix_tab[(b * 65 + w) * 224 ...] (w = 64 serves the carry digit of the recoding)
+// All-window tables of the VK bases for the fixed-base MSM lanes, window width c (4, 8, 12): for every base b and window w
+// the multiples [e + 1] (2^(c w) V_b), e = 0 .. 2^(c-1) - 1, affine, at fix_tab[((b W + w) 2^(c-1) + e) 28 ...].  Plan-load
+// work (once per key): the larger c is, the fewer additions a VK term costs in every proof (65 / 33 / 22 per base) - paid
+// for in HBM, which this part has (c = 12: 5 MB per base).  Two launches: the window bases 2^(c w) V_b (one lane per
+// (b, w): c w doublings), then one lane per table entry (double-and-add over the c - 1 bits of e + 1, one inversion).
 extern "C" __global__ void __launch_bounds__(64)
-k_vk_fixed_tables(const uint32_t *__restrict__ vk_bases, uint32_t n, uint32_t *__restrict__ fix_tab) {
+k_vk_fixed_window_bases(const uint32_t *__restrict__ vk_bases, uint32_t n, uint32_t c, uint32_t W, uint32_t *__restrict__ wbase /* [n][W][24] affine, Montgomery; all-zero = infinity */) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t b = t / 65, w = t - b * 65;
+    const uint32_t b = t / W, w = t - b * W;
     if (b >= n) return;
     G1A base;
 #pragma unroll
     for (int k = 0; k < 12; k++) { base.x.v[k] = vk_bases[(size_t)b * 24 + k]; base.y.v[k] = vk_bases[(size_t)b * 24 + 12 + k]; }
-    if (g1a_is_inf(base)) return;
+    uint32_t *dst = wbase + (size_t)t * 24;
+    if (g1a_is_inf(base)) {
+#pragma unroll
+        for (int k = 0; k < 24; k++) dst[k] = 0;
+        return;
+    }
     G1J28 p;
     g1j28_from_affine(p, base);
 #pragma unroll 1
-    for (uint32_t q = 0; q < 4 * w; q++) g1j28_dbl_ool(p, p);   // a point of prime order: never infinity
+    for (uint32_t q = 0; q < c * w; q++) g1j28_dbl_ool(p, p);   // a point of prime order: never infinity
     G1J pj;
     g1j28_to_g1j(pj, p, false);
     G1A aff;
     g1j_to_affine(aff, pj);
-    g1_build_window_table(fix_tab + ((size_t)b * 65 + w) * 224, aff);
+#pragma unroll
+    for (int k = 0; k < 12; k++) { dst[k] = aff.x.v[k]; dst[12 + k] = aff.y.v[k]; }
+}
+extern "C" __global__ void __launch_bounds__(64)
+k_vk_fixed_tables(const uint32_t *__restrict__ wbase, uint32_t n_bw /* bases x windows */, uint32_t c, uint32_t *__restrict__ fix_tab) {
+    const uint32_t E = 1u << (c - 1);
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t bw = (uint32_t)(t / E), e = (uint32_t)(t - (uint64_t)bw * E);
+    if (bw >= n_bw) return;
+    G1A base;
+    const uint32_t *src = wbase + (size_t)bw * 24;
+#pragma unroll
+    for (int k = 0; k < 12; k++) { base.x.v[k] = src[k]; base.y.v[k] = src[12 + k]; }
+    if (g1a_is_inf(base)) return;             // (the MSM skips an infinite base before it looks at the table)
+    G1J28 p, acc;
+    g1j28_from_affine(p, base);
+    bool inf = true;
+    const uint32_t m = e + 1;                 // 1 .. 2^(c-1): up to c bits
+#pragma unroll 1
+    for (int bit = (int)c - 1; bit >= 0; bit--) {
+        if (!inf) g1j28_dbl_ool(acc, acc);
+        if ((m >> bit) & 1u) g1j28_acc_add(acc, inf, p, false);   // complete (m = 2: P + P)
+    }
+    G1J pj;
+    g1j28_to_g1j(pj, acc, inf);
+    G1A aff;
+    g1j_to_affine(aff, pj);
+    F28 x, y;
+    f28_from_fp(x, aff.x);
+    f28_from_fp(y, aff.y);
+    g1_store_table_entry(fix_tab + (size_t)t * 28, x, y);
 }
 
 // ============================================================================ primitive probes (parity tests)

@@ -79,6 +79,9 @@ struct H2vDevPlan {
     // the VK bases [base][65][8][28]; terms [0, n_var) are per-proof points, [n_var, n_var + n_fix) VK bases
     const uint32_t *fix_tab;
     uint32_t n_var, n_fix;
+    // window width of the all-window tables (4, 8 or 12 bits: signed digits, 2^(c-1) entries per window) and their number
+    // of windows W; layout fix_tab[base][W][2^(c-1)][28] (affine x, y: 2 x 14 limbs of 28 bits)
+    uint32_t fix_c, fix_W;
     // optional wide schedule of the program (0 lanes = none); host-side use only (launch_vm swaps it in)
     uint32_t wide_lanes, wide_n_regs, wide_n_instr;
     const H2vInstr *wide_instr;

@@ -693,12 +693,14 @@ def test_circuit_without_public_inputs(be):
 
 @pytest.mark.parametrize("env", [{"H2V_PIPES": "3"}, {"H2V_PAIRING": "legacy"}, {"H2V_DEBUG_SYNC": "1"},
                                  {"H2V_MSM_LPT": "1"}, {"H2V_MSM_LPT": "2", "H2V_MSM_BS": "256"}, {"H2V_SPLIT_DEC": "0"},
-                                 {"H2V_MSM_FIX": "1"}, {"H2V_MSM_FIX": "3"}, {"H2V_VM_WIDE": "1"}, {"H2V_VM_WIDE": "0"},
+                                 {"H2V_MSM_FIX": "1"}, {"H2V_MSM_FIX": "3"}, {"H2V_MSM_FIX": "2", "H2V_FIX_C": "4"},
+                                 {"H2V_MSM_FIX": "1", "H2V_FIX_C": "8"}, {"H2V_VM_WIDE": "1"}, {"H2V_VM_WIDE": "0"},
                                  {"H2V_DEC_QUEUE": "0"}, {"H2V_MSM_TPL": "2"}, {"H2V_MSM_TPL": "4"},
                                  {"H2V_PAIRING_WIDE": "0"}, {"H2V_VM_P": "8"}])
 def test_alternate_pipeline_modes(be, env, tmp_path):
     """The knobs of the pipeline (chunked sub-batches on several streams, the one-lane pairing kernel, the serialised
-    debug path, the MSM launch shape - one or two lanes per term, block size, fixed-base lanes for the VK bases - that the
+    debug path, the MSM launch shape - one or two lanes per term, block size, fixed-base lanes for the VK bases with
+    all-window tables of 12- (default), 8- or 4-bit windows - that the
     cost model would otherwise pick from the batch size, the unsplit decompression kernel, the narrow / wide schedule of
     the combiner) are read once per process, so each runs in a child process; same verdicts."""
     import os
