@@ -845,7 +845,7 @@ static MsmSplit msm_split_shape(const H2vDevPlan &d, uint32_t n, const MsmShape 
     // unchanged (+-1 %); launches below a quarter of a wave per SIMD keep the single ladder launch (sha256 x 128: 1.17 -> 1.26).
     const bool in_flight = in_flight_hint >= 4 && d.n_fix >= 2 && (double)n * d.n_main_terms / 64.0 >= msm_n_simd() / 4.0;
     if (env_fix < 0 && !in_flight && (single.waves <= msm_n_simd() || d.n_fix < d.n_var)) return out;
-    const uint32_t k = env_fix > 0 ? (uint32_t)(env_fix > 4 ? 4 : env_fix) : in_flight ? 2u : 1u;
+    const uint32_t k = env_fix > 0 ? (uint32_t)(env_fix > 4 ? 4 : env_fix) : in_flight ? (d.n_fix >= 16 ? 4u : 2u) : 1u;   // (bases per lane: +-1 % either way)
     const uint32_t lanes = (d.n_fix + k - 1) / k;
     MsmShape fx = {1, 512, 1e300, 0};
     msm_try_shape(fx, 1, lanes, k * 800.0, n, 0.0, env_bs);
