@@ -170,6 +170,12 @@ class Workspace {
     const VerifyingKey &vk() const { return vk_; }
     /// tuning hint (h2v_workspace_hint_in_flight): the caller keeps n batches in flight, one workspace each; never changes results
     void hint_in_flight(uint32_t n) { check(h2v_workspace_hint_in_flight(w_, n)); }
+    /// calls of n proofs the workspace keeps in flight before a call waits for a lane (h2v_workspace_depth)
+    uint32_t depth(uint64_t n, bool rlc = false) const {
+        uint32_t d = 1;
+        check(h2v_workspace_depth(w_, n, rlc ? 1 : 0, &d));
+        return d;
+    }
     void submit(const h2v_batch &batch, bool rlc = false) {
         check(h2v_verify_batch_submit(vk_.handle(), &batch, w_, rlc ? H2V_SUBMIT_RLC : 0u, nullptr));
         n_ = batch.n;

@@ -63,7 +63,7 @@ def _rlc_opts(seed, one_stream: bool = False):
 EXPORTS = [
     "h2v_plan_load", "h2v_plan_free", "h2v_plan_info", "h2v_plan_compile", "h2v_blob_free", "h2v_workspace_create", "h2v_workspace_free",
     "h2v_workspace_timings", "h2v_workspace_hint_in_flight", "h2v_workspace_create_lanes", "h2v_workspace_defer_joins",
-    "h2v_workspace_join", "h2v_workspace_lanes", "h2v_workspace_set_option",
+    "h2v_workspace_join", "h2v_workspace_lanes", "h2v_workspace_depth", "h2v_workspace_set_option",
     "h2v_verify_batch", "h2v_verify_batch_submit", "h2v_verify_batch_wait", "h2v_verify_batch_device", "h2v_verify_batch_rlc", "h2v_verify_batch_rlc_device",
     "h2v_workspace_rlc_result", "h2v_probe_g1_msm_pippenger", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
     "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_quad_madd", "h2v_probe_pairing", "h2v_probe_pairing_ex",
@@ -103,6 +103,7 @@ def lib():
         L.h2v_workspace_defer_joins.argtypes = [C.c_void_p, C.c_int]
         L.h2v_workspace_join.argtypes = [C.c_void_p, C.c_void_p]
         L.h2v_workspace_lanes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.h2v_workspace_depth.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint32)]
         L.h2v_workspace_set_option.argtypes = [C.c_void_p, C.c_uint32, C.c_int32]
         L.h2v_workspace_timings.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Timings)]
         L.h2v_verify_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
@@ -281,6 +282,12 @@ class Workspace:
         a, b = C.c_uint32(), C.c_uint32()
         check(lib().h2v_workspace_lanes(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def depth(self, n: int, rlc: bool = False) -> int:
+        """h2v_workspace_depth: calls of n proofs the workspace keeps in flight before a call waits for a lane"""
+        a = C.c_uint32()
+        check(lib().h2v_workspace_depth(self._h, n, 1 if rlc else 0, C.byref(a)))
+        return a.value
 
     OPT_MSM_TERMS_PER_LANE, OPT_PAIRING_ENGINE, OPT_STREAMS = 1, 2, 3
 

@@ -518,16 +518,18 @@ static uint32_t default_chunk(const H2vDevPlan &d) {
 // batch): per-proof mode, each lane's pipeline on the lane's stream with the decompression beside it on a side stream:
 // 4 lanes 4.60, 5: 4.35, 6: 4.31, 11: 4.72; everything on the lane's stream: 5: 4.64, 8: 4.26, 11: 4.43 (five caller-owned
 // workspaces on fifteen streams, round 2's bench: 4.50); RLC mode (one stream per lane): 8 lanes 1.65, 11: 1.54, 16: 1.47.
+// With the split MSM, the 12-bit fixed-base tables and the six-lane pairing engine the per-proof optimum moved to 8 lanes
+// (= the whole pool of 16 streams; 9 lanes share streams: 4.27): simple_mul x 4096 6: 3.88, 7: 3.86, 8: 3.76; atms x 2048
+// 3.92 -> 3.57; sha256 shape x 1024 2.36 -> 2.26, x 128 1.16 -> 0.93; secp256k1 shape x 64 1.08 -> 0.87 ms per batch.
 #define H2V_DEFAULT_LANES 16u
-#define H2V_PER_PROOF_LANES 6u
+#define H2V_PER_PROOF_LANES 8u
 static int ensure_lane(h2v_workspace *w, uint32_t l) {
     if (w->lane[l]) return H2V_OK;
     h2v_workspace *lw = nullptr;
     int rc = ws_create_for(w->lane_plan, w->device, w->chunk, false, &lw);
     if (rc) return rc;
     w->lane[l] = lw;
-    lw->one_stream_mode = 2;            // the pipeline on the lane's stream, the decompression beside it on one side stream
-    if (const char *e = getenv("H2V_LANE_ONE_STREAM")) lw->one_stream_mode = atoi(e);   // experiment knob, read per creation
+    lw->one_stream_mode = 2;            // (set per call: laned_depth)
     lw->in_flight_hint = w->in_flight_hint > w->n_lanes ? w->in_flight_hint : w->n_lanes;
     lw->opt_msm_tpl = w->opt_msm_tpl; lw->opt_pairing = w->opt_pairing;
     if (make_stream(&w->lane_st[l]) != hipSuccess || hipEventCreateWithFlags(&w->lane_ev[l], hipEventDisableTiming) != hipSuccess)
@@ -573,7 +575,7 @@ extern "C" int h2v_workspace_set_option(h2v_workspace *ws, uint32_t option, int3
         else if (option == H2V_OPT_STREAMS) w->one_stream_mode = value;
     };
     if (option == H2V_OPT_MSM_TERMS_PER_LANE) { if (value < 0 || value > 4) return fail(H2V_E_ARG, "terms per lane: 0 (auto) .. 4"); }
-    else if (option == H2V_OPT_PAIRING_ENGINE) { if (value != 0 && value != 1 && value != 16 && value != 32 && value != 64) return fail(H2V_E_ARG, "pairing engine: 0 (auto), 16, 32, 64 lanes per proof, or 1 (the one-lane cross-check kernel)"); }
+    else if (option == H2V_OPT_PAIRING_ENGINE) { if (value != 0 && value != 1 && value != 6 && value != 16 && value != 32 && value != 64) return fail(H2V_E_ARG, "pairing engine: 0 (auto), 6, 16, 32, 64 lanes per proof, or 1 (the one-lane cross-check kernel)"); }
     else if (option == H2V_OPT_STREAMS) { if (value < -1 || value > 2) return fail(H2V_E_ARG, "streams: -1 (auto), 0 (three), 1 (the caller's), 2 (the caller's + one for the decompression)"); }
     else return fail(H2V_E_ARG, "unknown option");
     apply(ws);
@@ -584,6 +586,12 @@ extern "C" int h2v_workspace_lanes(const h2v_workspace *ws, uint32_t *n_lanes, u
     if (!ws) return fail(H2V_E_ARG, "null argument");
     if (n_lanes) *n_lanes = ws->n_lanes ? ws->n_lanes : 1;
     if (chunk) *chunk = ws->n_lanes ? ws->chunk : (uint32_t)ws->cap;
+    return H2V_OK;
+}
+static uint32_t laned_depth(const h2v_workspace *w, uint64_t n, bool rlc, int *stream_mode);
+extern "C" int h2v_workspace_depth(const h2v_workspace *ws, uint64_t n, int rlc, uint32_t *batches_in_flight) {
+    if (!ws || !batches_in_flight) return fail(H2V_E_ARG, "null argument");
+    *batches_in_flight = ws->n_lanes ? laned_depth(ws, n, rlc != 0, nullptr) : 1;
     return H2V_OK;
 }
 extern "C" int h2v_workspace_defer_joins(h2v_workspace *ws, int defer) {
@@ -883,15 +891,20 @@ static void launch_ivc_fold(const H2vDevPlan &d, uint32_t n, const uint32_t *pts
 // kernel stays as a cross-check (H2V_PAIRING=legacy, or impl = 0 in the probe).
 static uint32_t launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
                                 const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st, const uint32_t *skip = nullptr,
-                                bool prefer_narrow = false, double wide_up_to = -1.0) {
+                                bool prefer_narrow = false, double wide_up_to = -1.0, bool prefer_six = false) {
     if (wide_up_to < 0) wide_up_to = msm_n_simd();
     // The WIDE engine (one proof per wave, four lanes per coefficient: 3 / 2 / 1 terms per lane and call instead of 6 / 4 / 2)
     // when even one wave per proof leaves SIMDs free: n <= #SIMDs.  Above that the two-proofs-per-wave kernel does less
     // total work.  H2V_PAIRING_WIDE = 0 / 1 forces the choice; the conditional (RLC fall-back) launch is never wide.
     static const int env_wide = []() { const char *e = getenv("H2V_PAIRING_WIDE"); return e ? atoi(e) : -1; }();
     static const int env_narrow = []() { const char *e = getenv("H2V_PAIRING_NARROW"); return e ? atoi(e) : -1; }();
-    // impl 2 / 3 (probe): the narrow / the wide kernel whatever n
-    if (impl == 1 && g_opts.pairing) impl = g_opts.pairing == 1 ? 0 : g_opts.pairing == 16 ? 2 : g_opts.pairing == 64 ? 3 : 4;   // 4: the two-proofs-per-wave engine
+    static const int env_six = []() { const char *e = getenv("H2V_PAIRING_SIX"); return e ? atoi(e) : -1; }();
+    // impl 2 / 3 / 5 (probe): the narrow / the wide / the six-lane kernel whatever n
+    if (impl == 1 && g_opts.pairing) impl = g_opts.pairing == 1 ? 0 : g_opts.pairing == 16 ? 2 : g_opts.pairing == 64 ? 3 : g_opts.pairing == 6 ? 5 : 4;   // 4: the two-proofs-per-wave engine
+    if (impl == 5 || (impl == 1 && !skip && (env_six > 0 || (env_six < 0 && prefer_six)))) {
+        hipLaunchKernelGGL(k_pairing_six, dim3((n + SIX_GROUPS - 1) / SIX_GROUPS), dim3(64), SIX_LDS_BYTES, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
+        return 6u;
+    }
     const bool wide = !skip && impl != 2 && impl != 4 && (impl == 3 || (env_wide >= 0 ? env_wide != 0 : (double)n <= wide_up_to));
     const bool narrow = !skip && !wide && impl != 4 && (impl == 2 || env_narrow > 0 || (env_narrow < 0 && prefer_narrow));
     if (impl == 0) { hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg); return 1; }
@@ -915,8 +928,13 @@ static uint32_t launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *
     // (the wide engine issues twice the instructions of the normal one: a caller that keeps the chip full takes it only up to
     // #SIMDs / 2 proofs - sha256 shape x 1024, four in flight: wide 3.18, normal 2.98, narrow 3.12 ms per step; secp256k1 x 512:
     // wide 2.37, normal 2.47, narrow 2.64)
+    // The SIX-lane engine (ten proofs per wave, h2v_pairing_six.hpp: a quarter fewer instructions per pairing than the narrow
+    // one, a chain almost twice as long) wherever a caller that keeps the chip full would take the narrow one
+    // from 4 * #SIMDs proofs up (410 waves; H2V_PAIRING_SIX = 0 / 1 forces the choice).  ms per step, narrow -> six: simple_mul x 4096
+    // 4.06 -> 3.88 with six batches in flight, 3.76 with eight; below that size its few long waves lose: lookup_table x 2048
+    // 3.48 -> 3.65, atms x 2048 3.92 -> 5.10.
     return launch_pairing_impl(impl, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, st, nullptr, prefer_narrow,
-                               in_flight_hint >= 4 ? S / 2.0 : S);
+                               in_flight_hint >= 4 ? S / 2.0 : S, in_flight_hint >= 4 && (double)n >= 4.0 * S);
 }
 
 // ---------------------------------------------------------------------------------------------- pipeline
@@ -1103,11 +1121,29 @@ static const uint32_t *rlc_flags_of(const h2v_workspace *w);
 // chunks drift apart by themselves (a decompression launch wants every SIMD, so the second one queues behind the first),
 // and an explicit stagger - chunk c waiting for phase 1 of chunk c - 1 - measured 10-20 % slower.  rlc: every chunk is
 // its own batch check.
+// How many lanes a call of n proofs cycles through, and (per-proof mode) the streams of a chunk.  Chunks that give the MSM
+// less than a quarter wave per SIMD are chains of lone waves - latency, not issue slots - and want as many of them in flight
+// as there are streams: every lane, each chunk on its lane's stream alone.  Larger chunks: H2V_PER_PROOF_LANES lanes, the
+// decompression on a side stream.  Measured (ms per batch; 8 lanes two streams each -> 16 lanes one stream each): secp256k1
+// shape x 64 0.87 -> 0.57, x 128 1.12 -> 0.74; sha256 shape x 128 0.94 -> 0.74, x 256 1.32 -> 1.18; sha256 x 512 1.64 -> 1.70
+// and up: worse.  An explicit lane count (h2v_workspace_create_lanes) is kept; H2V_OPT_STREAMS / H2V_LANE_ONE_STREAM force the streams.
+static uint32_t laned_depth(const h2v_workspace *w, uint64_t n, bool rlc, int *stream_mode) {
+    if (stream_mode) *stream_mode = 1;
+    if (rlc) return w->n_lanes;
+    const uint64_t m = n < w->chunk ? n : w->chunk;
+    const bool small = (double)m * w->lane_plan.n_terms / 64.0 <= msm_n_simd() / 4.0;
+    if (stream_mode) {
+        static const int env_mode = []() { const char *e = getenv("H2V_LANE_ONE_STREAM"); return e ? atoi(e) : -1; }();
+        *stream_mode = w->one_stream_mode >= 0 ? w->one_stream_mode : env_mode >= 0 ? env_mode : small ? 1 : 2;
+    }
+    return (small || w->lanes_per_proof >= w->n_lanes) ? w->n_lanes : w->lanes_per_proof;
+}
 static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
                      uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, bool rlc, const uint32_t *seed, bool force_join,
                      bool never_join = false) {
     const H2vDevPlan &d = p->d;
-    const uint32_t L = rlc ? w->n_lanes : (w->lanes_per_proof < w->n_lanes ? w->lanes_per_proof : w->n_lanes);
+    int stream_mode = 1;
+    const uint32_t L = laned_depth(w, n, rlc, &stream_mode);
     const uint32_t nch = (n + w->chunk - 1) / w->chunk;
     const int slot = (int)(w->calls % h2v_workspace::RING);
     w->calls++;
@@ -1130,6 +1166,7 @@ static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const
             lw->rlc_fail_ptr = w->rlc_fail + slot;
             rc = run_rlc(p, m, proofs, off + lo, inst_c, ci_c, accept + lo, status_out ? status_out + lo : nullptr, lw, ls, sd, true);
         } else {
+            lw->one_stream_mode = stream_mode;
             rc = run_pipeline(d, m, proofs, off + lo, inst_c, ci_c, accept + lo, status_out ? status_out + lo : nullptr, lw, ls, nullptr, false);
         }
         if (rc) { (void)hipStreamSynchronize(ls); return rc; }
@@ -1321,7 +1358,7 @@ extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, u
 // the lanes, and the downloads on `hs_down`, each behind the lanes its batch ran on.  h2v_verify_batch_wait collects the
 // OLDEST batch.
 static int submit_laned(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws, bool rlc, const uint32_t *seed) {
-    const uint32_t depth = rlc ? ws->n_lanes : (ws->lanes_per_proof < ws->n_lanes ? ws->lanes_per_proof : ws->n_lanes);
+    const uint32_t depth = laned_depth(ws, b->n, rlc, nullptr);
     if (ws->h_head - ws->h_tail >= depth || ws->h_head - ws->h_tail >= (uint64_t)h2v_workspace::MAXH)
         return fail(H2V_E_ARG, "as many batches in flight as this workspace has lanes: call h2v_verify_batch_wait first");
     if (!ws->hs_down) HIPCHK(make_stream(&ws->hs_down));

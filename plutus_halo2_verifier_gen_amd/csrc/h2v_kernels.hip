@@ -15,6 +15,7 @@
 #include "h2v_plan.h"
 #include "h2v_tower.hpp"
 #include "h2v_pairing_coop.hpp"
+#include "h2v_pairing_six.hpp"
 
 // ============================================================================ blake2b-256 (RFC 7693)
 __device__ static constexpr uint64_t B2_IV[8] = {

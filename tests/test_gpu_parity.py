@@ -179,7 +179,7 @@ def test_verdicts_do_not_depend_on_the_chunking(be, circuits, name):
     want = list(ov.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, threads=16))
     assert want == batch.expected and 0 < sum(want) < n
     plain = be.Workspace(dp, n)
-    assert plain.lanes() == (1, n)
+    assert plain.lanes() == (1, n) and plain.depth(n) == 1
     assert list(dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=plain)) == want
     plain.close()
     dev = torch.device("cuda", 0)
@@ -189,7 +189,7 @@ def test_verdicts_do_not_depend_on_the_chunking(be, circuits, name):
     ptr = lambda t: t.data_ptr() if t is not None else None
     for lanes, chunk in [(3, 64), (2, 100), (16, 7), (5, 203), (4, 1000), (3, 1)]:
         ws = be.Workspace(dp, n, lanes=lanes, chunk=chunk)
-        assert ws.lanes() == (lanes, min(chunk, n))
+        assert ws.lanes() == (lanes, min(chunk, n)) and ws.depth(n) == ws.depth(n, rlc=True) == lanes   # (an explicit lane count holds)
         assert list(dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws)) == want, (lanes, chunk)
         got, _fb = dp.verify_batch_rlc(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws, seed=bytes(range(32)))
         assert list(got) == want, (lanes, chunk, "rlc")
@@ -276,7 +276,7 @@ def test_workspace_options_change_the_shape_not_the_verdicts(be, circuits):
     ws = be.Workspace(dp, n)
     W = be.Workspace
     for tpl, lpt_code in ((1, None), (2, 18), (3, 19), (4, 20), (0, None)):
-        for engine in (16, 32, 64, 1, 0):
+        for engine in (6, 16, 32, 64, 1, 0):
             for streams in (0, 1, 2, -1):
                 ws.set_option(W.OPT_MSM_TERMS_PER_LANE, tpl)
                 ws.set_option(W.OPT_PAIRING_ENGINE, engine)
@@ -351,12 +351,12 @@ def test_pairing_cooperative_matches_one_lane_kernel(be, orc, circuits):
         p2.append(bls.g1_compress(sA))
     p1 += [bls.g1_compress(None), bls.g1_compress(bls.G1_GEN), bls.g1_compress(None)]
     p2 += [bls.g1_compress(None), bls.g1_compress(None), bls.g1_compress(bls.G1_GEN)]
-    for k in range(2):   # 14 pairs: the last wave of every engine has idle groups (two of four in the narrow one)
+    for k in range(2):   # 14 pairs: the last wave of every engine has idle groups (two of four in the narrow one, six of ten in the six-lane one)
         A = bls.g1_mul(bls.G1_GEN, rng.randrange(1, R))
         p1.append(bls.g1_compress(A))
         p2.append(bls.g1_compress(bls.g1_mul(A, td.s) if k == 0 else bls.g1_mul(A, td.s + 1)))
     acc0, dump0 = be.probe_pairing_ex(dp, p1, p2, impl=0)
-    for impl in (1, 2, 3):   # the launcher's choice (wide for 12 pairs), the narrow engine (16 lanes per proof), the wide one (64)
+    for impl in (1, 2, 3, 5):   # the launcher's choice (wide for 12 pairs), the narrow engine (16 lanes per proof), the wide one (64), six lanes per proof
         acc1, dump1 = be.probe_pairing_ex(dp, p1, p2, impl=impl)
         assert acc0 == acc1 == [1, 1, 0] * 3 + [1, 0, 0] + [1, 0], impl
         for i in range(len(p1)):
@@ -537,6 +537,16 @@ def test_full_size_batch_properties(be, circuits):
     assert list(got_p) == [got[i] for i in order]
     pre = _permute(batch, list(range(1000)), n_pi)
     assert list(dp.verify_batch(pre.proofs, pre.proof_off, pre.instances, pre.committed)) == list(got[:1000])
+    # the library's own laned workspace (what h2v_workspace_create returns from four chunks up): the lanes a call cycles through
+    # depend on the chunk it gives the kernels - eight for whole chunks, all sixteen for small ones and for the RLC mode - and the
+    # verdicts on neither
+    lw = be.Workspace(dp, 4 * n)
+    assert lw.lanes() == (16, n) and lw.depth(n) == 8 and lw.depth(64) == 16 and lw.depth(n, rlc=True) == 16
+    assert list(dp.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=lw)) == batch.expected
+    small = _permute(batch, list(range(64)), n_pi)
+    for _ in range(3):
+        assert list(dp.verify_batch(small.proofs, small.proof_off, small.instances, small.committed, ws=lw)) == list(got[:64])
+    lw.close()
     sample = sorted(random.Random(6).sample(range(n), 192))
     sb = _permute(batch, sample, n_pi)
     want = ov.verify_batch(sb.proofs, sb.proof_off, sb.instances, sb.committed, threads=16)
