@@ -244,6 +244,15 @@ def test_coop_tables_self_check():
     assert gen_coop_tables.self_check()
 
 
+def test_six_lane_tables_self_check():
+    """The six-lanes-per-proof pairing engine (csrc/h2v_pairing_six.hpp): its operand tables against big-integer Fp12 arithmetic,
+    and a limb-for-limb model of the device engine (28-bit limbs, wrapping 64-bit columns, signed / unsigned Montgomery reduction)
+    with the column headroom asserted from the staged slots' limb bounds."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_six_tables
+    assert gen_six_tables.self_check()
+
+
 def test_g2_line_table_matches_pairing():
     """The precomputed line tables shipped in the plan reproduce the big-integer pairing (bilinearity)."""
     rng = random.Random(8)
@@ -485,11 +494,12 @@ def test_plan_loader_rejects_mutated_blobs_without_a_gpu():
 
 
 def test_generated_headers_are_current(tmp_path):
-    """csrc/bls_consts.h, coop_tables.h and coop_program.h are generated (and self-checked against big-integer
+    """csrc/bls_consts.h, coop_tables.h, six_tables.h and coop_program.h are generated (and self-checked against big-integer
     arithmetic) by tools/gen_*.py; the committed copies must be what the generators produce today."""
     import shutil
     csrc = os.path.join(ROOT, "plutus_halo2_verifier_gen_amd", "csrc")
-    names = {"gen_device_consts.py": "bls_consts.h", "gen_coop_tables.py": "coop_tables.h", "gen_coop_program.py": "coop_program.h"}
+    names = {"gen_device_consts.py": "bls_consts.h", "gen_coop_tables.py": "coop_tables.h", "gen_coop_program.py": "coop_program.h",
+             "gen_six_tables.py": "six_tables.h"}
     backup = {h: open(os.path.join(csrc, h)).read() for h in names.values()}
     stamps = {h: os.stat(os.path.join(csrc, h)) for h in names.values()}
     try:
