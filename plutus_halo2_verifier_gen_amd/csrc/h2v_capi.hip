@@ -142,6 +142,7 @@ struct h2v_workspace {
     HostSlot hslot[MAXH];
     uint64_t h_head = 0, h_tail = 0;
     hipStream_t hs_down = nullptr;
+    bool copy_streams_owned = false;        // laned: hs / hs_down carry copies only and are plain streams of this workspace (host_stream)
     uint32_t *rlc_fail = nullptr;           // RING counters: failed batch checks among the chunks of a call (RLC mode)
     uint32_t *rlc_fail_ptr = nullptr;       // (a lane: where its batch check reports a failure; set by the parent per call)
     // per call (ring): number of chunks, first lane, and every lane's call counters when the call had been enqueued -
@@ -447,6 +448,11 @@ static void ws_release(h2v_workspace *w) {
     if (w->h_block) (void)hipHostFree(w->h_block);
     if (w->h_accept) (void)hipHostFree(w->h_accept);
     if (w->hs) (void)hipStreamSynchronize(w->hs);   // (pool streams are shared and never destroyed: make_stream)
+    if (w->copy_streams_owned) {
+        if (w->hs) (void)hipStreamDestroy(w->hs);
+        if (w->hs_down) (void)hipStreamDestroy(w->hs_down);
+        w->hs = w->hs_down = nullptr; w->copy_streams_owned = false;
+    }
     if (w->ev_host) (void)hipEventDestroy(w->ev_host);
     for (hipStream_t q : w->pmain) if (q) (void)hipStreamSynchronize(q);
     for (hipStream_t q : w->pside) if (q) (void)hipStreamSynchronize(q);
@@ -1303,8 +1309,21 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
     return H2V_OK;
 }
 
+// The stream of the host-buffer entry points.  Not laned: it runs the kernels too - a pool stream (a hardware queue of its
+// own).  Laned: it carries the uploads and the fork event only (and hs_down the downloads), the kernels run on the lanes'
+// pool streams: plain non-blocking streams of the workspace, so that the copies never queue behind a lane's kernels - with
+// eight two-stream lanes the pool's sixteen streams are all taken, and a pool stream shared with a lane held every upload
+// back behind that lane's pairing launch (host path, 8 lanes: 877 k proofs/s; with its own copy streams: see DESIGN.md 6.1).
 static int host_stream(h2v_workspace *ws) {
-    if (!ws->hs) HIPCHK(make_stream(&ws->hs));
+    if (!ws->hs) {
+        if (ws->n_lanes) {
+            HIPCHK(hipStreamCreateWithFlags(&ws->hs, hipStreamNonBlocking));
+            ws->copy_streams_owned = true;
+            if (!ws->hs_down) HIPCHK(hipStreamCreateWithFlags(&ws->hs_down, hipStreamNonBlocking));
+        } else {
+            HIPCHK(make_stream(&ws->hs));
+        }
+    }
     if (!ws->ev_host) HIPCHK(hipEventCreateWithFlags(&ws->ev_host, hipEventDisableTiming));
     return H2V_OK;
 }
