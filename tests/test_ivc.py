@@ -141,6 +141,14 @@ def test_ivc_fold_on_gpu(case):
     got = dp.verify_batch(mixed.proofs, mixed.proof_off, mixed.instances, None)
     want = ov.verify_batch(mixed.proofs, mixed.proof_off, mixed.instances, None, threads=8)
     assert list(got) == list(want) == mixed.expected and 0 < sum(got) < mixed.n
+    # every pairing engine takes the FOLDED left-hand point (el_jac), the six-lanes-per-proof one included (96 proofs: ten waves,
+    # the last with four idle groups)
+    ws = backend.Workspace(dp, mixed.n)
+    for engine in (6, 16, 32, 64):
+        ws.set_option(backend.Workspace.OPT_PAIRING_ENGINE, engine)
+        assert list(dp.verify_batch(mixed.proofs, mixed.proof_off, mixed.instances, None, ws=ws)) == mixed.expected, engine
+        assert ws.timings().pairing_lanes_per_proof == engine
+    ws.close()
     # el / er entering the pairing are the folded ones, bit for bit
     for i in (mixed.expected.index(1), 0):
         proof = big.proof(i)
