@@ -112,8 +112,8 @@ void h2v_workspace_free(h2v_workspace *ws);
  * Verdicts never depend on n_lanes or chunk (tests/test_gpu_parity.py::test_verdicts_do_not_depend_on_the_chunking); in
  * RLC mode every chunk is its own batch check.
  *   n_lanes = 0 / chunk = 0: the library's choice for this plan (chunk = the batch that gives every kernel one wave per
- *   SIMD: 4096 proofs for 16 MSM terms, 1024 for 60; 16 lanes, of which the per-proof mode cycles through 6).  h2v_workspace_create(plan, max_batch) itself
- *   returns a laned workspace when max_batch >= 2 x that chunk.  n_lanes <= 16. */
+ *   SIMD: 4096 proofs for 16 MSM terms, 1024 for 60; 16 lanes, of which the per-proof mode cycles through 8 - all 16 for chunks too small to fill the chip: h2v_workspace_depth).  h2v_workspace_create(plan, max_batch) itself
+ *   returns a laned workspace when max_batch >= 4 x that chunk.  n_lanes <= 16. */
 int h2v_workspace_create_lanes(const h2v_plan *plan, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk, h2v_workspace **out);
 /* Deferred joins (laned workspaces): with defer = 1 a device-resident verify call returns without making the caller's stream
  * wait for its chunks, so the chunks of CONSECUTIVE calls overlap in the lanes - one workspace then does what five
@@ -236,7 +236,7 @@ int h2v_probe_quad_madd(int device, const uint32_t *pq, int neg, uint32_t *out);
 int h2v_probe_pairing(const h2v_plan *plan, uint32_t n, const uint8_t *p1_compressed, const uint8_t *p2_compressed,
                       uint8_t *out);
 /* same with an explicit kernel (impl 0: one lane per proof, 1: cooperative - 32 lanes per proof, or the wide engine for small n,
- * as the launcher picks -, 2 / 3: its narrow (16 lanes per proof) / wide (64) engine whatever n, -1: default) and an
+ * as the launcher picks -, 2 / 3 / 5: its narrow (16 lanes per proof) / wide (64) / six-lane engine whatever n, -1: default) and an
  * optional dump (n * 24 * 48 bytes): the 12 Fp coefficients (flat order w^k, re/im; canonical LE) of f after the
  * Miller loop and, for the cooperative kernel, after the final exponentiation */
 int h2v_probe_pairing_ex(const h2v_plan *plan, uint32_t n, const uint8_t *p1_compressed, const uint8_t *p2_compressed,
