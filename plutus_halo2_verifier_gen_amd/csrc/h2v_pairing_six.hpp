@@ -315,52 +315,31 @@ H2V_DI SixF2 six_frob(const Six &c, const SixF2 &a) {   // a -> a^p: coefficient
     f28_carry(r.im);
     return r;
 }
-// 1/f: N = f * conj(f) lies in Fp6 (even coefficients); the group's first lane inverts it with the tower code
+// 1/f = conj(f) / N with N = f conj(f) in Fp6 (the even coefficients).  1/N without tower code on one lane: the conjugates of
+// N over Fp2 are its images under Frobenius p^2 and p^4, so adj = N^(p^2) N^(p^4) and N adj = Norm(N) lies in Fp2 (coefficient 0);
+// lane 0 of the group inverts that one Fp2 element (one Fp inversion), and 1/N = adj / Norm(N).  Four Frobenius maps and four
+// engine products more than the tower inversion the other engines run on their first lane - and 1.2 KB less scratch per lane
+// (Fp6 temporaries and the frames of fp6_inv), which is what a queue's scratch arena is sized by.
 H2V_DN SixRegs six_inv_raw(const Six c, const SixRegs fr, bool &ok) {
     const SixF2 f = six_unpack(fr);
     const SixF2 fc = six_conj(c, f);
-    const SixF2 nrm = six_mul(c, f, fc);
-    Fp n0, n1;
-    f28_to_fp(n0, nrm.re);
-    f28_to_fp(n1, nrm.im);
-    if (c.act) {   // raw 12 x 32 limbs through the (free) A slots
-        uint32_t *p0 = six_slot(c, SIX_SLOT_A + 2 * c.k), *p1 = six_slot(c, SIX_SLOT_A + 2 * c.k + 1);
-#pragma unroll
-        for (int i = 0; i < 12; i++) { p0[i] = n0.v[i]; p1[i] = n1.v[i]; }
-    }
-    __syncthreads();
+    const SixF2 nrm = six_mul(c, f, fc);                       // N
+    const SixF2 n2 = six_frob(c, six_frob(c, nrm));            // N^(p^2)        (v <= 5)
+    const SixF2 n4 = six_frob(c, six_frob(c, n2));             // N^(p^4)
+    const SixF2 adj = six_mul(c, n2, n4);
+    const SixF2 nn = six_mul(c, nrm, adj);                     // Norm(N): coefficient 0 only
+    Fp2 z, zi;
+    f28_to_fp(z.c0, nn.re);
+    f28_to_fp(z.c1, nn.im);
+    fp_set_zero(zi.c0);
+    fp_set_zero(zi.c1);
     bool good = true;
-    if (c.act && c.k == 0) {
-        Fp6 n6, inv6;
-        Fp *dst[6] = {&n6.c0.c0, &n6.c0.c1, &n6.c1.c0, &n6.c1.c1, &n6.c2.c0, &n6.c2.c1};
-        for (int q = 0; q < 6; q++) {   // coefficient 2 (q >> 1), part q & 1
-            const uint32_t *p = six_slot(c, SIX_SLOT_A + 2 * (2 * (q >> 1)) + (q & 1));
-#pragma unroll
-            for (int i = 0; i < 12; i++) dst[q]->v[i] = p[i];
-        }
-        good = fp6_inv(inv6, n6);
-        const Fp *res[6] = {&inv6.c0.c0, &inv6.c0.c1, &inv6.c1.c0, &inv6.c1.c1, &inv6.c2.c0, &inv6.c2.c1};
-        for (int q = 0; q < 6; q++) {
-            uint32_t *p = six_slot(c, SIX_SLOT_A + 2 * (2 * (q >> 1)) + (q & 1));
-#pragma unroll
-            for (int i = 0; i < 12; i++) p[i] = res[q]->v[i];
-        }
-    }
-    __syncthreads();
-    Fp i0, i1;
-    fp_set_zero(i0);
-    fp_set_zero(i1);
-    if (!(c.k & 1)) {
-        const uint32_t *p0 = six_slot(c, SIX_SLOT_A + 2 * c.k), *p1 = six_slot(c, SIX_SLOT_A + 2 * c.k + 1);
-#pragma unroll
-        for (int i = 0; i < 12; i++) { i0.v[i] = p0[i]; i1.v[i] = p1[i]; }
-    }
-    __syncthreads();
+    if (c.k == 0) good = fp2_inv(zi, z);
     ok = good;
-    SixF2 ninv;
-    f28_from_fp(ninv.re, i0);
-    f28_from_fp(ninv.im, i1);
-    const SixF2 r = six_mul(c, fc, ninv);
+    SixF2 ninv;                                                // 1 / Norm(N) as an Fp12 element: coefficient 0, zero elsewhere
+    f28_from_fp(ninv.re, zi.c0);
+    f28_from_fp(ninv.im, zi.c1);
+    const SixF2 r = six_mul(c, fc, six_mul(c, adj, ninv));
     SixRegs o;
     o.re = f28_pack(r.re);
     o.im = f28_pack(r.im);

@@ -547,6 +547,19 @@ def test_full_size_batch_properties(be, circuits):
     for _ in range(3):
         assert list(dp.verify_batch(small.proofs, small.proof_off, small.instances, small.committed, ws=lw)) == list(got[:64])
     lw.close()
+    # Large single calls through several kinds of workspace in ONE process, ending on the default laned one: every pool stream
+    # has run the kernels with the largest private segments by then.  (With 3 KB of scratch per lane in the decompression, MSM and
+    # six-lane pairing kernels this very sequence ended in HSA_STATUS_ERROR_OUT_OF_RESOURCES - a queue's scratch arena is sized by
+    # the largest segment it has seen, and sixteen queues of them did not fit; the kernels now stay at or below 2 KB.)
+    five = _permute(batch, [i % n for i in range(5 * n)], n_pi)
+    for make in (lambda: be.Workspace(dp, 2 * n, lanes=1, chunk=2 * n), lambda: be.Workspace(dp, 2 * n),
+                 lambda: be.Workspace(dp, 5 * n, lanes=1, chunk=5 * n), lambda: be.Workspace(dp, 5 * n)):
+        w_ = make()
+        m = min(w_.max_batch, 5 * n)
+        part = five if m == 5 * n else _permute(five, list(range(m)), n_pi)
+        for _ in range(2):
+            assert list(dp.verify_batch(part.proofs, part.proof_off, part.instances, part.committed, ws=w_)) == (batch.expected * 5)[:m]
+        w_.close()
     sample = sorted(random.Random(6).sample(range(n), 192))
     sb = _permute(batch, sample, n_pi)
     want = ov.verify_batch(sb.proofs, sb.proof_off, sb.instances, sb.committed, threads=16)

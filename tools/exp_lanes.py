@@ -57,14 +57,17 @@ def main():
             dp.verify_batch_device(*ptrs, ws=ws, stream=stream)
 
     def single(n, lanes, chunk, reps_=6):
-        ws = backend.Workspace(dp, n, lanes=lanes, chunk=chunk) if lanes else backend.Workspace.__new__(backend.Workspace)
-        if not lanes:   # classic, one pipeline
+        if lanes < 0:    # whatever h2v_workspace_create returns for a workspace of n proofs (laned from four chunks up)
+            ws = backend.Workspace(dp, n)
+        else:
+            ws = backend.Workspace(dp, n, lanes=lanes, chunk=chunk) if lanes else backend.Workspace.__new__(backend.Workspace)
+        if lanes == 0:   # classic, one pipeline
             import ctypes as C
             ws._h = C.c_void_p()
             backend.check(backend.lib().h2v_workspace_create_lanes(dp.handle, n, 1, n, C.byref(ws._h)))
         acc = torch.zeros(n, dtype=torch.uint8, device=dev)
         st_ = torch.zeros(n, dtype=torch.int32, device=dev)
-        for _ in range(max(2, lanes)):
+        for _ in range(max(2, lanes, 3)):
             call(ws, n, acc, st_)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -78,9 +81,9 @@ def main():
         return el, ok, lc
 
     for n in [int(x) for x in args.single.split(",") if x]:
-        for lanes in [0] + [int(x) for x in args.lanes.split(",")]:
+        for lanes in [0, -1] + [int(x) for x in args.lanes.split(",") if x]:
             for chunk in [int(x) for x in args.chunks.split(",")]:
-                if lanes == 0 and chunk != int(args.chunks.split(",")[0]):
+                if lanes <= 0 and chunk != int(args.chunks.split(",")[0]):
                     continue
                 el, ok, lc = single(n, lanes, chunk)
                 print("single call n=%6d lanes=%2d chunk=%5d -> %8.3f ms  %9.0f proofs/s  (%.3f ms per 4096) ok=%s stagger=%s" % (
@@ -88,7 +91,9 @@ def main():
 
     # a stream of batches of B proofs through ONE laned workspace with deferred joins
     K = args.stream_steps
-    for lanes in [int(x) for x in args.lanes.split(",")] + [11]:
+    if not K:
+        return
+    for lanes in [int(x) for x in args.lanes.split(",") if x] + ([11] if args.stream_steps else []):
         ws = backend.Workspace(dp, B, lanes=lanes, chunk=B)
         ws.defer_joins(True)
         accs = [torch.zeros(B, dtype=torch.uint8, device=dev) for _ in range(lanes)]

@@ -28,8 +28,12 @@ OP_NAMES = ["END", "MUL", "MSTEP", "CONJ", "FROB", "INV", "MOV", "SETONE", "DUMP
 # CSQR d, a, n: d = a^(2^n) by n cyclotomic squarings; the value stays in registers between them (a run of squarings
 # is one interpreter step: no round trip of the variable through private memory per squaring)
 # variables
-F, A, T, U, T0, T1, T2, T3, X = range(9)
-N_VARS = 9
+# (five variables: the running power S is overwritten step by step and the result is built in F - every variable is a slice of
+# each lane's private memory, which sizes the queue's scratch arena)
+F, A, T, U, S = range(5)
+T0 = T1 = T2 = S
+T3 = F
+N_VARS = 5
 
 
 def build_program():
@@ -61,8 +65,7 @@ def build_program():
     e(OP_CONJ, U, T2); e(OP_MUL, T3, T3, U)                  # ^(x^2+p^2-1)
     e(OP_MUL, U, T, T); e(OP_MUL, U, U, T)                   # t^3
     e(OP_MUL, T3, T3, U)
-    e(OP_DUMP, 1, T3)
-    e(OP_MOV, F, T3)          # result is read from F
+    e(OP_DUMP, 1, T3)         # (T3 is F: the result is read from F)
     e(OP_END)
     return prog
 
