@@ -1703,7 +1703,9 @@ static bool rlc_supported(const h2v_plan *p) { return !p->d.ivc && p->n_var > 0 
 // is two small bucket MSMs (right: 64 n_var + n_fix terms, 255-bit scalars; left: 64 terms, 128-bit) with 7-bit windows
 // (64 buckets x 19 windows: ~20 entries per bucket on the right).  Batches below GRP_MIN_N proofs or above GRP_MAX_G groups
 // go straight to the per-proof kernels.  Everything here is enqueued behind the batch check and returns at once when it
-// passed.  H2V_RLC_GROUPS=0 switches the stage off (measurements).
+// passed.  H2V_RLC_GROUPS=0 switches the stage off (measurements).  (Window width 5 / 6 / 7 / 8 bits, one rejecting proof per
+// 4096-proof batch, sixteen batches in flight: 2.90 / 2.72 / 2.86 / 2.80 ms per batch - the three pairing stages in a row are
+// what the fall-back waits for, not these sums.)
 #define GRP_MIN_N 256u
 #define GRP_MAX_G 512u
 #define GRP_C 7u
