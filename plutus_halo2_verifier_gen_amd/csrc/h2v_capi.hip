@@ -814,14 +814,23 @@ static uint32_t launch_msm_ladders(const H2vDevPlan &d, const H2vMsmArgs &ma, ui
 // host thread, inside run_pipeline / run_rlc, which set this for their duration
 struct LaunchOptions { int msm_tpl = 0, pairing = 0; };
 static thread_local LaunchOptions g_opts;
-static int msm_terms_per_lane(uint32_t in_flight_hint) {
+// Terms per lane of the ladder kernel for callers that keep the chip full: more terms per lane share more doublings and make
+// fewer, longer waves - as many as still leave the launch a quarter of a wave per SIMD (two at least).  ms per batch, eight
+// batches in flight, terms per lane 2 / 3 / 4: simple_mul x 4096 (10 terms: 320 / 256 / 192 waves) 3.73 / 3.64 / 3.84;
+// lookup_table x 2048 (25 terms: 416 / 288 / 224) 3.42 / 3.36 / -; x 4096 6.82 / 6.71 / 6.59; atms x 2048 (20 terms: 320 / 224 /
+// 160) 3.55 / 3.72 / 4.05; sha256 shape in chunks of 1024 (25 terms: 208 / 144) 2.26 / 2.35.
+static int msm_terms_per_lane(uint32_t in_flight_hint, uint32_t n = 0, uint32_t n_terms = 0) {
     static const int v = []() { const char *e = getenv("H2V_MSM_TPL"); const int t = e ? atoi(e) : 0; return t >= 1 && t <= 4 ? t : 0; }();
     if (g_opts.msm_tpl >= 1 && g_opts.msm_tpl <= 4) return g_opts.msm_tpl;
-    return v ? v : (in_flight_hint >= 4 ? 2 : 1);
+    if (v) return v;
+    if (in_flight_hint < 4) return 1;
+    for (int t = 4; t > 2; t--)
+        if ((double)n * ((n_terms + t - 1) / t) / 64.0 >= msm_n_simd() / 4.0) return t;
+    return 2;
 }
 static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint32_t n, const uint32_t *scalars, const uint32_t *pts,
                                  uint32_t *tabws, hipStream_t st, uint32_t in_flight_hint = 1) {
-    const int tpl = msm_terms_per_lane(in_flight_hint);
+    const int tpl = msm_terms_per_lane(in_flight_hint, n, ma.n_terms);
     // (only launches of at least a quarter of a wave per SIMD at one lane per term: below that the launch is a chain of lone
     //  waves whatever else is in flight, and the two-lanes-per-term ladder is the shortest chain - sha256 shape x 128 with six
     //  shares in flight: MSM 2.5 ms -> 1.4 ms alone)
