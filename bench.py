@@ -551,9 +551,10 @@ def main():
             pairing_lane = sum(calls * ((terms // nq) * 196 + 196) for calls, terms in ((35, 12), (63, 8), (315, 4), (136, 6)))
             if pair_lanes == 6:
                 # six lanes per proof (csrc/h2v_pairing_six.hpp): a lane owns an Fp2 coefficient; MUL / SQR / LINE are 6 / 4 / 3
-                # Karatsuba terms of 3 products + 2 reductions, the cyclotomic squaring 8 products + 2 reductions, and per
-                # Miller round one product + reduction for the line's (-lambda) xP; a wave carries 10 proofs on 64 lanes
-                pairing_lane = 35 * (3 * 6 + 2) * 196 + 63 * (3 * 4 + 2) * 196 + 136 * (3 * 3 + 2) * 196 + 315 * (8 + 2) * 196 + 68 * 2 * 196
+                # Karatsuba terms of 3 products + 2 reductions, the cyclotomic squaring 5 products + 2 reductions + two folds of
+                # 14 multiply-adds, and per Miller round one product + reduction for the line's (-lambda) xP; a wave carries 10
+                # proofs on 64 lanes
+                pairing_lane = 35 * (3 * 6 + 2) * 196 + 63 * (3 * 4 + 2) * 196 + 136 * (3 * 3 + 2) * 196 + 315 * ((5 + 2) * 196 + 28) + 68 * 2 * 196
             bytes_per_launch = {
                 "g1_msm": B * (128 * T_lad + 144),
                 "g1_msm_fixed": B * (128 * n_fix_terms + 144),

@@ -94,6 +94,19 @@ H2V_DI void f28_carry(F28 &a) {
     }
     a.l[13] += c;
 }
+// Fold a carried element with value < 32p below 2p (and a hair): the quotient by p is estimated from the top limb (never too
+// large, at most one too small) and q p subtracted with signed carries.  (tools/gen_six_tables.py: fold - the same integer
+// steps, checked on every multiple of p up to 32p, its neighbours and random values.)
+H2V_DI void f28_fold(F28 &a) {
+    const uint32_t q = __umulhi(a.l[13], FP_FOLD_M);
+    int64_t t = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        t += (int64_t)a.l[i] - (int64_t)((uint64_t)q * FP_MOD28[i]);
+        a.l[i] = i < 13 ? (uint32_t)t & FP28_MASK : (uint32_t)t;
+        t >>= 28;
+    }
+}
 // Exact test "a == 0 (mod p)" for a carried element with value < 5p: compare with 0, p, 2p, 3p, 4p.
 H2V_DI bool f28_is_zero_v5(const F28 &a) {
     uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;

@@ -12,8 +12,9 @@
 // The sums x0 + x1, y0 + y1 are formed LIMB-WISE in registers (uncarried), so W - U - V equals sum(x0 y1 + x1 y0) column by column: the
 // imaginary part's columns are non-negative (unsigned reduction; W itself may wrap modulo 2^64 on the way - harmless);
 // U - V is taken in two's complement columns (|column| < 2^63) and reduced with arithmetic carries, p added at the end.
-// Wrapped terms (x xi) take the xi on the A side: XA = xi a = (a0 - a1, a0 + a1).  The cyclotomic squaring keeps its direct
-// form (4 + 4 products into two accumulators, constants +-2/3, reduced results tripled).  Per line the products
+// Wrapped terms (x xi) take the xi on the A side: XA = xi a = (a0 - a1, a0 + a1).  The cyclotomic squaring is five
+// products into U, U, V, W, W (re = U - V, im = W + V: S_b M_b and 2 b0 b1 serve both parts); the lane forms 3 r -/+ 2 g itself
+// and folds it below 2p with a quotient estimate from the top limb (f28_fold).  Per line the products
 // b = (-lambda) xP of the two loops are taken by lanes 0..3 of the group just before the two line steps (one product each).
 // Tables and the headroom argument: tools/gen_six_tables.py (value-level check against big-integer Fp12 arithmetic and a
 // limb-level model of this code with the column bounds asserted).  Program, line tables, semantics: h2v_pairing_coop.hpp.
@@ -31,7 +32,7 @@
 #define SIX_GROUPS 10
 #define SIX_SLOT_DW 14
 #define SIX_GROUP_DW (SIX_N_GROUP_SLOTS * SIX_SLOT_DW)
-#define SIX_TAB_DW ((6 * 4 * SIX_N_MUL + 6 * 4 * SIX_N_SQR + 2 * 6 * 4 * SIX_N_LINE + 6 * 6 * SIX_N_CSQR) / 4)
+#define SIX_TAB_DW ((6 * 4 * SIX_N_MUL + 6 * 4 * SIX_N_SQR + 2 * 6 * 4 * SIX_N_LINE + 6 * 16) / 4)
 #define SIX_TAB_OFF (SIX_N_SHARED_SLOTS * SIX_SLOT_DW)
 #define SIX_GRP_OFF ((SIX_TAB_OFF + SIX_TAB_DW + 1) & ~1)
 #define SIX_LDS_BYTES ((size_t)(SIX_GRP_OFF + SIX_GROUPS * SIX_GROUP_DW) * 4)
@@ -160,34 +161,35 @@ H2V_DN SixRegs six_kara(const Six c, const int tab_row_byte, const int nt) {
     o.im = f28_pack(r.im);
     return o;
 }
-// cyclotomic squaring: 4 products (x + x2) y for the real part, 4 for the imaginary part (3 slot bytes each), results
-// tripled (< 4p)
+// cyclotomic squaring: five products (x + x2) y into U, U, V, W, W (3 slot bytes each; gen_six_tables.py: csqr_table) ->
+// re = U - V (signed columns), im = W + V, reduced: re below 2.2p, im below 1.2p.  The lane finishes with 3 r -/+ 2 g (six_csqr).
 H2V_DN SixRegs six_csqr_engine(const Six c, const int tab_row_byte) {
     const uint8_t *tab = reinterpret_cast<const uint8_t *>(coop_lds + SIX_TAB_OFF) + tab_row_byte;
-    uint64_t U[28], W[28];
+    uint64_t U[28], V[28], W[28];
 #pragma unroll
-    for (int i = 0; i < 28; i++) { U[i] = 0; W[i] = 0; }
-#pragma unroll 1
-    for (int t = 0; t < SIX_N_CSQR; t++) {
-        uint32_t x[14], x2[14], y[14];
-        six_load_pair(x, x2, six_slot(c, tab[3 * t]), six_slot(c, tab[3 * t + 1]));
-        six_load(y, six_slot(c, tab[3 * t + 2]));
+    for (int i = 0; i < 28; i++) { U[i] = 0; V[i] = 0; W[i] = 0; }
+    uint32_t x[14], x2[14], y[14];
+#define SIX_CSQR_SET(ACC, T)                                                                             \
+    do {                                                                                                 \
+        six_load_pair(x, x2, six_slot(c, tab[3 * (T)]), six_slot(c, tab[3 * (T) + 1]));                  \
+        six_load(y, six_slot(c, tab[3 * (T) + 2]));                                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 14; i_++) x[i_] += x2[i_];                               \
+        six_mac(ACC, x, y);                                                                              \
+    } while (0)
+    SIX_CSQR_SET(U, 0);
+    SIX_CSQR_SET(U, 1);
+    SIX_CSQR_SET(V, 2);
+    SIX_CSQR_SET(W, 3);
+    SIX_CSQR_SET(W, 4);
+#undef SIX_CSQR_SET
 #pragma unroll
-        for (int i = 0; i < 14; i++) x[i] += x2[i];
-        six_mac(U, x, y);
-        six_load_pair(x, x2, six_slot(c, tab[3 * SIX_N_CSQR + 3 * t]), six_slot(c, tab[3 * SIX_N_CSQR + 3 * t + 1]));
-        six_load(y, six_slot(c, tab[3 * SIX_N_CSQR + 3 * t + 2]));
-#pragma unroll
-        for (int i = 0; i < 14; i++) x[i] += x2[i];
-        six_mac(W, x, y);
+    for (int i = 0; i < 27; i++) {   // (column 27 holds no product)
+        U[i] -= V[i];
+        W[i] += V[i];
     }
     SixF2 r;
-    six_reduce<false>(r.re, U);
+    six_reduce<true>(r.re, U);
     six_reduce<false>(r.im, W);
-#pragma unroll
-    for (int i = 0; i < 14; i++) { r.re.l[i] *= 3u; r.im.l[i] *= 3u; }
-    f28_carry(r.re);
-    f28_carry(r.im);
     SixRegs o;
     o.re = f28_pack(r.re);
     o.im = f28_pack(r.im);
@@ -287,8 +289,21 @@ H2V_DI SixF2 six_csqr(const Six &c, const SixF2 &a) {
         }
     }
     __syncthreads();
-    const SixF2 r = six_unpack(six_csqr_engine(c, SIX_TAB_CSQR_B + c.k * 6 * SIX_N_CSQR));
+    SixF2 r = six_unpack(six_csqr_engine(c, SIX_TAB_CSQR_B + c.k * 16));
     __syncthreads();
+    // h_k = 3 Q_k - 2 g_k (k even) / + 2 g_k (k odd), folded: 3 r + (13p - 2g | 2g) is below 20p (r < 2.2p, g < 6p), the fold
+    // brings it below 2p.  (The other engines multiply g by the constants -/+ 2/3 inside the sum: two products more per lane.)
+    const bool minus = (c.k & 1) == 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint32_t g0 = a.re.l[i] << 1, g1 = a.im.l[i] << 1;
+        r.re.l[i] = 3u * r.re.l[i] + (minus ? F28_BIAS_13_2[i] - g0 : g0);
+        r.im.l[i] = 3u * r.im.l[i] + (minus ? F28_BIAS_13_2[i] - g1 : g1);
+    }
+    f28_carry(r.re);
+    f28_carry(r.im);
+    f28_fold(r.re);
+    f28_fold(r.im);
     return r;
 }
 H2V_DI SixF2 six_conj(const Six &c, const SixF2 &a) {   // w -> -w: odd coefficients change sign.  a: v <= 5
@@ -384,11 +399,7 @@ k_pairing_six(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, con
         for (int t = 0; t < 5; t++)
             for (int q = lane; q < off[t + 1] - off[t]; q += 64) coop_lds[SIX_TAB_OFF + off[t] + q] = src[t][q];
     }
-    if (lane < 14) {   // the shared constants: +-2/3 for the cyclotomic squaring, zero
-        coop_lds[(SIX_SLOT_C23P - SIX_SHARED_BASE) * SIX_SLOT_DW + lane] = FP_C23P28[lane];
-        coop_lds[(SIX_SLOT_C23N - SIX_SHARED_BASE) * SIX_SLOT_DW + lane] = FP_C23N28[lane];
-        coop_lds[(SIX_SLOT_ZERO - SIX_SHARED_BASE) * SIX_SLOT_DW + lane] = 0u;
-    }
+    if (lane < 14) coop_lds[(SIX_SLOT_ZERO - SIX_SHARED_BASE) * SIX_SLOT_DW + lane] = 0u;   // the shared zero operand
     // ---- leader: status, the two G1 arguments (el ; -er normalised to affine)
     uint32_t st = 0;
     uint32_t flags = 0;  // bit0: el is infinity, bit1: er is infinity

@@ -12,8 +12,9 @@ and an engine call (MUL: 6 terms, SQR: 4, LINE: 3) ends with   re = U - V  (sign
 equal to sum(x0 y1 + x1 y0) because the engine forms the sums LIMB-WISE in registers, so unsigned), one Montgomery reduction each: 3 NT + 2 products
 of 196 multiply-adds where the one-coefficient-per-lane engine spends 2 (2 NT + 1) on the same Fp2 coefficient.
 Wrapped terms (x xi) take the xi on the A side: XA = xi a = (a0 - a1, a0 + a1).
-The cyclotomic squaring keeps its direct form (two accumulators, operands S = re + im, M = re - im, NA = -im, D = 2a,
-the +-2/3 constants): 4 + 4 products, the reduced results tripled; S is formed by the engine too.
+The cyclotomic squaring is five products into U, U, V, W, W (operands S = re + im - formed by the engine -, M = re - im,
+NA = -im, D = 2a): re = U - V, im = W + V; the lane forms h = 3 (reduced) -/+ 2 g itself and folds it below 2p by a quotient
+estimate from the top limb (the +-2/3 constant products of the other engines cost two products more).
 A group's operand slots are 56 bytes (14 limbs, no padding) and 38 in number: 2.1 KB per proof, 23 KB per wave of ten.
 """
 import os
@@ -51,7 +52,7 @@ LN_NL0, LN_NL1, LN_C0, LN_C1 = 0, 1, 4, 5
 C23P, C23N, ZERO = SH + 16, SH + 17, SH + 18
 N_SHARED_SLOTS = 19
 C23 = 2 * pow(3, -1, P) % P
-N_MUL, N_SQR, N_LINE, N_CSQR = 6, 4, 3, 4
+N_MUL, N_SQR, N_LINE, N_CSQR = 6, 4, 3, 5
 ZT = (ZERO, ZERO, ZERO, ZERO)
 
 
@@ -111,8 +112,14 @@ def line_table(loop):
 
 
 def csqr_table():
-    """Per lane 4 products (x + x2) * y for the real part, then 4 for the imaginary part (formulas: gen_coop_tables.csqr_table);
-    x2 = ZERO except for S_k = re_k + im_k, which the engine forms from A0(k), A1(k)."""
+    """Per lane FIVE products (x + x2) * y into the accumulators U, U, V, W, W; the engine ends with re = U - V (signed columns),
+    im = W + V, one reduction each (formulas: gen_coop_tables.csqr_table; x2 = ZERO except for S_k = re_k + im_k, which the engine
+    forms from A0(k), A1(k)).  Granger-Scott with the pair (a, b) of the lane's kind:
+       even    a^2 + xi b^2:  re = S_a M_a + S_b M_b - 2 b0 b1     im = 2 a0 a1 + S_b M_b + 2 b0 b1     (V = b0 D_b1 is SHARED, and so
+                                                                                                         is the product S_b M_b: U and W)
+       odd     2 a b:         re = a0 D_b0 + (-a1) D_b1            im = a0 D_b1 + a1 D_b0               (V = 0)
+       xi-odd  2 xi a b:      re = D_a0 M_b + (-2 a1) S_b          im = S_b D_a0 + D_a1 M_b             (V = 0)
+    The lane then forms h = 3 (reduced) -/+ 2 g_k itself and folds it below 2p (h2v_pairing_six.hpp: six_csqr)."""
     kind = {0: ("even", 0, 3), 3: ("odd", 0, 3), 1: ("xi_odd", 2, 5), 4: ("even", 2, 5), 2: ("even", 1, 4), 5: ("odd", 1, 4)}
     Z = (ZERO, ZERO, ZERO)
     one = lambda x, y: (x, ZERO, y)
@@ -121,19 +128,13 @@ def csqr_table():
     for k in range(6):
         ty, a, b = kind[k]
         if ty == "even":
-            re = [SxM(a), SxM(b), one(C_NA(b), B0(b))]
-            im = [one(A0(a), B1(a)), SxM(b), one(A0(b), B1(b))]
+            sets = [SxM(a), SxM(b), one(A0(b), B1(b)), one(A0(a), B1(a)), SxM(b)]
         elif ty == "odd":
-            re = [one(A0(a), B0(b)), one(C_NA(a), B1(b)), Z]
-            im = [one(A0(a), B1(b)), one(A1(a), B0(b)), Z]
+            sets = [one(A0(a), B0(b)), one(C_NA(a), B1(b)), Z, one(A0(a), B1(b)), one(A1(a), B0(b))]
         else:
             assert a == 2
-            re = [one(B0(a), C_M(b)), (A0(b), A1(b), C_ND2), Z]           # D_a0 M_b + S_b ND2
-            im = [(A0(b), A1(b), B0(a)), one(B1(a), C_M(b)), Z]          # S_b D_a0 + D_a1 M_b
-        cst = C23N if k % 2 == 0 else C23P
-        re.append(one(A0(k), cst))
-        im.append(one(A1(k), cst))
-        tab.append(re + im)
+            sets = [one(B0(a), C_M(b)), (A0(b), A1(b), C_ND2), Z, (A0(b), A1(b), B0(a)), one(B1(a), C_M(b))]
+        tab.append(sets)
     return tab
 
 
@@ -255,21 +256,65 @@ def kara_engine(terms, s):
     return limbs_val(reduce_cols(re, True)), limbs_val(reduce_cols(im, False))
 
 
-def csqr_engine(sets, s):
+FOLD_M = (1 << 32) // ((P >> 364) + 1)
+BIAS_13_2 = None
+
+
+def bias_13_2():
+    """13 p written with every limb below the top >= 2 * 2^28 (tools/gen_device_consts.py: bias(13, 2))"""
+    c = [(13 * P >> (28 * i)) & MASK for i in range(13)] + [13 * P >> 364]
+    sp = 3
+    out = [c[0] + (sp << 28)] + [c[i] + (sp << 28) - sp for i in range(1, 13)] + [c[13] - sp]
+    assert sum(x << (28 * i) for i, x in enumerate(out)) == 13 * P
+    return out
+
+
+def carry_limbs(l):
+    out, c = [], 0
+    for i in range(13):
+        t = l[i] + c
+        assert t < (1 << 32)
+        out.append(t & MASK)
+        c = t >> 28
+    assert l[13] + c < (1 << 32)
+    return out + [l[13] + c]
+
+
+def fold(l):
+    """the device's f28_fold: carried limbs of a value below 32 p -> the same residue below 2p (and a hair), carried"""
+    assert all(v < (1 << 28) for v in l[:13]) and l[13] < (1 << 22)
+    q = (l[13] * FOLD_M) >> 32
+    out, t = [], 0
+    for i in range(14):
+        t += l[i] - q * P_L[i]
+        assert -(1 << 63) <= t < (1 << 63)
+        out.append(t & MASK if i < 13 else t)
+        t >>= 28
+    assert t == 0 and 0 <= out[13] < (1 << 28)
+    return out
+
+
+def csqr_engine(sets, s, g, k):
+    """sets: the lane's five products; g = (re, im) limbs of the lane's own coefficient as staged in A0(k), A1(k)"""
+    lam3 = lambda t: 14 * (s.lam[t[0]] + s.lam[t[1]]) * s.lam[t[2]]
+    assert lam3(sets[0]) + lam3(sets[1]) + RED < (1 << 63) and lam3(sets[2]) < (1 << 63), "re columns"
+    assert lam3(sets[2]) + lam3(sets[3]) + lam3(sets[4]) + RED < (1 << 64), "im columns"
+    U, V, W = [0] * 28, [0] * 28, [0] * 28
+    for acc, (x, x2, y) in zip((U, U, V, W, W), sets):
+        mac(acc, [a + b for a, b in zip(s[x], s[x2])], s[y])
+    assert max(U) < (1 << 63) and max(V) < (1 << 63)
+    re = [(U[i] - V[i]) & M64 for i in range(28)]
+    im = [(W[i] + V[i]) & M64 for i in range(28)]
+    r = [reduce_cols(re, True), reduce_cols(im, False)]
+    bias = bias_13_2()
     out = []
-    for half in (sets[:4], sets[4:]):
-        assert sum(14 * (s.lam[x] + s.lam[x2]) * s.lam[y] for x, x2, y in half) + RED < (1 << 64), "csqr columns"
-        acc = [0] * 28
-        tot = [0] * 28
-        for x, x2, y in half:
-            xs = [a + b for a, b in zip(s[x], s[x2])]
-            mac(acc, xs, s[y])
-            for i in range(14):
-                for j in range(14):
-                    tot[i + j] += xs[i] * s[y][j]
-        assert tot == acc, "column wrapped"
-        r = reduce_cols(acc, False)
-        out.append(3 * limbs_val(r))
+    for part in range(2):
+        two_g = [2 * v for v in s[(A0 if part == 0 else A1)(k)]]
+        h = [3 * r[part][i] + (bias[i] - two_g[i] if k % 2 == 0 else two_g[i]) for i in range(14)]
+        assert all(0 <= v < (1 << 32) for v in h)
+        f = fold(carry_limbs(h))
+        assert limbs_val(f) < 2 * P + (P >> 10)
+        out.append(limbs_val(f))
     return out[0], out[1]
 
 
@@ -337,6 +382,11 @@ def self_check():
             assert all(v < 3 * P for pair in got for v in pair)
             line = [cc, bls.F2_ZERO, bls.f2_scale(nl, xp), (yp, 0), bls.F2_ZERO, bls.F2_ZERO]
             assert unmont([(x % P, y % P) for x, y in got]) == bls.f12_mul(a, line)
+    # the fold on its own: every multiple of p up to 32 p and its neighbours, random values, the largest value it is handed
+    for v in [k * P + d for k in range(32) for d in (-1, 0, 1) if k * P + d >= 0] + [rng.randrange(32 * P) for _ in range(2000)] + [32 * P - 1]:
+        lim = [(v >> (28 * i)) & MASK for i in range(13)] + [v >> 364]
+        f = limbs_val(fold(lim))
+        assert f % P == v % P and f < 2 * P + (P >> 10)
     # cyclotomic squaring on an element of the cyclotomic subgroup
     f = bls.miller_loop(bls.g1_mul(bls.G1_GEN, 777), bls.g2_mul(bls.G2_GEN, 3))
     t = bls.f12_mul(bls.f12_conj(f), bls.f12_inv(f))
@@ -344,8 +394,8 @@ def self_check():
     for trial in range(4):
         s = Slots(); s.put(ZERO, 0); s.lam[ZERO] = 0
         stage_csqr(s, spread(rng, mont(t), 6))
-        got = [csqr_engine(ct[k], s) for k in range(6)]
-        assert all(v < 4 * P for pair in got for v in pair)
+        got = [csqr_engine(ct[k], s, None, k) for k in range(6)]
+        assert all(v < 3 * P for pair in got for v in pair)
         assert unmont([(x % P, y % P) for x, y in got]) == bls.f12_sqr(t)
         t = bls.f12_mul(bls.f12_sqr(t), t)
     return True
@@ -370,7 +420,7 @@ def emit():
     arr("SIX_TAB_SQR", sqr_table(), 4 * N_SQR)
     arr("SIX_TAB_LINE1", line_table(1), 4 * N_LINE)
     arr("SIX_TAB_LINE2", line_table(2), 4 * N_LINE)
-    arr("SIX_TAB_CSQR", csqr_table(), 3 * 2 * N_CSQR)
+    arr("SIX_TAB_CSQR", [row + [(ZERO,)] for row in csqr_table()], 16)      # (15 slot bytes per lane, padded to 16)
     path = os.path.join(ROOT, "plutus_halo2_verifier_gen_amd", "csrc", "six_tables.h")
     with open(path, "w") as f:
         f.write("\n".join(o) + "\n")
