@@ -541,7 +541,7 @@ def main():
             quad = shape if shape == 8 else 0                    # a quad per GLV half (small launches of few terms)
 
             def shape_names(lpt_code, lanes):   # the kernels behind the launcher's reported shapes
-                return {"g1_msm": {18: "k_g1_msm_multi2", 19: "k_g1_msm_multi3", 20: "k_g1_msm_multi4", 1: "k_g1_msm_merged", 8: "k_g1_msm_quad"}.get(lpt_code, "k_g1_msm"),
+                return {"g1_msm": {18: "k_g1_msm_multi", 19: "k_g1_msm_multi", 20: "k_g1_msm_multi", 1: "k_g1_msm_merged", 8: "k_g1_msm_quad"}.get(lpt_code, "k_g1_msm"),
                         "g1_msm_fixed": "k_g1_msm_fixed",
                         "g1_decompress": dec_name, "transcript_combiner": vm_name,
                         "pairing": {6: "k_pairing_six", 16: "k_pairing_coop_narrow", 64: "k_pairing_coop_wide", 1: "k_pairing_check"}.get(lanes, "k_pairing_coop")}

@@ -805,7 +805,7 @@ static uint32_t launch_msm_ladders(const H2vDevPlan &d, const H2vMsmArgs &ma, ui
     else hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
     return sh.lpt;
 }
-// H2V_MSM_TPL = 2 / 4: k_g1_msm_multi2 / 4 (several terms per lane share the doublings: less work, fewer and longer waves;
+// H2V_MSM_TPL = 2 .. 4: k_g1_msm_multi (several terms per lane share the doublings: less work, fewer and longer waves;
 // for callers that keep several batches in flight - bench.py sets it then).  Single-group launches with prebuilt tables only.
 // Without the variable the caller's hint decides (h2v_workspace_hint_in_flight): a caller that keeps >= 4 batches in flight is
 // bound by the instructions issued, not by chain length, and two terms per lane issue 26 % fewer multiply-adds per proof
@@ -837,12 +837,14 @@ static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint
     const bool fills = (double)n * ma.n_terms / 64.0 >= msm_n_simd() / 4.0;
     const bool tpl_forced = getenv("H2V_MSM_TPL") != nullptr || g_opts.msm_tpl > 0;
     if (tpl > 1 && (fills || tpl_forced) && ma.pt_tab && !ma.skip && ma.grp_end[0] == ma.n_terms && ma.n_terms >= (uint32_t)tpl && ma.n_terms <= 256u * tpl) {
-        const uint32_t lpp = (ma.n_terms + tpl - 1) / tpl, bs = 256;
+        // lanes per proof as for `tpl` whole terms per lane, then the proof's 2 T GLV halves dealt out evenly over them: ten terms
+        // on four lanes are 5 + 5 + 5 + 5 halves, not 6 + 6 + 6 + 2 (a forced tpl keeps its 2 tpl halves per lane)
+        const uint32_t lpp0 = (ma.n_terms + tpl - 1) / tpl, bs = 256;
+        const uint32_t hpl = tpl_forced ? 2u * (uint32_t)tpl : (2 * ma.n_terms + lpp0 - 1) / lpp0;
+        const uint32_t lpp = (2 * ma.n_terms + hpl - 1) / hpl;
         const uint32_t per_block = bs / lpp, blocks = (n + per_block - 1) / per_block;
-        if (tpl == 2) hipLaunchKernelGGL(k_g1_msm_multi2, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
-        else if (tpl == 3) hipLaunchKernelGGL(k_g1_msm_multi3, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
-        else hipLaunchKernelGGL(k_g1_msm_multi4, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
-        return 16 + (uint32_t)tpl;   // reported as msm_lanes_per_term: 18 / 20 = two / four terms per lane
+        hipLaunchKernelGGL(k_g1_msm_multi, dim3(blocks), dim3(bs), (size_t)bs * 172, st, d, ma, n, per_block, hpl, scalars, pts, tabws);
+        return 16 + (hpl + 1) / 2;   // reported as msm_lanes_per_term: 18 / 19 / 20 = up to two / three / four terms' halves per lane
     }
     return launch_msm_ladders(d, ma, n, msm_ladder_shape(ma.n_terms, n, 0.0, ma.pt_tab != nullptr && !ma.skip), scalars, pts, tabws, st);
 }

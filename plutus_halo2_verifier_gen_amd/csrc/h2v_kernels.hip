@@ -938,16 +938,20 @@ k_g1_msm_fixed(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block /*
 }
 
 
-// Several terms per lane (K = 2, 4): the K x 2 GLV halves of a lane's terms share ONE accumulator and therefore the 128
-// doublings - per term 128 / K doublings + 66 mixed additions instead of 128 + 66 (K = 2: 26 % fewer multiply-adds per
-// proof, K = 4: 39 %), on 1 / K of the waves with a chain (128 x 7 + K x 66 x 11) / 1622 as long.  It loses when the launch
+// Several GLV halves per lane (H = 4 .. 8: two to four terms): the halves a lane carries share ONE accumulator and therefore the
+// 128 doublings - per lane 128 doublings + 33 H mixed additions instead of one ladder per half (H = 4: 26 % fewer multiply-adds
+// per proof, H = 8: 39 %), on 2 / H of the waves with a chain (128 x 7 + 33 H x 11) / 1622 as long.  It loses when the launch
 // is alone on the chip (half or a quarter of the SIMDs get a wave) and wins when other kernels fill them: several steps in
 // flight, where the step time is the instruction count.  Non-recursive plans with prebuilt tables.
+// The proof's 2 T halves are dealt out H per lane in order (half hh = 2 term + glv half): lanes of one proof differ by at most
+// the last one's load, and no lane waits through addition slots of halves it does not have - with whole terms per lane ten terms
+// on four lanes were 3 + 3 + 3 + 1 and every wave ran six addition slots per window for five halves per lane on average.
 // One accumulator over DIFFERENT points has no lattice argument against exceptional additions (crafted proofs can make
 // P_2 = [m] P_1), so the ladder runs unchecked and is judged once at the end: an exceptional addition or doubling leaves
 // Z = 0, which every later Z inherits; such a lane (never an honest one) redoes its ladder with the complete group law.
-template <int K, bool COMPLETE>
-H2V_DN void msm_multi_ladder(G1J28 &out, bool &out_inf, const int8_t (&dg)[2 * K][33], const uint32_t *const (&tab)[2 * K]) {
+#define MSM_MAX_HALVES 8
+template <bool COMPLETE>
+H2V_DN void msm_multi_ladder(G1J28 &out, bool &out_inf, const int8_t (&dg)[MSM_MAX_HALVES][33], const uint32_t *const (&tab)[MSM_MAX_HALVES], const int H) {
     G1J28 lad;
     bool lad_inf = true;
 #pragma unroll 1
@@ -957,7 +961,7 @@ H2V_DN void msm_multi_ladder(G1J28 &out, bool &out_inf, const int8_t (&dg)[2 * K
             for (int rep = 0; rep < 4; rep++) g1j28_dbl_t<true>(lad, lad);
         }
 #pragma unroll 1
-        for (int h = 0; h < 2 * K; h++) {
+        for (int h = 0; h < H; h++) {
             const int d = dg[h][q];
             if (d == 0) continue;
             const uint32_t *ent = tab[h] + ((d < 0 ? -d : d) - 1) * 28;
@@ -983,22 +987,21 @@ H2V_DN void msm_multi_ladder(G1J28 &out, bool &out_inf, const int8_t (&dg)[2 * K
     out = lad;
     out_inf = lad_inf;
 }
-template <int K>
-H2V_DI void msm_multi_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, uint32_t per_block,
+H2V_DI void msm_multi_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, uint32_t per_block, const uint32_t H,
                            const uint32_t *__restrict__ scalars, const uint32_t *__restrict__ pts, uint32_t *red) {
     const uint32_t tid = threadIdx.x, bs = blockDim.x;
-    const uint32_t lanes_per_proof = (ma.n_terms + K - 1) / K;
+    const uint32_t lanes_per_proof = (2 * ma.n_terms + H - 1) / H;
     const uint32_t seg = tid / lanes_per_proof, sub = tid - seg * lanes_per_proof;
     const uint32_t i = blockIdx.x * per_block + seg;
     const bool active = seg < per_block && i < n;
     G1J28 lad;
     bool lad_inf = true;
     if (active) {
-        int8_t dg[2 * K][33];
-        const uint32_t *tab[2 * K];
+        int8_t dg[MSM_MAX_HALVES][33];
+        const uint32_t *tab[MSM_MAX_HALVES];
 #pragma unroll 1
-        for (int j = 0; j < K; j++) {
-            const uint32_t term = sub * K + j;
+        for (uint32_t j = 0; j < H; j++) {
+            const uint32_t hh = sub * H + j, term = hh >> 1, h = hh & 1;
             bool use = term < ma.n_terms;
             const uint32_t tt = use ? term : 0u;
             const uint32_t kind = ma.terms[2 * (ma.term_base + tt)], idx = ma.terms[2 * (ma.term_base + tt) + 1];
@@ -1012,30 +1015,26 @@ H2V_DI void msm_multi_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_
             for (int k = 0; k < 8; k++) { s[k] = sp[k]; any_s |= s[k]; }
             use = use && any_b != 0 && any_s != 0;       // the point at infinity / a zero scalar contribute nothing
             uint32_t k1[4], k2[4];
-            glv_split(k1, k2, s);
+            glv_split(k1, k2, s);                        // (a term whose halves sit in two lanes is split in both)
             const uint32_t *t0 = is_vk ? ma.vk_tab + (size_t)idx * 448 : ma.pt_tab + ((size_t)i * ma.slots + idx) * 448;
-            tab[2 * j] = t0;
-            tab[2 * j + 1] = t0 + 224;
+            tab[j] = t0 + h * 224;
+            uint32_t carry = 0;
 #pragma unroll 1
-            for (int h = 0; h < 2; h++) {
-                uint32_t carry = 0;
-#pragma unroll 1
-                for (int q = 0; q < 32; q++) {
-                    const uint32_t kw = h ? k2[q >> 3] : k1[q >> 3];
-                    uint32_t d = ((kw >> (4 * (q & 7))) & 15u) + carry;
-                    carry = d > 8 ? 1u : 0u;
-                    dg[2 * j + h][q] = use ? (int8_t)(carry ? (int)d - 16 : (int)d) : (int8_t)0;
-                }
-                dg[2 * j + h][32] = use ? (int8_t)carry : (int8_t)0;
+            for (int q = 0; q < 32; q++) {
+                const uint32_t kw = h ? k2[q >> 3] : k1[q >> 3];
+                uint32_t d = ((kw >> (4 * (q & 7))) & 15u) + carry;
+                carry = d > 8 ? 1u : 0u;
+                dg[j][q] = use ? (int8_t)(carry ? (int)d - 16 : (int)d) : (int8_t)0;
             }
+            dg[j][32] = use ? (int8_t)carry : (int8_t)0;
         }
-        msm_multi_ladder<K, false>(lad, lad_inf, dg, tab);
+        msm_multi_ladder<false>(lad, lad_inf, dg, tab, (int)H);
         if (!lad_inf) {
             Fp zc;
             F28 z = lad.z;
             f28_carry(z);
             f28_to_fp(zc, z);
-            if (fp_is_zero(zc)) msm_multi_ladder<K, true>(lad, lad_inf, dg, tab);   // crafted points only
+            if (fp_is_zero(zc)) msm_multi_ladder<true>(lad, lad_inf, dg, tab, (int)H);   // crafted points only
         }
     }
     // reduction over the lanes of each proof (as in msm_body: lazy field, complete additions)
@@ -1080,25 +1079,11 @@ H2V_DI void msm_multi_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_
     }
 }
 extern "C" __global__ void __launch_bounds__(256, 2)
-k_g1_msm_multi2(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, const uint32_t *__restrict__ scalars,
-                const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
+k_g1_msm_multi(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, uint32_t halves_per_lane, const uint32_t *__restrict__ scalars,
+               const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
     extern __shared__ uint32_t red[];
     (void)tabws;
-    msm_multi_body<2>(plan, ma, n, per_block, scalars, pts, red);
-}
-extern "C" __global__ void __launch_bounds__(256, 2)
-k_g1_msm_multi4(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, const uint32_t *__restrict__ scalars,
-                const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
-    extern __shared__ uint32_t red[];
-    (void)tabws;
-    msm_multi_body<4>(plan, ma, n, per_block, scalars, pts, red);
-}
-extern "C" __global__ void __launch_bounds__(256, 2)
-k_g1_msm_multi3(H2vDevPlan plan, H2vMsmArgs ma, uint32_t n, uint32_t per_block, const uint32_t *__restrict__ scalars,
-                const uint32_t *__restrict__ pts, uint32_t *__restrict__ tabws) {
-    extern __shared__ uint32_t red[];
-    (void)tabws;
-    msm_multi_body<3>(plan, ma, n, per_block, scalars, pts, red);
+    msm_multi_body(plan, ma, n, per_block, halves_per_lane, scalars, pts, red);
 }
 
 // er += er_fix (complete Jacobian addition, one lane per proof): joins the two launches of a split MSM

@@ -221,7 +221,7 @@ def test_verdicts_do_not_depend_on_the_chunking(be, circuits, name):
 
 
 def test_in_flight_hint_changes_the_shape_not_the_verdicts(be, circuits):
-    """h2v_workspace_hint_in_flight(>= 4): the per-proof MSM runs two terms per lane (k_g1_msm_multi2, reported as 18) -
+    """h2v_workspace_hint_in_flight(>= 4): the per-proof MSM runs two terms per lane (k_g1_msm_multi with four halves per lane, reported as 18) -
     the accept vector and the statuses stay those of the default shape."""
     from plutus_halo2_verifier_gen_amd import synth
     for name in ("simple_mul", "lookup_table", "atms_with_lookups"):   # (atms at 2048+ proofs: ladders beside a fixed-base launch)
