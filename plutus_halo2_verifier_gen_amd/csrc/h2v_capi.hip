@@ -941,7 +941,13 @@ static uint32_t launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *
                            const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st, uint32_t in_flight_hint = 1) {
     static const int impl = []() { const char *e = getenv("H2V_PAIRING"); return (e && strcmp(e, "legacy") == 0) ? 0 : 1; }();
     const double S = msm_n_simd();
-    const bool prefer_narrow = in_flight_hint >= 4 ? (double)n >= 2.0 * S : ((double)n > 2.0 * S && (double)n <= 4.0 * S);
+    // Eight or more batches in flight (the library's lanes): the chip is full whatever one launch brings, so the engine with the
+    // fewest instructions that still has waves to spread wins much earlier - wide (2 x the normal engine's instructions) only up
+    // to #SIMDs / 16 proofs, narrow from #SIMDs / 4.  ms per batch, wide / normal / narrow: secp256k1 shape x 64 0.55 / 0.58 / 0.63;
+    // sha256 shape x 128 0.67 / 0.66 / 0.72; x 256 1.15 / 1.08 / 1.06; x 512 1.61 / 1.43 / 1.47; secp256k1 x 512 1.67 / 1.57 / 1.55;
+    // simple_mul x 512 1.02 / 0.88 / 0.84; x 1024 - / 1.47 / 1.39; sha256 x 1024 - / 2.19 / 2.16.
+    const bool many = in_flight_hint >= 8;
+    const bool prefer_narrow = many ? (double)n >= S / 4.0 : in_flight_hint >= 4 ? (double)n >= 2.0 * S : ((double)n > 2.0 * S && (double)n <= 4.0 * S);
     // (the wide engine issues twice the instructions of the normal one: a caller that keeps the chip full takes it only up to
     // #SIMDs / 2 proofs - sha256 shape x 1024, four in flight: wide 3.18, normal 2.98, narrow 3.12 ms per step; secp256k1 x 512:
     // wide 2.37, normal 2.47, narrow 2.64)
@@ -951,7 +957,7 @@ static uint32_t launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *
     // 4.06 -> 3.88 with six batches in flight, 3.76 with eight; below that size its few long waves lose: lookup_table x 2048
     // 3.48 -> 3.65, atms x 2048 3.92 -> 5.10.
     return launch_pairing_impl(impl, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, st, nullptr, prefer_narrow,
-                               in_flight_hint >= 4 ? S / 2.0 : S, in_flight_hint >= 4 && (double)n >= 4.0 * S);
+                               many ? S / 16.0 : in_flight_hint >= 4 ? S / 2.0 : S, in_flight_hint >= 4 && (double)n >= 4.0 * S);
 }
 
 // ---------------------------------------------------------------------------------------------- pipeline
