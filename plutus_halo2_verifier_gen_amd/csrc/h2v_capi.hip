@@ -834,7 +834,9 @@ static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint
     // (only launches of at least a quarter of a wave per SIMD at one lane per term: below that the launch is a chain of lone
     //  waves whatever else is in flight, and the two-lanes-per-term ladder is the shortest chain - sha256 shape x 128 with six
     //  shares in flight: MSM 2.5 ms -> 1.4 ms alone)
-    const bool fills = (double)n * ma.n_terms / 64.0 >= msm_n_simd() / 4.0;
+    // (eight or more batches in flight: from an eighth - sha256 / secp256k1 shape x 256, sixteen shares in flight: 1.05 / 1.08 ->
+    //  0.89 / 0.91 ms per share with two terms per lane; x 128 and x 64 stay with the shortest chain: 0.66 -> 0.74, 0.54 -> 0.64)
+    const bool fills = (double)n * ma.n_terms / 64.0 >= msm_n_simd() / (in_flight_hint >= 8 ? 8.0 : 4.0);
     const bool tpl_forced = getenv("H2V_MSM_TPL") != nullptr || g_opts.msm_tpl > 0;
     if (tpl > 1 && (fills || tpl_forced) && ma.pt_tab && !ma.skip && ma.grp_end[0] == ma.n_terms && ma.n_terms >= (uint32_t)tpl && ma.n_terms <= 256u * tpl) {
         // lanes per proof as for `tpl` whole terms per lane, then the proof's 2 T GLV halves dealt out evenly over them: ten terms
