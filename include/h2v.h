@@ -134,7 +134,7 @@ int h2v_workspace_set_option(h2v_workspace *ws, uint32_t option, int32_t value);
 int h2v_workspace_lanes(const h2v_workspace *ws, uint32_t *n_lanes, uint32_t *chunk);
 /* how many calls of n proofs each (rlc != 0: RLC mode) the workspace keeps in flight before a call has to wait for a lane:
  * the lanes that mode cycles through for chunks of that size (1 for a workspace that is not laned).  Per-proof mode: 8 lanes
- * with the decompression on a side stream, or - chunks that give the MSM less than a quarter wave per SIMD - all 16, each
+ * with the decompression on a side stream, or - chunks that give the MSM at most half a wave per SIMD - all 16, each
  * chunk on its lane's stream alone; RLC mode: all of them. */
 int h2v_workspace_depth(const h2v_workspace *ws, uint64_t n, int rlc, uint32_t *batches_in_flight);
 /* (new) Tuning hint: the caller keeps n_in_flight batches in flight on this device (each on its own workspace).  From 4 up

@@ -1147,16 +1147,17 @@ static const uint32_t *rlc_flags_of(const h2v_workspace *w);
 // and an explicit stagger - chunk c waiting for phase 1 of chunk c - 1 - measured 10-20 % slower.  rlc: every chunk is
 // its own batch check.
 // How many lanes a call of n proofs cycles through, and (per-proof mode) the streams of a chunk.  Chunks that give the MSM
-// less than a quarter wave per SIMD are chains of lone waves - latency, not issue slots - and want as many of them in flight
+// at most half a wave per SIMD are chains of lone waves - latency, not issue slots - and want as many of them in flight
 // as there are streams: every lane, each chunk on its lane's stream alone.  Larger chunks: H2V_PER_PROOF_LANES lanes, the
 // decompression on a side stream.  Measured (ms per batch; 8 lanes two streams each -> 16 lanes one stream each): secp256k1
-// shape x 64 0.87 -> 0.57, x 128 1.12 -> 0.74; sha256 shape x 128 0.94 -> 0.74, x 256 1.32 -> 1.18; sha256 x 512 1.64 -> 1.70
-// and up: worse.  An explicit lane count (h2v_workspace_create_lanes) is kept; H2V_OPT_STREAMS / H2V_LANE_ONE_STREAM force the streams.
+// shape x 64 0.87 -> 0.57, x 128 1.12 -> 0.74; sha256 shape x 128 0.94 -> 0.74, x 256 1.29 -> 0.90, x 512 1.45 -> 1.24, secp256k1
+// x 512 1.51 -> 1.34, simple_mul x 1024 1.48 -> 1.23; simple_mul x 2048 and sha256 x 1024: the same either way (2.16 / 2.18).
+// An explicit lane count (h2v_workspace_create_lanes) is kept; H2V_OPT_STREAMS / H2V_LANE_ONE_STREAM force the streams.
 static uint32_t laned_depth(const h2v_workspace *w, uint64_t n, bool rlc, int *stream_mode) {
     if (stream_mode) *stream_mode = 1;
     if (rlc) return w->n_lanes;
     const uint64_t m = n < w->chunk ? n : w->chunk;
-    const bool small = (double)m * w->lane_plan.n_terms / 64.0 <= msm_n_simd() / 4.0;
+    const bool small = (double)m * w->lane_plan.n_terms / 64.0 <= msm_n_simd() / 2.0;
     if (stream_mode) {
         static const int env_mode = []() { const char *e = getenv("H2V_LANE_ONE_STREAM"); return e ? atoi(e) : -1; }();
         *stream_mode = w->one_stream_mode >= 0 ? w->one_stream_mode : env_mode >= 0 ? env_mode : small ? 1 : 2;
