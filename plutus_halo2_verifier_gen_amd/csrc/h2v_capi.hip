@@ -698,6 +698,10 @@ static int ws_streams(h2v_workspace *w, int k, bool need_main, bool need_side, b
     return H2V_OK;
 }
 
+// launch-shape options of the workspace a call runs on (h2v_workspace_set_option): the launchers below run on the calling
+// host thread, inside run_pipeline / run_rlc, which set this for their duration
+struct LaunchOptions { int msm_tpl = 0, pairing = 0; uint32_t in_flight = 1; };
+static thread_local LaunchOptions g_opts;
 // Transcript + combiner launch.  A block is one wave; its 64 lanes are P proofs x L lanes per proof (the plan's
 // bundles have L records), the Fr register file of the P proofs lives in LDS (160 KB per CU).  A single-lane plan whose
 // register file does not fit 64 proofs runs P = 32 / 16 / 8 proofs per block with the other lanes idle, or - below 8 -
@@ -716,7 +720,11 @@ static int launch_vm(const H2vDevPlan &d0, uint32_t n, uint32_t stride, const ui
     static const int env_wide = []() { const char *e = getenv("H2V_VM_WIDE"); return e ? atoi(e) : -1; }();
     H2vDevPlan d = d0;
     const bool wide_ok = d.wide_lanes && !trace;
-    const bool wide = wide_ok && (env_wide >= 0 ? env_wide != 0 : ((uint64_t)n * d.wide_lanes + 63) / 64 <= 256);
+    // (eight or more batches in flight: the chip is full anyway and the wide schedule's extra instructions count - only launches
+    //  of at most 32 waves take it.  ms per batch, wide -> narrow schedule: sha256 shape x 128 0.66 -> 0.69, x 256 0.88 -> 0.84,
+    //  x 512 1.22 -> 1.18, x 1024 2.16 -> 2.00; secp256k1 shape x 64 0.54 -> 0.56, x 512 1.32 -> 1.16)
+    const uint64_t wide_waves = ((uint64_t)n * d.wide_lanes + 63) / 64;
+    const bool wide = wide_ok && (env_wide >= 0 ? env_wide != 0 : wide_waves <= (g_opts.in_flight >= 8 ? 32u : 256u));
     if (wide) { d.vm_lanes = d.wide_lanes; d.n_regs = d.wide_n_regs; d.n_instr = d.wide_n_instr; d.instr = d.wide_instr; }
     uint32_t P = vm_lds_slots(d);
     if (P == 0) {
@@ -810,10 +818,6 @@ static uint32_t launch_msm_ladders(const H2vDevPlan &d, const H2vMsmArgs &ma, ui
 // Without the variable the caller's hint decides (h2v_workspace_hint_in_flight): a caller that keeps >= 4 batches in flight is
 // bound by the instructions issued, not by chain length, and two terms per lane issue 26 % fewer multiply-adds per proof
 // (measured, simple_mul x 4096: 5 in flight 5.12 -> 4.66 ms per step; with 3 in flight 5.04 -> 5.01).
-// launch-shape options of the workspace a call runs on (h2v_workspace_set_option): the launchers below run on the calling
-// host thread, inside run_pipeline / run_rlc, which set this for their duration
-struct LaunchOptions { int msm_tpl = 0, pairing = 0; };
-static thread_local LaunchOptions g_opts;
 // Terms per lane of the ladder kernel for callers that keep the chip full: more terms per lane share more doublings and make
 // fewer, longer waves - as many as still leave the launch a quarter of a wave per SIMD (two at least).  ms per batch, eight
 // batches in flight, terms per lane 2 / 3 / 4: simple_mul x 4096 (10 terms: 320 / 256 / 192 waves) 3.73 / 3.64 / 3.84;
@@ -969,7 +973,7 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
 static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst,
                         const uint8_t *ci, uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st,
                         h2v_timings *tm, bool want_trace) {
-    g_opts.msm_tpl = w->opt_msm_tpl; g_opts.pairing = w->opt_pairing;
+    g_opts.msm_tpl = w->opt_msm_tpl; g_opts.pairing = w->opt_pairing; g_opts.in_flight = w->in_flight_hint;
     struct Reset { ~Reset() { g_opts = LaunchOptions(); } } reset_opts;
     const uint32_t slots = H2V_SLOTS(d);
     const uint32_t vm_blocks = (n + 63) / 64;
@@ -1827,6 +1831,7 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     const H2vDevPlan &d = p->d;
     int rc = rlc_ensure(w, p);
     if (rc) return rc;
+    g_opts.msm_tpl = w->opt_msm_tpl; g_opts.pairing = w->opt_pairing; g_opts.in_flight = w->in_flight_hint;
     RlcWs *r = w->rlc;
     const uint32_t slots = H2V_SLOTS(d);
     hipEvent_t *ev = r->ring[r->calls % h2v_workspace::RING];
