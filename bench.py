@@ -544,10 +544,10 @@ def main():
                 return {"g1_msm": {18: "k_g1_msm_multi", 19: "k_g1_msm_multi", 20: "k_g1_msm_multi", 1: "k_g1_msm_merged", 8: "k_g1_msm_quad"}.get(lpt_code, "k_g1_msm"),
                         "g1_msm_fixed": "k_g1_msm_fixed",
                         "g1_decompress": dec_name, "transcript_combiner": vm_name,
-                        "pairing": {6: "k_pairing_six", 16: "k_pairing_coop_narrow", 64: "k_pairing_coop_wide", 1: "k_pairing_check"}.get(lanes, "k_pairing_coop")}
+                        "pairing": {6: "k_pairing_six", 12: "k_pairing_coop_twelve", 16: "k_pairing_coop_narrow", 64: "k_pairing_coop_wide", 1: "k_pairing_check"}.get(lanes, "k_pairing_coop")}
             kname = shape_names(shape, pair_lanes)
             # lanes per coefficient 1 / 2 / 4 (narrow / normal / wide engine): a lane multiplies 1/nq of a coefficient's terms and reduces once
-            nq = {16: 1, 64: 4}.get(pair_lanes, 2)
+            nq = {12: 1, 16: 1, 64: 4}.get(pair_lanes, 2)
             pairing_lane = sum(calls * ((terms // nq) * 196 + 196) for calls, terms in ((35, 12), (63, 8), (315, 4), (136, 6)))
             if pair_lanes == 6:
                 # six lanes per proof (csrc/h2v_pairing_six.hpp): a lane owns an Fp2 coefficient; MUL / SQR / LINE are 6 / 4 / 3
@@ -572,7 +572,10 @@ def main():
                           else (B * T_lad * 8 * 33 * 18 * MAD_MUL + B * (lpt * T_lad - 1) * MAD_ADD + B * 3 * MAD_MUL) if quad  # every lane of a quad runs each level's multiplication
                           else B * T_lad * lpt * msm_lane + B * (lpt * T_lad - 1) * MAD_ADD + B * 3 * MAD_MUL,
                 "g1_msm_fixed": B * n_fix_terms * 65 * MAD_MADD + B * n_fix_terms * MAD_ADD,
-                "pairing": -(-B // 10) * 64 * pairing_lane if pair_lanes == 6 else B * (1 if pair_lanes == 1 else pair_lanes) * pairing_lane,
+                # (twelve lanes per proof: the narrow engine's per-lane program + per Miller round one product and reduction for the
+                #  line products; five proofs on the 64 lanes of a wave)
+                "pairing": -(-B // 10) * 64 * pairing_lane if pair_lanes == 6 else -(-B // 5) * 64 * (pairing_lane + 68 * 2 * 196) if pair_lanes == 12
+                           else B * (1 if pair_lanes == 1 else pair_lanes) * pairing_lane,
                 "g1_decompress": B * slots * (377 * MAD_SQR + 86 * MAD_MUL + 126 * MAD_DBL + 10 * MAD_ADD + tab_point),
                 "transcript_combiner": B * sum(128 for ins in pl.instrs if ins[0] == PL.OP_MUL),
             }

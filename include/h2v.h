@@ -70,8 +70,8 @@ typedef struct {
     uint32_t launches;
     uint32_t msm_lanes_per_term;
     uint32_t pairing_lanes_per_proof;   /* 32: two proofs per wave; 64: the wide engine (small launches); 16: the narrow one (four
-                                         * proofs per wave); 6: ten proofs per wave, a whole Fp2 coefficient per lane (Karatsuba terms: fewest instructions, for
-                                         * full chips); 1: the one-lane cross-check kernel */
+                                         * proofs per wave); 12: the narrow engine packed five proofs to a wave; 6: ten proofs per wave, a whole Fp2 coefficient
+                                         * per lane (Karatsuba terms: fewest instructions, for full chips); 1: the one-lane cross-check kernel */
     /* (round 3) msm_lanes_per_term == 3: the MSM ran as TWO kernels side by side - g1_msm_ms is the ladder launch over the
      * per-proof terms (its shape: msm_var_lanes_per_term, coded like msm_lanes_per_term), g1_msm_fixed_ms the fixed-base
      * launch over the VK-base terms; 0 otherwise */
@@ -127,7 +127,7 @@ int h2v_workspace_join(h2v_workspace *ws, void *stream);
  * depend on them - tests/test_gpu_parity.py::test_workspace_options_change_the_shape_not_the_verdicts).  value 0 = the
  * launcher's own choice (DESIGN.md sections 4.1, 4.2, 6). */
 #define H2V_OPT_MSM_TERMS_PER_LANE 1u /* per-proof MSM: 1 .. 4 terms per lane on one accumulator (shared doublings) */
-#define H2V_OPT_PAIRING_ENGINE 2u     /* lanes per proof of the pairing kernel: 6 (ten proofs per wave), 16 (narrow), 32, 64 (wide), 1 (the one-lane cross-check kernel) */
+#define H2V_OPT_PAIRING_ENGINE 2u     /* lanes per proof of the pairing kernel: 6 (ten proofs per wave), 12 (five), 16 (narrow: four), 32, 64 (wide), 1 (the one-lane cross-check kernel) */
 #define H2V_OPT_STREAMS 3u            /* -1 auto, 0: three library streams per call, 1: everything on the caller's stream, 2: + one side stream */
 int h2v_workspace_set_option(h2v_workspace *ws, uint32_t option, int32_t value);
 /* lanes and chunk size of a workspace (1 lane = not laned) */

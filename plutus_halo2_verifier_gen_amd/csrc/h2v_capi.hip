@@ -581,7 +581,7 @@ extern "C" int h2v_workspace_set_option(h2v_workspace *ws, uint32_t option, int3
         else if (option == H2V_OPT_STREAMS) w->one_stream_mode = value;
     };
     if (option == H2V_OPT_MSM_TERMS_PER_LANE) { if (value < 0 || value > 4) return fail(H2V_E_ARG, "terms per lane: 0 (auto) .. 4"); }
-    else if (option == H2V_OPT_PAIRING_ENGINE) { if (value != 0 && value != 1 && value != 6 && value != 16 && value != 32 && value != 64) return fail(H2V_E_ARG, "pairing engine: 0 (auto), 6, 16, 32, 64 lanes per proof, or 1 (the one-lane cross-check kernel)"); }
+    else if (option == H2V_OPT_PAIRING_ENGINE) { if (value != 0 && value != 1 && value != 6 && value != 12 && value != 16 && value != 32 && value != 64) return fail(H2V_E_ARG, "pairing engine: 0 (auto), 6, 12, 16, 32, 64 lanes per proof, or 1 (the one-lane cross-check kernel)"); }
     else if (option == H2V_OPT_STREAMS) { if (value < -1 || value > 2) return fail(H2V_E_ARG, "streams: -1 (auto), 0 (three), 1 (the caller's), 2 (the caller's + one for the decompression)"); }
     else return fail(H2V_E_ARG, "unknown option");
     apply(ws);
@@ -914,7 +914,7 @@ static void launch_ivc_fold(const H2vDevPlan &d, uint32_t n, const uint32_t *pts
 // kernel stays as a cross-check (H2V_PAIRING=legacy, or impl = 0 in the probe).
 static uint32_t launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
                                 const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st, const uint32_t *skip = nullptr,
-                                bool prefer_narrow = false, double wide_up_to = -1.0, bool prefer_six = false) {
+                                bool prefer_narrow = false, double wide_up_to = -1.0, bool prefer_six = false, bool prefer_twelve = false) {
     if (wide_up_to < 0) wide_up_to = msm_n_simd();
     // The WIDE engine (one proof per wave, four lanes per coefficient: 3 / 2 / 1 terms per lane and call instead of 6 / 4 / 2)
     // when even one wave per proof leaves SIMDs free: n <= #SIMDs.  Above that the two-proofs-per-wave kernel does less
@@ -923,13 +923,19 @@ static uint32_t launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, c
     static const int env_narrow = []() { const char *e = getenv("H2V_PAIRING_NARROW"); return e ? atoi(e) : -1; }();
     static const int env_six = []() { const char *e = getenv("H2V_PAIRING_SIX"); return e ? atoi(e) : -1; }();
     // impl 2 / 3 / 5 (probe): the narrow / the wide / the six-lane kernel whatever n
-    if (impl == 1 && g_opts.pairing) impl = g_opts.pairing == 1 ? 0 : g_opts.pairing == 16 ? 2 : g_opts.pairing == 64 ? 3 : g_opts.pairing == 6 ? 5 : 4;   // 4: the two-proofs-per-wave engine
+    static const int env_twelve = []() { const char *e = getenv("H2V_PAIRING_TWELVE"); return e ? atoi(e) : -1; }();
+    if (impl == 1 && g_opts.pairing) impl = g_opts.pairing == 1 ? 0 : g_opts.pairing == 16 ? 2 : g_opts.pairing == 64 ? 3 : g_opts.pairing == 6 ? 5 : g_opts.pairing == 12 ? 6 : 4;   // 4: the two-proofs-per-wave engine
     if (impl == 5 || (impl == 1 && !skip && (env_six > 0 || (env_six < 0 && prefer_six)))) {
         hipLaunchKernelGGL(k_pairing_six, dim3((n + SIX_GROUPS - 1) / SIX_GROUPS), dim3(64), SIX_LDS_BYTES, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
         return 6u;
     }
-    const bool wide = !skip && impl != 2 && impl != 4 && (impl == 3 || (env_wide >= 0 ? env_wide != 0 : (double)n <= wide_up_to));
+    const bool wide = !skip && impl != 2 && impl != 4 && impl != 6 && (impl == 3 || (env_wide >= 0 ? env_wide != 0 : (double)n <= wide_up_to));
     const bool narrow = !skip && !wide && impl != 4 && (impl == 2 || env_narrow > 0 || (env_narrow < 0 && prefer_narrow));
+    // the narrow engine packed five proofs to a wave (impl 6, option 12, H2V_PAIRING_TWELVE = 0 / 1): wherever the narrow one would run
+    if (impl == 6 || (narrow && impl != 2 && env_twelve != 0 && (env_twelve > 0 || prefer_twelve))) {
+        hipLaunchKernelGGL(k_pairing_coop_twelve, dim3((n + COOP_GROUPS_TWELVE - 1) / COOP_GROUPS_TWELVE), dim3(64), COOP_LDS_BYTES(COOP_GROUPS_TWELVE), st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
+        return 12u;
+    }
     if (impl == 0) { hipLaunchKernelGGL(k_pairing_check, dim3((n + 63) / 64), dim3(64), 0, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg); return 1; }
     else if (wide) hipLaunchKernelGGL(k_pairing_coop_wide, dim3(n), dim3(64), COOP_LDS_BYTES(1), st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
     else if (narrow) hipLaunchKernelGGL(k_pairing_coop_narrow, dim3((n + 3) / 4), dim3(64), COOP_LDS_BYTES(COOP_GROUPS_NARROW), st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
@@ -952,6 +958,9 @@ static uint32_t launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *
     // to #SIMDs / 16 proofs, narrow from #SIMDs / 4.  ms per batch, wide / normal / narrow: secp256k1 shape x 64 0.55 / 0.58 / 0.63;
     // sha256 shape x 128 0.67 / 0.66 / 0.72; x 256 1.15 / 1.08 / 1.06; x 512 1.61 / 1.43 / 1.47; secp256k1 x 512 1.67 / 1.57 / 1.55;
     // simple_mul x 512 1.02 / 0.88 / 0.84; x 1024 - / 1.47 / 1.39; sha256 x 1024 - / 2.19 / 2.16.
+    // ... and where the narrow engine would run, its twelve-lane packing (five proofs per wave instead of four with four idle lanes
+    // each; the line products in a pass of their own): ms per batch, narrow -> twelve: sha256 shape x 1024 1.99 -> 1.96, secp256k1 x 512
+    // 1.21 -> 1.17, lookup_table x 2048 3.26 -> 3.16, atms x 2048 3.40 -> 3.34, simple_mul x 1024 1.24 -> 1.17.
     const bool many = in_flight_hint >= 8;
     const bool prefer_narrow = many ? (double)n >= S / 4.0 : in_flight_hint >= 4 ? (double)n >= 2.0 * S : ((double)n > 2.0 * S && (double)n <= 4.0 * S);
     // (the wide engine issues twice the instructions of the normal one: a caller that keeps the chip full takes it only up to
@@ -963,7 +972,7 @@ static uint32_t launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *
     // 4.06 -> 3.88 with six batches in flight, 3.76 with eight; below that size its few long waves lose: lookup_table x 2048
     // 3.48 -> 3.65, atms x 2048 3.92 -> 5.10.
     return launch_pairing_impl(impl, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, st, nullptr, prefer_narrow,
-                               many ? S / 16.0 : in_flight_hint >= 4 ? S / 2.0 : S, in_flight_hint >= 4 && (double)n >= 4.0 * S);
+                               many ? S / 16.0 : in_flight_hint >= 4 ? S / 2.0 : S, in_flight_hint >= 4 && (double)n >= 4.0 * S, many);
 }
 
 // ---------------------------------------------------------------------------------------------- pipeline

@@ -31,6 +31,7 @@
 #define COOP_GROUP_DW (COOP_GROUP_SLOTS * COOP_SLOT_DW)   // (padding the group stride by 4 / 8 / 16 dwords changed nothing: 2.653-2.662 ms)
 #define COOP_GROUPS_PER_WAVE 2               // the normal kernel; the narrow one has 4 (COOP_GROUPS_NARROW), the wide one 1
 #define COOP_GROUPS_NARROW 4
+#define COOP_GROUPS_TWELVE 5
 #define COOP_TAB_DW ((16 * 2 * COOP_N_MUL_TERMS + 2 * 16 * 2 * COOP_N_LINE_TERMS + 16 * 2 * COOP_N_CSQR_TERMS + 16 * 2 * COOP_N_SQR_TERMS) / 4)  // operand tables, copied at start
 
 // File-scope LDS so that every device function addresses it as LDS (ds_read/ds_write), not through flat pointers; sized
@@ -60,6 +61,10 @@ struct Coop {
     // both staging roles (both = true, h = 0).
     int q, nq;
     bool both;
+    // TWELVE kernel (five proofs per wave): the narrow engine without its four idle lanes per proof - a group is 12 lanes, one per
+    // coefficient; lanes 60..63 of the wave play spare lanes of the last group and never store.  No lane is left over for the next
+    // line's products (-lambda) xP: lanes 0..7 of a group take the eight of a round in a pass of their own before its two line steps.
+    bool twelve;
 };
 
 H2V_DI uint32_t *coop_slot(const Coop &c, int s) {
@@ -211,6 +216,37 @@ H2V_DI F28 coop_engine(const Coop &c, const int tab_row_byte) {
     return f28_unpack(z.a, z.b, z.c, z.d);
 }
 
+// one product of two staged slots, reduced (< 2p): the twelve-lane kernel's line products
+H2V_DN F28Regs coop_prod(const Coop c, const int xs, const int ys) {
+    uint32_t x[14], y[14];
+    coop_load28_pair(x, y, coop_slot(c, xs), coop_slot(c, ys));
+    uint64_t acc[28];
+#pragma unroll
+    for (int i = 0; i < 14; i++)
+#pragma unroll
+        for (int j = 0; j < 14; j++) {
+            if (i == 0 || j == 13) acc[i + j] = (uint64_t)x[i] * y[j];
+            else acc[i + j] += (uint64_t)x[i] * y[j];
+        }
+    acc[27] = 0;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        const uint32_t m = ((uint32_t)acc[k] * FP_N0_28) & FP28_MASK;
+#pragma unroll
+        for (int j = 0; j < 14; j++) acc[k + j] += (uint64_t)m * FP_MOD28[j];
+        acc[k + 1] += acc[k] >> 28;
+    }
+    F28 r;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        carry += acc[14 + k];
+        r.l[k] = (uint32_t)carry & FP28_MASK;
+        carry >>= 28;
+    }
+    r.l[13] = (uint32_t)(carry + acc[27]);
+    return f28_pack(r);
+}
 H2V_DI F28 coop_shfl_xor1(const F28 &a) {
     F28 r;
 #pragma unroll
@@ -376,7 +412,7 @@ H2V_DI F28 coop_line(const Coop &c, const F28 &f) {
     __syncthreads();
     const F28 r = coop_engine<COOP_N_LINE_TERMS, false>(c, (LOOP == 1 ? COOP_TAB_LINE1_B : COOP_TAB_LINE2_B) + c.g * 2 * COOP_N_LINE_TERMS);
     __syncthreads();
-    if (c.g >= 12 && c.h == 0) coop_store28(coop_slot(c, (LOOP == 1 ? COOP_SLOT_T2 : COOP_SLOT_T1) + (c.g - 12)), r);
+    if (c.g >= 12 && c.h == 0 && !c.twelve) coop_store28(coop_slot(c, (LOOP == 1 ? COOP_SLOT_T2 : COOP_SLOT_T1) + (c.g - 12)), r);
     return r;
 }
 // 1/f for a distributed f: N = f * conj(f) lies in Fp6 (even powers of w); lane 0 inverts it with the tower code
@@ -438,23 +474,27 @@ H2V_DI F28 coop_inv(const Coop &c, const F28 &f, bool &ok) {
 // big-integer pairing by tools/gen_coop_program.py).  Fp12 variables live in a private array, so no vector state is
 // live across the engine call (the first version kept them in VGPRs and spent 65 % of its wave-cycles waiting on
 // the spills around every call).
-template <bool WIDE, bool NARROW = false>
+template <bool WIDE, bool NARROW = false, bool TWELVE = false>
 H2V_DI void pairing_coop_body(const H2vDevPlan &plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
                               const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac /* folded el (recursion) or NULL */,
                               uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg, const uint32_t bid,
                               bool *verdict_out = nullptr /* WIDE: the verdict, in every lane */) {
     static_assert(!(WIDE && NARROW), "one proof per wave, or four");
-    const int lane = threadIdx.x, grp = WIDE ? 0 : NARROW ? lane >> 4 : lane >> 5;
+    static_assert(!TWELVE || NARROW, "the twelve-lane kernel is the narrow engine, packed");
+    const int lane = threadIdx.x;
+    const int grp12 = (lane * 43) >> 9;     // lane / 12 for lane < 64
+    const int grp = WIDE ? 0 : TWELVE ? (grp12 < COOP_GROUPS_TWELVE ? grp12 : COOP_GROUPS_TWELVE - 1) : NARROW ? lane >> 4 : lane >> 5;
     Coop c;
-    c.g = lane & 15;
+    c.g = TWELVE ? (grp12 < COOP_GROUPS_TWELVE ? lane - 12 * grp12 : 12 + (lane - 12 * COOP_GROUPS_TWELVE)) : lane & 15;
     c.h = NARROW ? 0 : (lane >> 4) & 1;
     c.both = NARROW;
+    c.twelve = TWELVE;
     c.nq = WIDE ? 4 : NARROW ? 1 : 2;
     c.q = WIDE ? c.h + 2 * (lane >> 5) : c.h;
     c.grp_off = COOP_GRP_OFF + grp * COOP_GROUP_DW;
-    const int leader = NARROW ? grp * 16 : grp * 32;  // lane (g = 0, h = 0) of the group
+    const int leader = TWELVE ? grp * 12 : NARROW ? grp * 16 : grp * 32;  // lane (g = 0, h = 0) of the group
     const bool is_leader = lane == leader;
-    const uint32_t i = WIDE ? bid : bid * (NARROW ? COOP_GROUPS_NARROW : COOP_GROUPS_PER_WAVE) + grp;
+    const uint32_t i = WIDE ? bid : bid * (TWELVE ? COOP_GROUPS_TWELVE : NARROW ? COOP_GROUPS_NARROW : COOP_GROUPS_PER_WAVE) + grp;
     const bool live = i < n;
     const uint32_t ii = live ? i : n - 1;  // dead groups shadow the last proof, never write
     const uint32_t slots = H2V_SLOTS(plan);
@@ -564,6 +604,23 @@ H2V_DI void pairing_coop_body(const H2vDevPlan &plan, uint32_t n, const uint32_t
                 const int steps = ((BLS_X_ABS >> bit) & 1) ? 2 : 1;
 #pragma unroll 1
                 for (int s2 = 0; s2 < steps; s2++, ln++) {
+                    if (TWELVE) {
+                        // both lines' constants, then the round's eight products (-lambda) xP in one pass: lane g < 8 takes
+                        // constant g & 3 (nl0, nl1, nxl0, nxl1) of loop 1 + (g >> 2)
+                        coop_stage_line(c, COOP_SLOT_LN1, plan.lines28_sg2, ln, lane);
+                        coop_stage_line(c, COOP_SLOT_LN2, plan.lines28_g2, ln, lane);
+                        __syncthreads();
+                        {
+                            const int lp = (c.g >> 2) & 1, which = c.g & 3;
+                            const F28Regs z = coop_prod(c, (lp ? COOP_SLOT_LN2 : COOP_SLOT_LN1) + which, lp ? COOP_SLOT_PX2 : COOP_SLOT_PX1);
+                            if (c.g < 8) coop_store28(coop_slot(c, (lp ? COOP_SLOT_T2 : COOP_SLOT_T1) + which), f28_unpack(z.a, z.b, z.c, z.d));
+                        }
+                        const F28 r1 = coop_line<1>(c, f);      // (its staging barrier covers the T slots)
+                        if (!skip1 && c.g < 12) f = r1;
+                        const F28 r2 = coop_line<2>(c, f);
+                        if (!skip2 && c.g < 12) f = r2;
+                        continue;
+                    }
                     if (ln > 0) coop_stage_line(c, COOP_SLOT_LN2, plan.lines28_g2, ln, lane);
                     __syncthreads();
                     const F28 r1 = coop_line<1>(c, f);
@@ -589,6 +646,7 @@ H2V_DI void pairing_coop_body(const H2vDevPlan &plan, uint32_t n, const uint32_t
             vars[d] = coop_conj(c, x);
         } break;
         case COOP_OP_WARMUP: {
+            if (TWELVE) break;       // (every round takes its own products)
             coop_stage_line(c, COOP_SLOT_LN1, plan.lines28_sg2, 0, lane);
             coop_stage_line(c, COOP_SLOT_LN2, plan.lines28_g2, 0, lane);
             __syncthreads();
@@ -627,7 +685,7 @@ H2V_DI void pairing_coop_body(const H2vDevPlan &plan, uint32_t n, const uint32_t
     if (c.g == 0) { Fp one; fp_set_one(one); mine = fp_eq(res, one); }
     else if (c.g < 12) mine = fp_is_zero(res);
     const unsigned long long bal = __ballot(mine);
-    const bool is_one = WIDE ? bal == ~0ull : NARROW ? ((bal >> leader) & 0xffffull) == 0xffffull : ((bal >> leader) & 0xffffffffull) == 0xffffffffull;
+    const bool is_one = WIDE ? bal == ~0ull : TWELVE ? ((bal >> leader) & 0xfffull) == 0xfffull : NARROW ? ((bal >> leader) & 0xffffull) == 0xffffull : ((bal >> leader) & 0xffffffffull) == 0xffffffffull;
     inv_ok = __shfl((int)inv_ok, leader) != 0;
     if (is_leader && live) {
         if (st == 0 && !(is_one && inv_ok)) st |= H2V_ST_PAIRING;
@@ -665,6 +723,13 @@ k_pairing_coop_narrow(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ 
                       const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac, uint32_t *__restrict__ status,
                       uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
     pairing_coop_body<false, true>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg, blockIdx.x);
+}
+// five proofs per wave: the narrow engine without its idle lanes (see Coop::twelve)
+extern "C" __global__ void __launch_bounds__(64, 2)
+k_pairing_coop_twelve(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
+                      const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac, uint32_t *__restrict__ status,
+                      uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
+    pairing_coop_body<false, true, true>(plan, n, pts, valid, valid_sub, er_jac, el_jac, status, accept, dbg, blockIdx.x);
 }
 // The single pairing of the RLC batch mode with its epilogue fused in.  flags[0]: batch check passed -> accept[i] = good_i for
 // the whole batch, and the kernels queued behind return at once; failed -> accept[] is left to them.  flags[1 + g] for the

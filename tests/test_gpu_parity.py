@@ -276,7 +276,7 @@ def test_workspace_options_change_the_shape_not_the_verdicts(be, circuits):
     ws = be.Workspace(dp, n)
     W = be.Workspace
     for tpl, lpt_code in ((1, None), (2, 18), (3, 19), (4, 20), (0, None)):
-        for engine in (6, 16, 32, 64, 1, 0):
+        for engine in (6, 12, 16, 32, 64, 1, 0):
             for streams in (0, 1, 2, -1):
                 ws.set_option(W.OPT_MSM_TERMS_PER_LANE, tpl)
                 ws.set_option(W.OPT_PAIRING_ENGINE, engine)
@@ -356,7 +356,7 @@ def test_pairing_cooperative_matches_one_lane_kernel(be, orc, circuits):
         p1.append(bls.g1_compress(A))
         p2.append(bls.g1_compress(bls.g1_mul(A, td.s) if k == 0 else bls.g1_mul(A, td.s + 1)))
     acc0, dump0 = be.probe_pairing_ex(dp, p1, p2, impl=0)
-    for impl in (1, 2, 3, 5):   # the launcher's choice (wide for 12 pairs), the narrow engine (16 lanes per proof), the wide one (64), six lanes per proof
+    for impl in (1, 2, 3, 5, 6):   # the launcher's choice (wide for 12 pairs), the narrow engine (16 lanes per proof), the wide one (64), six lanes per proof, twelve
         acc1, dump1 = be.probe_pairing_ex(dp, p1, p2, impl=impl)
         assert acc0 == acc1 == [1, 1, 0] * 3 + [1, 0, 0] + [1, 0], impl
         for i in range(len(p1)):

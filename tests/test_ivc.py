@@ -144,7 +144,7 @@ def test_ivc_fold_on_gpu(case):
     # every pairing engine takes the FOLDED left-hand point (el_jac), the six-lanes-per-proof one included (96 proofs: ten waves,
     # the last with four idle groups)
     ws = backend.Workspace(dp, mixed.n)
-    for engine in (6, 16, 32, 64):
+    for engine in (6, 12, 16, 32, 64):
         ws.set_option(backend.Workspace.OPT_PAIRING_ENGINE, engine)
         assert list(dp.verify_batch(mixed.proofs, mixed.proof_off, mixed.instances, None, ws=ws)) == mixed.expected, engine
         assert ws.timings().pairing_lanes_per_proof == engine
