@@ -615,7 +615,10 @@ def main():
             # The six-lane pairing engine packs ten proofs per wave: 4096 proofs are 410 waves on 1024 SIMDs, a chain of ~5 ms on
             # 40 % of the chip - its OWN duration is longer than a step by construction, and the line says that too.
             fits = kernel_ms[dominant] / launches <= elapsed / args.steps * 1e3 * 1.05
-            assert fits or not alone or B < 2048 or (dominant == "pairing" and pair_lanes == 6), (kernel_ms, elapsed / args.steps * 1e3)
+            consistent = fits or not alone or B < 2048 or (dominant == "pairing" and pair_lanes == 6)
+            # (one process per GPU: nothing else runs during the own-duration pass, and a violation is a bug.  With several ranks
+            #  the pass of another rank may share the device - the one-GPU rehearsal does - so the line records it instead)
+            assert consistent or world > 1, (kernel_ms, elapsed / args.steps * 1e3)
         result = {
             "metric": "halo2_proofs_verified_per_sec",
             "value": round(B_total * args.steps / elapsed, 2),
@@ -650,6 +653,7 @@ def main():
                                   "achieved": round(sum(mads.values()) / (elapsed / args.steps) / 1e12, 3), "peak": round(IMAD_PEAK_TOPS, 2) if IMAD_PEAK_TOPS else None,
                                   "unit": "T lane-mad/s", "frac": round(sum(mads.values()) / (elapsed / args.steps) / 1e12 / IMAD_PEAK_TOPS, 4) if IMAD_PEAK_TOPS else None},
             "batch_latency_ms": round(batch_latency_ms, 4),
+            "own_duration_pass_consistent": (consistent if args.mode != "rlc" else None),
             "pipelines_per_step": launches, "msm_lanes_per_term": msm_lpt, "msm_ladder_shape_of_a_split": var_lpt if msm_lpt == 3 else None, "pairing_lanes_per_proof": pair_lanes if args.mode == "per-proof" else None,
             "all_accepted": ok_all if timed_expected is None else None,
             "verdicts_as_expected_every_checked_step": ok_all,
