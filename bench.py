@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the accept gather out (rehearsals: what the collective costs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rlc-secondary", action="store_true", help="per-proof runs: skip the extra measurement of the RLC mode")
-    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="proofs the CPU baseline verifies (2048 x ~9 ms of one core each = ~20 core-seconds, ~1.2 s on the 16 threads)")
     ap.add_argument("--hint", type=int, default=0, help="h2v_workspace_hint_in_flight value (default: the steps in flight); the counter passes of "
                                                      "tools/scripts/profile_round.sh run one step at a time with the shapes of the timed run")
     ap.add_argument("--no-alone", action="store_true", help="skip the one-step-at-a-time pass (with --timed-only: the profiled command launches the timed steps only)")
