@@ -968,11 +968,12 @@ static uint32_t launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *
     // wide 2.37, normal 2.47, narrow 2.64)
     // The SIX-lane engine (ten proofs per wave, h2v_pairing_six.hpp: a quarter fewer instructions per pairing than the narrow
     // one, a chain almost twice as long) wherever a caller that keeps the chip full would take the narrow one
-    // from 4 * #SIMDs proofs up (410 waves; H2V_PAIRING_SIX = 0 / 1 forces the choice).  ms per step, narrow -> six: simple_mul x 4096
+    // from 4 * #SIMDs proofs up (410 waves; with eight or more batches in flight from 3 * #SIMDs: simple_mul x 3072 2.85 -> 2.69 ms per
+    // batch against the twelve-lane engine, x 2048 the same either way; H2V_PAIRING_SIX = 0 / 1 forces the choice).  ms per step, narrow -> six: simple_mul x 4096
     // 4.06 -> 3.88 with six batches in flight, 3.76 with eight; below that size its few long waves lose: lookup_table x 2048
     // 3.48 -> 3.65, atms x 2048 3.92 -> 5.10.
     return launch_pairing_impl(impl, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, st, nullptr, prefer_narrow,
-                               many ? S / 16.0 : in_flight_hint >= 4 ? S / 2.0 : S, in_flight_hint >= 4 && (double)n >= 4.0 * S, many);
+                               many ? S / 16.0 : in_flight_hint >= 4 ? S / 2.0 : S, in_flight_hint >= 4 && (double)n >= (many ? 3.0 : 4.0) * S, many);
 }
 
 // ---------------------------------------------------------------------------------------------- pipeline
