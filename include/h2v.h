@@ -140,8 +140,10 @@ int h2v_workspace_depth(const h2v_workspace *ws, uint64_t n, int rlc, uint32_t *
 /* (new) Tuning hint: the caller keeps n_in_flight batches in flight on this device (each on its own workspace).  From 4 up
  * the launcher prefers shapes that issue fewer instructions over shapes with shorter dependent chains (per-proof MSM: two
  * terms per lane on one accumulator; the narrow pairing engine from 2 x #SIMDs proofs; from 6 the whole per-proof pipeline on
- * the caller's stream; RLC mode: from 3 the one-stream form, as with H2V_RLC_ONE_STREAM).  Results do not depend on it.
- * Default 1. */
+ * the caller's stream; RLC mode: from 3 the one-stream form, as with H2V_RLC_ONE_STREAM; from 8 the thresholds of a chip that
+ * is full whatever one launch brings: DESIGN.md section 6.1).  Results do not depend on it.  Default 1.  A LANED workspace
+ * estimates it per call by itself - all its lanes when joins are deferred or host batches are streamed, otherwise the number
+ * of chunks of the call - unless this function was called: then the given value holds. */
 int h2v_workspace_hint_in_flight(h2v_workspace *ws, uint32_t n_in_flight);
 /* Per-kernel device times of a past call that used `ws` (calls_back = 0: the most recent; up to 63 back), from HIP
  * events recorded on the streams the kernels ran on.  Synchronise the launch stream before asking. */

@@ -77,6 +77,7 @@ struct h2v_plan {
 struct h2v_workspace {
     int device = 0;
     uint32_t in_flight_hint = 1;   // h2v_workspace_hint_in_flight: how many batches the caller keeps in flight on this device
+    bool hint_given = false;       // (laned: the caller said so itself; otherwise run_laned estimates it per call)
     uint64_t cap = 0;       // max batch
     uint32_t stride = 0;    // register-file stride (cap rounded up to 64)
     // what the buffers were sized for (the creating plan's shape): a plan fits iff each of its values is <= these
@@ -626,7 +627,7 @@ extern "C" void h2v_workspace_free(h2v_workspace *w) {
 extern "C" int h2v_workspace_hint_in_flight(h2v_workspace *ws, uint32_t n_in_flight) {
     if (!ws || n_in_flight == 0) return fail(H2V_E_ARG, "bad argument");
     ws->in_flight_hint = n_in_flight;
-    for (uint32_t l = 0; l < ws->n_lanes; l++) if (ws->lane[l]) ws->lane[l]->in_flight_hint = n_in_flight > ws->n_lanes ? n_in_flight : ws->n_lanes;
+    ws->hint_given = true;
     return H2V_OK;
 }
 
@@ -1194,6 +1195,10 @@ static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const
         if (c2 >= 2048 && c2 < chunk) chunk = c2;
     }
     const uint32_t nch = (n + chunk - 1) / chunk;
+    // What the chunks' launch shapes may assume about the chip: with deferred joins (and the host-buffer stream of batches)
+    // consecutive calls overlap and every lane is busy; a call that waits for its own chunks has only THOSE in flight - one
+    // 4096-proof chunk on a laned workspace is a lone batch (with the full-chip shapes it took 11.6 ms instead of 5.8).
+    const uint32_t call_hint = w->hint_given ? w->in_flight_hint : (w->defer_joins || never_join) ? w->n_lanes : (nch < L ? nch : L);
     const int slot = (int)(w->calls % h2v_workspace::RING);
     w->calls++;
     w->lring_chunks[slot] = nch; w->lring_first[slot] = (uint32_t)(w->next_lane % L); w->lring_mod[slot] = L; w->lring_rlc[slot] = rlc ? 1 : 0;
@@ -1213,9 +1218,11 @@ static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const
             for (int k = 0; k < 8; k++) sd[k] = seed[k];
             sd[7] ^= 0x9e3779b9u * (c + 1);      // (a chunk is its own batch check: its own coefficients)
             lw->rlc_fail_ptr = w->rlc_fail + slot;
+            lw->in_flight_hint = call_hint;
             rc = run_rlc(p, m, proofs, off + lo, inst_c, ci_c, accept + lo, status_out ? status_out + lo : nullptr, lw, ls, sd, true);
         } else {
             lw->one_stream_mode = stream_mode;
+            lw->in_flight_hint = call_hint;
             rc = run_pipeline(d, m, proofs, off + lo, inst_c, ci_c, accept + lo, status_out ? status_out + lo : nullptr, lw, ls, nullptr, false);
         }
         if (rc) { (void)hipStreamSynchronize(ls); return rc; }
