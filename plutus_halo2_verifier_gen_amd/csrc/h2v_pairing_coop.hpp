@@ -145,8 +145,11 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
             }
         acc[27] = 0;
     }
+    // (one lane per coefficient, cyclotomic squaring: the row's LAST term - the constant -/+ 2/3 against the lane's own coefficient -
+    //  is left out; coop_csqr forms 3 r -/+ 2 g itself and folds it, a product cheaper)
+    constexpr int NTE = (NQ == 1 && TRIPLE) ? NT - 1 : NT;
 #pragma unroll 1
-    for (int t = (NQ == 1 ? 0 : c.q) + NQ; t < NT; t += NQ) {
+    for (int t = (NQ == 1 ? 0 : c.q) + NQ; t < NTE; t += NQ) {
         uint32_t x[14], y[14];
         coop_load28_pair(x, y, coop_slot(c, tab[2 * t]), coop_slot(c, tab[2 * t + 1]));
 #pragma unroll
@@ -190,11 +193,6 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
             const auto sw = __builtin_amdgcn_permlane16_swap(r.l[i], r.l[i], false, false);
             r.l[i] = sw[0] + sw[1];
         }
-    } else if (TRIPLE) {
-        // one lane per coefficient: all four terms of the cyclotomic squaring in one set of columns (4 x 14 x 2 x 2^56: no
-        // room for the factor 3), so the REDUCED sum is tripled: below 3 (4 * 168 / 2520 + 1) p = 3.8 p
-#pragma unroll
-        for (int i = 0; i < 14; i++) r.l[i] *= 3u;
     }
     if (NQ == 4) {   // the other half-wave holds the sum of the other two quarters
 #pragma unroll
@@ -206,7 +204,7 @@ H2V_DN F28Regs coop_accumulate(const Coop c, const int tab_row_byte) {
     // value: two halves < 2 * 1.4 p; four quarters < 4 * (3 * 168 / 2520 + 1) p = 4.8 p; one lane: (12 * 7 * 13 / 2520 + 1) p =
     // 1.43 p (MUL), 1.56 p (SQR), 3.8 p (CSQR, above) (every operand bound of the staging code assumes v <= 6, CONJ and INV
     // v <= 5); limbs back below 2^28
-    if (NQ >= 2 || TRIPLE) f28_carry(r);   // (one lane per coefficient, no tripling: the limbs left the extraction carried)
+    if (NQ >= 2) f28_carry(r);   // (one lane per coefficient: the limbs left the extraction carried)
     return f28_pack(r);
 }
 template <int NT, bool TRIPLE>
@@ -332,8 +330,20 @@ H2V_DI F28 coop_csqr(const Coop &c, const F28 &a) {
         coop_csqr_stage(c, a, pa, neg, c.h != 0);
     }
     __syncthreads();
-    const F28 r = coop_engine<COOP_N_CSQR_TERMS, true>(c, COOP_TAB_CSQR_B + c.g * 2 * COOP_N_CSQR_TERMS);
+    F28 r = coop_engine<COOP_N_CSQR_TERMS, true>(c, COOP_TAB_CSQR_B + c.g * 2 * COOP_N_CSQR_TERMS);
     __syncthreads();
+    if (c.nq == 1) {
+        // one lane per coefficient: r = Q_k reduced (< 1.2p); h_k = 3 Q_k - 2 g_k (even k) / + 2 g_k (odd k) below 17p, folded below 2p
+        // (h2v_fp28.hpp: f28_fold; the engines with several lanes per coefficient take the constant product and tripled columns)
+        const bool minus = ((c.g >> 1) & 1) == 0;
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            const uint32_t g2 = a.l[i] << 1;
+            r.l[i] = 3u * r.l[i] + (minus ? F28_BIAS_13_2[i] - g2 : g2);
+        }
+        f28_carry(r);
+        f28_fold(r);
+    }
     return r;
 }
 // a^2 for a general a (the Miller loop's f^2): 8 terms per coefficient instead of the 12 of coop_mul(a, a)

@@ -222,6 +222,9 @@ def csqr_table():
                     terms = [(D(a, 0), S(b)), (D(a, 1), M(b))]
         if g < 12:
             assert len(terms) <= N_CSQR_TERMS - 1
+            while len(terms) < N_CSQR_TERMS - 1:
+                terms.append((SLOT_ZERO, SLOT_ZERO))
+            # the constant term LAST in every row: the one-lane-per-coefficient engines leave it out and form -/+ 2 g themselves
             terms.append((A(g >> 1, g & 1), SLOT_C23N if (g >> 1) % 2 == 0 else SLOT_C23P))
         while len(terms) < N_CSQR_TERMS:
             terms.append((SLOT_ZERO, SLOT_ZERO))
