@@ -34,22 +34,36 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # No file, no peak: int_roofline.peak / frac are null rather than a remembered constant.
 
 
-def imad_peak():
+def imad_costs():
+    """(cycles per v_mad_u64_u32 wave-instruction per SIMD, cycles per plain 32-bit VALU instruction, file) from the newest
+    profiles/r*_imad_ubench.txt: the 4-waves-per-SIMD section; the ubench's per-SIMD reading (v2: s_memtime stamps grouped by
+    physical SIMD) when the file has it, else the event-time reading of the old format."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_imad_ubench.txt")))
+
+    def version_key(path):
+        m = re.match(r"r(\d+)_", os.path.basename(path))
+        return int(m.group(1)) if m else -1
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_imad_ubench.txt")), key=version_key)
     if not files:
-        return None, None
-    cyc, sect = None, None
+        return None, None, None
+    got, sect = {}, None
     for line in open(files[-1]):
         m = re.match(r"--- (\d+) wave", line)
         if m:
             sect = int(m.group(1))
-        m = re.match(r"mad_u64_u32 .*~([0-9.]+) cycles", line)
+        m = re.match(r"(mad_u64_u32|add_u32) .*?~([0-9.]+) cycles", line)
         if m and sect == 4:
-            cyc = float(m.group(1))
+            m2 = re.search(r"per SIMD that held \d+ waves: ([0-9.]+) cycles", line)
+            got[m.group(1)] = float(m2.group(1)) if m2 else float(m.group(2))
+    return got.get("mad_u64_u32"), got.get("add_u32"), os.path.basename(files[-1])
+
+
+def imad_peak():
+    cyc, _c_min, src = imad_costs()
     if not cyc:
         return None, None
-    return 1024 * 64 * 2.4e9 / cyc / 1e12, os.path.basename(files[-1])
+    return 1024 * 64 * 2.4e9 / cyc / 1e12, src
 
 
 IMAD_PEAK_TOPS, IMAD_PEAK_SOURCE = imad_peak()

@@ -244,6 +244,23 @@ int h2v_probe_pairing(const h2v_plan *plan, uint32_t n, const uint8_t *p1_compre
 int h2v_probe_pairing_ex(const h2v_plan *plan, uint32_t n, const uint8_t *p1_compressed, const uint8_t *p2_compressed,
                          uint8_t *out, int impl, uint8_t *dbg);
 
+/* ---- library lifecycle (round 4) ---------------------------------------------------------------------------------
+ * h2v_shutdown(device) - device = -1: every device - quiesces and releases everything the library owns there: it waits
+ * for the library's pool streams (the hardware queues the lanes run on), releases every live workspace of that device
+ * (buffers, events, copy streams) and the device memory of every plan loaded on it, and destroys the pool streams.
+ * Afterwards every entry point that needs that device returns H2V_E_DEVICE; workspace / plan handles stay valid as empty
+ * shells (h2v_plan_info still answers) and are freed with the usual h2v_*_free.  Idempotent; not to be called while
+ * another thread is inside a verify call.
+ * Who calls it: a host calls it once, after its last verify call and before the process starts to exit - the Rust side in
+ * the `Drop` of the object that owns the library, h2v.hpp through h2v::shutdown(), the Python binding
+ * with atexit.  The reference's side is RAII throughout (the guard is consumed by value, examples/simple_mul.rs:98-104);
+ * this is the one piece of process-wide state the backend adds.  As a backstop the library registers the call with
+ * atexit() itself when it creates its first pool stream (i.e. after the HIP runtime has initialised, so that it runs
+ * before the runtime's own exit handlers).  Why it exists: pool streams that were still alive when the HIP runtime and a
+ * profiler's tool library ran their static destructors crashed the process at exit (SIGSEGV through __cxa_finalize under
+ * rocprofv3, round 3). */
+int h2v_shutdown(int device);
+
 const char *h2v_last_error(void);
 /* sha256 (hex) of the sources this binary was built from; "unknown" for a build outside __graft_entry__.build() */
 const char *h2v_build_id(void);

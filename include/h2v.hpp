@@ -43,6 +43,16 @@ struct VerifyError : std::runtime_error {  // Err(plonk::Error): the proof does 
 inline void check(int rc) {
     if (rc != H2V_OK) throw Error(rc, h2v_last_error());
 }
+/// h2v_shutdown: releases everything the library owns on `device` (-1: every device) - pool streams, workspaces, plans.
+/// Call it once after the last verify call and before main() returns (or hold a ShutdownGuard in main): objects of this
+/// header that are still alive afterwards are empty shells whose destructors only free host memory.
+inline void shutdown(int device = -1) { check(h2v_shutdown(device)); }
+struct ShutdownGuard {   // `h2v::ShutdownGuard guard;` as the first local of main(): runs after every other local is gone
+    ShutdownGuard() = default;
+    ShutdownGuard(const ShutdownGuard &) = delete;
+    ShutdownGuard &operator=(const ShutdownGuard &) = delete;
+    ~ShutdownGuard() { (void)h2v_shutdown(-1); }
+};
 
 class VerifyingKey {  // VerifyingKey<F, KZGCommitmentScheme<Bls12>> + ParamsVerifierKZG for this path
   public:

@@ -68,7 +68,7 @@ EXPORTS = [
     "h2v_workspace_rlc_result", "h2v_probe_g1_msm_pippenger", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
     "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_quad_madd", "h2v_probe_pairing", "h2v_probe_pairing_ex",
     "h2v_last_error", "h2v_build_id",
-    "h2v_device_count",
+    "h2v_device_count", "h2v_shutdown",
 ]
 
 _lib = None
@@ -126,6 +126,12 @@ def lib():
         L.h2v_probe_g1_msm.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p]
         L.h2v_probe_pairing.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p]
         L.h2v_probe_pairing_ex.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.h2v_shutdown.argtypes = [C.c_int]
+        # h2v_shutdown before the interpreter goes down: the library's pool streams (hardware queues of their own) must not
+        # outlive the HIP runtime / a profiler's tool library (include/h2v.h: library lifecycle).  Handles that Python still
+        # holds afterwards are empty shells; their __del__ frees the host structs only.
+        import atexit
+        atexit.register(L.h2v_shutdown, -1)
         _lib = L
     return _lib
 
@@ -148,6 +154,11 @@ def plan_compile(vk_json: str) -> bytes:
 
 def device_count() -> int:
     return lib().h2v_device_count()
+
+
+def shutdown(device: int = -1) -> None:
+    """h2v_shutdown: release everything the library owns on `device` (-1: every device); later calls raise H2VError."""
+    check(lib().h2v_shutdown(device))
 
 
 class DevicePlan:

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,37 @@ static int fail(int code, const std::string &msg) {
     } while (0)
 
 extern "C" const char *h2v_last_error(void) { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------- lifecycle
+// Everything the library owns on a device - the pool of CU-mask streams (make_stream), every live workspace's buffers,
+// streams and events, every plan's device memory - is released by h2v_shutdown(device), which a host calls before the
+// process exits (backend.py: atexit; h2v.hpp: h2v::shutdown; the library itself registers it with atexit() when the first
+// pool stream is created, i.e. after the HIP runtime's own initialisation, so that it runs BEFORE the runtime's exit
+// handlers).  Why: a stream with a hardware queue of its own that is still alive when the runtime and a profiler's tool
+// library run their static destructors was the exit-time SIGSEGV of round 3 (under rocprofv3, after "tool
+// finalization", through __cxa_finalize: only the forms that had created pool streams crashed).  After the call every
+// entry point that needs the device returns H2V_E_DEVICE; handles stay valid as empty shells and are freed as usual.
+static std::mutex g_reg_mu;
+static std::vector<h2v_workspace *> g_ws_live;
+static std::vector<h2v_plan *> g_plan_live;
+static bool g_shut[16] = {};
+static bool dev_shut(int dev) {
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    return dev >= 0 && dev < 16 && g_shut[dev];
+}
+#define ALIVE_DEV(dev)                                                                                   \
+    do {                                                                                                 \
+        if (dev_shut(dev)) return fail(H2V_E_DEVICE, "h2v_shutdown has been called for this device");    \
+    } while (0)
+#define ALIVE(obj)                                                                                       \
+    do {                                                                                                 \
+        if ((obj) && (obj)->dead) return fail(H2V_E_DEVICE, "h2v_shutdown has been called: this handle is an empty shell"); \
+    } while (0)
+template <class T> static void reg_add(std::vector<T *> &v, T *x) { std::lock_guard<std::mutex> lock(g_reg_mu); v.push_back(x); }
+template <class T> static void reg_del(std::vector<T *> &v, T *x) {
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    for (size_t i = 0; i < v.size(); i++) if (v[i] == x) { v[i] = v.back(); v.pop_back(); return; }
+}
 // content hash of csrc/ + include/h2v.h this binary was built from (__graft_entry__.build_hip compares it with the tree)
 #ifndef H2V_SRC_HASH_STR
 #define H2V_SRC_HASH_STR "unknown"
@@ -64,6 +96,7 @@ extern "C" void h2v_blob_free(uint8_t *blob) { free(blob); }
 
 struct h2v_plan {
     int device = 0;
+    bool dead = false;         // h2v_shutdown released the device memory: every call with this plan is H2V_E_DEVICE
     H2vDevPlan d{};            // device view
     void *blob = nullptr;      // one device allocation holding every section
     void *fold_terms = nullptr;  // recursion: the 4-entry term table of the two fold MSMs
@@ -76,6 +109,7 @@ struct h2v_plan {
 
 struct h2v_workspace {
     int device = 0;
+    bool dead = false;             // h2v_shutdown released everything: an empty shell until h2v_workspace_free
     uint32_t in_flight_hint = 1;   // h2v_workspace_hint_in_flight: how many batches the caller keeps in flight on this device
     bool hint_given = false;       // (laned: the caller said so itself; otherwise run_laned estimates it per call)
     uint64_t cap = 0;       // max batch
@@ -288,6 +322,7 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(H2V_E_DEVICE, "no HIP device: the HIP backend is required (no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(H2V_E_ARG, "device index out of range");
+    ALIVE_DEV(device);
     HIPCHK(hipSetDevice(device));
     h2v_plan *p = new h2v_plan();
     p->device = device;
@@ -395,16 +430,22 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
     p->n_squeezes = n_sq;
     p->stream_len = w[H2V_HW_STREAM_LEN];
     for (uint32_t k = 0; k < n_trace; k++) p->trace_slots.push_back(rd32(trp + 8 * k));
+    reg_add(g_plan_live, p);
     *out = p;
     return H2V_OK;
 }
-extern "C" void h2v_plan_free(h2v_plan *p) {
-    if (!p) return;
+static void plan_release(h2v_plan *p) {   // the device memory; the host-side facts (h2v_plan_info) stay
     (void)hipSetDevice(p->device);
     if (p->blob) (void)hipFree(p->blob);
     if (p->fold_terms) (void)hipFree(p->fold_terms);
     if (p->vk_tab) (void)hipFree(p->vk_tab);
     if (p->fix_tab) (void)hipFree(p->fix_tab);
+    p->blob = p->fold_terms = p->vk_tab = p->fix_tab = nullptr;
+}
+extern "C" void h2v_plan_free(h2v_plan *p) {
+    if (!p) return;
+    reg_del(g_plan_live, p);
+    if (!p->dead) plan_release(p);
     delete p;
 }
 extern "C" int h2v_plan_info(const h2v_plan *p, uint32_t *proof_len, uint32_t *n_pi, uint32_t *n_ci, uint32_t *n_terms) {
@@ -448,7 +489,7 @@ static void ws_release(h2v_workspace *w) {
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (w->h_block) (void)hipHostFree(w->h_block);
     if (w->h_accept) (void)hipHostFree(w->h_accept);
-    if (w->hs) (void)hipStreamSynchronize(w->hs);   // (pool streams are shared and never destroyed: make_stream)
+    if (w->hs) (void)hipStreamSynchronize(w->hs);   // (pool streams are shared: make_stream; h2v_shutdown destroys them)
     if (w->copy_streams_owned) {
         if (w->hs) (void)hipStreamDestroy(w->hs);
         if (w->hs_down) (void)hipStreamDestroy(w->hs_down);
@@ -468,6 +509,7 @@ static void ws_release(h2v_workspace *w) {
 static uint32_t vm_lds_slots(const H2vDevPlan &d);
 static int ws_create_for(const H2vDevPlan &d, int device, uint64_t max_batch, bool with_trace, h2v_workspace **out) {
     if (max_batch == 0 || max_batch > (1ull << 24)) return fail(H2V_E_ARG, "max_batch out of range");
+    ALIVE_DEV(device);
     HIPCHK(hipSetDevice(device));
     h2v_workspace *w = new h2v_workspace();
     w->device = device;
@@ -532,21 +574,24 @@ static uint32_t default_chunk(const H2vDevPlan &d) {
 #define H2V_PER_PROOF_LANES 8u
 static int ensure_lane(h2v_workspace *w, uint32_t l) {
     if (w->lane[l]) return H2V_OK;
+    // the lane's stream and event first, the lane itself last: a lane that exists has both (a failure here leaves lane[l]
+    // NULL, and the next call tries again instead of enqueueing on a NULL stream)
+    if (!w->lane_st[l] && make_stream(&w->lane_st[l]) != hipSuccess) { w->lane_st[l] = nullptr; return fail(H2V_E_DEVICE, "lane stream creation failed"); }
+    if (!w->lane_ev[l] && hipEventCreateWithFlags(&w->lane_ev[l], hipEventDisableTiming) != hipSuccess) { w->lane_ev[l] = nullptr; return fail(H2V_E_DEVICE, "lane event creation failed"); }
     h2v_workspace *lw = nullptr;
     int rc = ws_create_for(w->lane_plan, w->device, w->chunk, false, &lw);
     if (rc) return rc;
-    w->lane[l] = lw;
     lw->one_stream_mode = 2;            // (set per call: laned_depth)
     lw->in_flight_hint = w->in_flight_hint > w->n_lanes ? w->in_flight_hint : w->n_lanes;
     lw->opt_msm_tpl = w->opt_msm_tpl; lw->opt_pairing = w->opt_pairing;
-    if (make_stream(&w->lane_st[l]) != hipSuccess || hipEventCreateWithFlags(&w->lane_ev[l], hipEventDisableTiming) != hipSuccess)
-        return fail(H2V_E_DEVICE, "lane stream / event creation failed");
+    w->lane[l] = lw;
     return H2V_OK;
 }
 extern "C" int h2v_workspace_create_lanes(const h2v_plan *p, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk, h2v_workspace **out) {
     if (!p || !out) return fail(H2V_E_ARG, "null argument");
     if (max_batch == 0 || max_batch > (1ull << 24)) return fail(H2V_E_ARG, "max_batch out of range");
     if (n_lanes > (uint32_t)h2v_workspace::MAXL) return fail(H2V_E_ARG, "at most 16 lanes");
+    ALIVE(p);
     if (chunk == 0) chunk = default_chunk(p->d);
     if ((uint64_t)chunk > max_batch) chunk = (uint32_t)max_batch;
     HIPCHK(hipSetDevice(p->device));
@@ -564,6 +609,7 @@ extern "C" int h2v_workspace_create_lanes(const h2v_plan *p, uint64_t max_batch,
     // the first lane now (an allocation failure surfaces here, not in the middle of a verify call); the others on first use
     if (ok) ok = ensure_lane(w, 0) == H2V_OK;
     if (!ok) { const std::string e = g_err; ws_release(w); delete w; return fail(H2V_E_DEVICE, "lane creation failed: " + e); }
+    reg_add(g_ws_live, w);
     *out = w;
     return H2V_OK;
 }
@@ -571,11 +617,15 @@ extern "C" int h2v_workspace_create(const h2v_plan *p, uint64_t max_batch, h2v_w
     if (!p || !out) return fail(H2V_E_ARG, "null argument");
     // a workspace for batches of at least four chunks is laned: the call is pipelined inside the library (measured,
     // simple_mul: 8192 proofs in one launch per kernel 5.6 ms per 4096 against 5.9 in two chunks; 20480: 5.3 against 4.7)
+    ALIVE(p);
     if (max_batch >= 4ull * default_chunk(p->d)) return h2v_workspace_create_lanes(p, max_batch, 0, 0, out);
-    return ws_create_for(p->d, p->device, max_batch, false, out);
+    const int rc = ws_create_for(p->d, p->device, max_batch, false, out);
+    if (rc == H2V_OK) reg_add(g_ws_live, *out);
+    return rc;
 }
 extern "C" int h2v_workspace_set_option(h2v_workspace *ws, uint32_t option, int32_t value) {
     if (!ws) return fail(H2V_E_ARG, "null argument");
+    ALIVE(ws);
     auto apply = [&](h2v_workspace *w) {
         if (option == H2V_OPT_MSM_TERMS_PER_LANE) w->opt_msm_tpl = value;
         else if (option == H2V_OPT_PAIRING_ENGINE) w->opt_pairing = value;
@@ -598,11 +648,13 @@ extern "C" int h2v_workspace_lanes(const h2v_workspace *ws, uint32_t *n_lanes, u
 static uint32_t laned_depth(const h2v_workspace *w, uint64_t n, bool rlc, int *stream_mode);
 extern "C" int h2v_workspace_depth(const h2v_workspace *ws, uint64_t n, int rlc, uint32_t *batches_in_flight) {
     if (!ws || !batches_in_flight) return fail(H2V_E_ARG, "null argument");
+    ALIVE(ws);
     *batches_in_flight = ws->n_lanes ? laned_depth(ws, n, rlc != 0, nullptr) : 1;
     return H2V_OK;
 }
 extern "C" int h2v_workspace_defer_joins(h2v_workspace *ws, int defer) {
     if (!ws) return fail(H2V_E_ARG, "null argument");
+    ALIVE(ws);
     if (!ws->n_lanes) return fail(H2V_E_ARG, "only a laned workspace can defer its joins (h2v_workspace_create_lanes)");
     ws->defer_joins = defer != 0;
     return H2V_OK;
@@ -615,17 +667,20 @@ static int lanes_join(h2v_workspace *w, hipStream_t st) {
 }
 extern "C" int h2v_workspace_join(h2v_workspace *ws, void *stream) {
     if (!ws) return fail(H2V_E_ARG, "null argument");
+    ALIVE(ws);
     if (!ws->n_lanes) return H2V_OK;   // an ordinary workspace's calls are already ordered on the caller's stream
     HIPCHK(hipSetDevice(ws->device));
     return lanes_join(ws, (hipStream_t)stream);
 }
 extern "C" void h2v_workspace_free(h2v_workspace *w) {
     if (!w) return;
-    ws_release(w);
+    reg_del(g_ws_live, w);
+    if (!w->dead) ws_release(w);
     delete w;
 }
 extern "C" int h2v_workspace_hint_in_flight(h2v_workspace *ws, uint32_t n_in_flight) {
     if (!ws || n_in_flight == 0) return fail(H2V_E_ARG, "bad argument");
+    ALIVE(ws);
     ws->in_flight_hint = n_in_flight;
     ws->hint_given = true;
     return H2V_OK;
@@ -657,22 +712,22 @@ static int ws_fits(const h2v_workspace *w, const h2v_plan *p, uint64_t n, bool w
 // its own scratch arena, sized for the kernel with the largest private segment (a process that had created 47 of them
 // died with HSA_STATUS_ERROR_OUT_OF_RESOURCES at the next launch), so the library owns a fixed POOL of such streams per
 // device - H2V_QUEUE_POOL, default 16 (24 measured slower: 4.97 against 4.30 ms per batch) - and hands them out round robin: workspaces share them (a stream is an ordering
-// domain, sharing one only adds order), they are never destroyed, and the mask names every CU.  Pool streams have the
+// domain, sharing one only adds order), they live until h2v_shutdown, and the mask names every CU.  Pool streams have the
 // default flags, i.e. they are ordered with the legacy NULL stream: callers that defer joins should not submit on the
 // NULL stream.  H2V_STREAM_CUMASK=0: plain non-blocking streams of the runtime's own pool instead.
-#include <mutex>
+static std::vector<hipStream_t> g_pool[16];
+static size_t g_pool_next[16] = {};
+extern "C" int h2v_shutdown(int device);
 static hipError_t make_stream(hipStream_t *s) {
     static const int cumask = []() { const char *e = getenv("H2V_STREAM_CUMASK"); return e ? atoi(e) : 1; }();
     static const size_t pool_cap = []() { const char *e = getenv("H2V_QUEUE_POOL"); const int v = e ? atoi(e) : 16; return (size_t)(v < 1 ? 1 : v > 32 ? 32 : v); }();
-    static std::mutex mu;
-    static std::vector<hipStream_t> pool[16];
-    static size_t next[16] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-    std::lock_guard<std::mutex> lock(mu);
-    if (pool[dev].size() < pool_cap) {
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    if (g_shut[dev]) return hipErrorContextIsDestroyed;
+    if (g_pool[dev].size() < pool_cap) {
         hipStream_t ns = nullptr;
         if (cumask) {
             int cus = 256;
@@ -684,12 +739,51 @@ static hipError_t make_stream(hipStream_t *s) {
             e = hipStreamCreateWithFlags(&ns, hipStreamNonBlocking);
         }
         if (e != hipSuccess) return e;
-        pool[dev].push_back(ns);
+        // registered now, i.e. after the HIP runtime has initialised itself: exit handlers run in reverse order of
+        // registration, so the pool is destroyed while the runtime (and a profiler's tool) are still whole
+        static const int registered = atexit([]() { (void)h2v_shutdown(-1); });
+        (void)registered;
+        g_pool[dev].push_back(ns);
         *s = ns;
         return hipSuccess;
     }
-    *s = pool[dev][next[dev]++ % pool[dev].size()];
+    *s = g_pool[dev][g_pool_next[dev]++ % g_pool[dev].size()];
     return hipSuccess;
+}
+// Releases everything the library owns on `device` (-1: on every device): waits for the pool streams, releases every live
+// workspace (they become empty shells: dead) and every plan's device memory, destroys the pool streams.  Idempotent.
+extern "C" int h2v_shutdown(int device) {
+    if (device < -1 || device >= 16) return fail(H2V_E_ARG, "device index out of range");
+    std::vector<h2v_workspace *> wss;
+    std::vector<h2v_plan *> plans;
+    std::vector<hipStream_t> streams[16];
+    {
+        std::lock_guard<std::mutex> lock(g_reg_mu);
+        for (h2v_workspace *w : g_ws_live) if (!w->dead && (device < 0 || w->device == device)) wss.push_back(w);
+        for (h2v_plan *p : g_plan_live) if (!p->dead && (device < 0 || p->device == device)) plans.push_back(p);
+        for (int d = 0; d < 16; d++)
+            if (device < 0 || d == device) { g_shut[d] = true; streams[d].swap(g_pool[d]); }
+    }
+    int rc = H2V_OK;
+    for (int d = 0; d < 16; d++) {
+        if (streams[d].empty()) continue;
+        if (hipSetDevice(d) != hipSuccess) { rc = fail(H2V_E_DEVICE, "hipSetDevice failed during shutdown"); continue; }
+        for (hipStream_t q : streams[d]) (void)hipStreamSynchronize(q);
+    }
+    for (h2v_workspace *w : wss) {
+        const int dev = w->device;
+        ws_release(w);
+        *w = h2v_workspace();
+        w->device = dev; w->dead = true;
+    }
+    for (h2v_plan *p : plans) { plan_release(p); p->dead = true; }
+    for (int d = 0; d < 16; d++) {
+        if (streams[d].empty()) continue;
+        if (hipSetDevice(d) != hipSuccess) continue;
+        for (hipStream_t q : streams[d])
+            if (hipStreamDestroy(q) != hipSuccess) rc = fail(H2V_E_DEVICE, "hipStreamDestroy(pool stream) failed");
+    }
+    return rc;
 }
 // the main / side / third stream of pipeline chunk k, created when first asked for
 static int ws_streams(h2v_workspace *w, int k, bool need_main, bool need_side, bool need_sub) {
@@ -1254,6 +1348,7 @@ extern "C" int h2v_verify_batch_device(const h2v_plan *p, const h2v_batch *b, ui
     if (!b->proofs || !b->proof_off) return fail(H2V_E_ARG, "null proofs / offsets");
     if (p->d.n_pi && !b->instances) return fail(H2V_E_ARG, "plan has public inputs but instances == NULL");
     if (p->d.n_ci && !b->committed) return fail(H2V_E_ARG, "plan has a committed instance but committed == NULL");
+    ALIVE(p); ALIVE(ws);
     HIPCHK(hipSetDevice(p->device));
     h2v_workspace *tmp = nullptr;
     if (!ws) {
@@ -1284,6 +1379,7 @@ extern "C" int h2v_verify_batch_device(const h2v_plan *p, const h2v_batch *b, ui
 // recorded on the streams the kernels ran on; the caller must have synchronised the launch stream first.
 extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_timings *tm) {
     if (!w || !tm) return fail(H2V_E_ARG, "null argument");
+    ALIVE(w);
     if (calls_back >= h2v_workspace::RING || calls_back >= w->calls) return fail(H2V_E_ARG, "no such call in the event ring");
     HIPCHK(hipSetDevice(w->device));
     const int slot = (int)((w->calls - 1 - calls_back) % h2v_workspace::RING);
@@ -1518,6 +1614,7 @@ static int wait_laned(h2v_workspace *ws, uint8_t *accept, int *fell_back) {
 // workspaces to overlap the upload of batch k+1 with the kernels of batch k.
 extern "C" int h2v_verify_batch_submit(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws, uint32_t flags, const h2v_rlc_opts *opts) {
     if (!p || !b || !ws) return fail(H2V_E_ARG, "null argument");
+    ALIVE(p); ALIVE(ws);
     if (ws->pending && !ws->n_lanes) return fail(H2V_E_ARG, "the workspace already has a batch in flight: call h2v_verify_batch_wait first");
     if (b->n && (!b->proofs || !b->proof_off)) return fail(H2V_E_ARG, "null proofs / offsets");
     if (b->n && p->d.n_pi && !b->instances) return fail(H2V_E_ARG, "plan has public inputs but instances == NULL");
@@ -1569,6 +1666,7 @@ extern "C" int h2v_verify_batch_submit(const h2v_plan *p, const h2v_batch *b, h2
 // in RLC mode and the batch check failed, so that the per-proof kernels produced accept[].
 extern "C" int h2v_verify_batch_wait(h2v_workspace *ws, uint8_t *accept, int *fell_back) {
     if (!ws || !accept) return fail(H2V_E_ARG, "null argument");
+    ALIVE(ws);
     if (ws->n_lanes) { HIPCHK(hipSetDevice(ws->device)); return wait_laned(ws, accept, fell_back); }
     if (!ws->pending) return fail(H2V_E_ARG, "no batch in flight on this workspace");
     HIPCHK(hipSetDevice(ws->device));
@@ -1589,6 +1687,7 @@ static int verify_host(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, h
     if (!p || !b || !accept) return fail(H2V_E_ARG, "null argument");
     if (fell_back) *fell_back = 0;
     if (b->n == 0) return H2V_OK;
+    ALIVE(p); ALIVE(ws);
     HIPCHK(hipSetDevice(p->device));
     h2v_workspace *tmp = nullptr;
     int rc;
@@ -1969,6 +2068,7 @@ extern "C" int h2v_verify_batch_rlc_device(const h2v_plan *p, const h2v_batch *b
     if (rc) return rc;
     if (b->n == 0) return H2V_OK;
     if (!ws) return fail(H2V_E_ARG, "the RLC entry points need a workspace (results of the batch check live in it)");
+    ALIVE(p); ALIVE(ws);
     HIPCHK(hipSetDevice(p->device));
     if ((rc = ws_fits(ws, p, b->n, false))) return rc;
     if (ws->pending) return fail(H2V_E_ARG, "the workspace has a host batch in flight: call h2v_verify_batch_wait first");
@@ -1992,6 +2092,7 @@ extern "C" int h2v_verify_batch_rlc(const h2v_plan *p, const h2v_batch *b, uint8
 // After the stream of an RLC call has been synchronised: did the batch check pass (1) or did the per-proof kernels run (0)?
 // kernel times of a past call (calls_back = 0: the most recent).
 extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, uint32_t *batch_accepted, h2v_rlc_timings *tm) {
+    ALIVE(w);
     if (w && w->n_lanes) {
         // laned: the AND of the chunks' batch verdicts; times summed over the chunks, total = first start .. last verdict
         if (w->calls == 0 || calls_back >= h2v_workspace::RING || calls_back >= w->calls) return fail(H2V_E_ARG, "no such call in the event ring");
@@ -2055,6 +2156,7 @@ extern "C" int h2v_trace(const h2v_plan *p, const uint8_t *proof, size_t proof_l
                          const uint8_t *committed, uint8_t *scalars_out, uint8_t *msm_scalars_out, uint8_t el_out[96],
                          uint8_t er_out[96], uint32_t *status_out, uint8_t *accept_out) {
     if (!p || !proof) return fail(H2V_E_ARG, "null argument");
+    ALIVE(p);
     HIPCHK(hipSetDevice(p->device));
     h2v_workspace *ws = nullptr;
     int rc = ws_create_for(p->d, p->device, 1, true, &ws);
@@ -2098,6 +2200,7 @@ static int pick_device(int device) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(H2V_E_DEVICE, "no HIP device: the HIP backend is required (no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(H2V_E_ARG, "device index out of range");
+    ALIVE_DEV(device);
     HIPCHK(hipSetDevice(device));
     return H2V_OK;
 }
@@ -2237,6 +2340,7 @@ extern "C" int h2v_probe_pairing(const h2v_plan *p, uint32_t n, const uint8_t *p
 // (f after the Miller loop and - cooperative kernel only - after the final exponentiation; canonical LE limbs)
 extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t *p1c, const uint8_t *p2c, uint8_t *out, int impl, uint8_t *dbg) {
     if (!p || !p1c || !p2c || !out || n == 0) return fail(H2V_E_ARG, "bad argument");
+    ALIVE(p);
     DevBuf ddbg;
     HIPCHK(hipSetDevice(p->device));
     MiniPlan mp;

@@ -697,6 +697,64 @@ def test_baseline_config_sizes(be, circuits, name, n):
     assert list(acc2) == [1] * clean.n and (not fb2 or name == "ivc") and (fell_back or name == "ivc")
 
 
+def test_mixed_batch_of_two_plans_in_flight_on_one_device(be, circuits):
+    """BASELINE configs[2] AS NAMED - "lookup_table + atms_with_lookups mixed batch, 1 x MI355X": two plans, two laned
+    workspaces on one device in one process, 2048 proofs each (8 % corrupted, every corruption kind), the calls of the two
+    plans interleaved on ONE caller stream with deferred joins, so that chunks of both plans are in flight on the shared pool
+    of sixteen streams at the same time.  Before that the IVC and the sha256 plans have run on laned workspaces in the same
+    process: the pool's queues have seen the kernels with the largest private segments (a queue's scratch arena is sized by
+    the largest it has run - the one new failure class of round 3 was sixteen arenas that did not fit).  Verdicts == the
+    construction for every call, == the oracle on a sample of each plan, and the RLC form of the same interleaving agrees."""
+    import torch
+    from plutus_halo2_verifier_gen_amd import synth
+    dev = torch.device("cuda", 0)
+    up = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) if b else None
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    for name, m in (("ivc", 96), ("sha256", 160)):
+        vk, td, pl, dp, ov = circuits[name]
+        b = synth.forge_batch(vk, td, m, seed=31, plan=pl, workers=8)
+        b = synth.with_rejects(pl, b, vk.n_public_inputs, fraction=0.2, seed=32, kinds=list(synth.CORRUPTIONS))
+        w_ = be.Workspace(dp, m, lanes=4, chunk=40)
+        assert list(dp.verify_batch(b.proofs, b.proof_off, b.instances, b.committed, ws=w_)) == b.expected, name
+        w_.close()
+    n = 2048
+    parts = []
+    for k, name in enumerate(("lookup_table", "atms_with_lookups")):
+        vk, td, pl, dp, ov = circuits[name]
+        b = synth.forge_batch(vk, td, n, seed=500 + k, plan=pl, workers=8)
+        b = synth.with_rejects(pl, b, vk.n_public_inputs, fraction=0.08, seed=510 + k, kinds=list(synth.CORRUPTIONS))
+        assert 0 < sum(b.expected) < n
+        ws = be.Workspace(dp, n, lanes=0, chunk=0)      # the library's lanes and chunk for this plan
+        ws.defer_joins(True)
+        d = (up(b.proofs), torch.tensor(b.proof_off, dtype=torch.int64).to(dev), up(b.instances), up(b.committed))
+        parts.append((name, vk, pl, dp, ov, b, ws, d))
+    s = torch.cuda.Stream(device=dev)
+    rounds = 4
+    for rlc in (False, True):
+        accs = []
+        for r in range(rounds):
+            for (name, vk, pl, dp, ov, b, ws, d) in parts:
+                acc = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+                st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+                if rlc:
+                    dp.verify_batch_rlc_device(n, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), acc.data_ptr(), st.data_ptr(), ws=ws, stream=s.cuda_stream,
+                                               seed=bytes(range(32)))
+                else:
+                    dp.verify_batch_device(n, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), acc.data_ptr(), st.data_ptr(), ws=ws, stream=s.cuda_stream)
+                accs.append((name, b, acc, st))
+        for part in parts:
+            part[6].join(s.cuda_stream)
+        s.synchronize()
+        for name, b, acc, st in accs:
+            assert acc.cpu().tolist() == b.expected, (name, rlc)
+            assert [int(x == 0) for x in st.cpu().tolist()] == b.expected, (name, rlc)
+    for (name, vk, pl, dp, ov, b, ws, d) in parts:
+        sample = sorted(random.Random(17).sample(range(n), 48))
+        sb = _permute(b, sample, vk.n_public_inputs)
+        assert list(ov.verify_batch(sb.proofs, sb.proof_off, sb.instances, sb.committed, threads=16)) == [b.expected[i] for i in sample], name
+        ws.close()
+
+
 def test_circuit_without_public_inputs(be):
     """n_public_inputs == 0 with a queried instance column (the Lagrange sum is empty) and instances == NULL at the ABI."""
     from plutus_halo2_verifier_gen_amd import backend, plan as PL, synth, vk as V
@@ -742,6 +800,54 @@ def test_alternate_pipeline_modes(be, env, tmp_path):
         "print('modes ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", script], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "modes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_shutdown_releases_the_pool_and_refuses_further_calls(be):
+    """h2v_shutdown (include/h2v.h: library lifecycle), in a child process: a laned workspace with deferred joins has chunks
+    in flight on the library's pool streams; shutdown waits for them, releases workspace and plan, destroys the streams;
+    the verdicts written before it are intact; every further call is H2V_E_DEVICE (-3), the handles are freed as usual, a
+    second shutdown is a no-op and the process exits 0 (the exit-time crash of round 3 was a pool stream that outlived
+    the runtime)."""
+    import os
+    import subprocess
+    import sys
+    script = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import ctypes as C, torch\n"
+        "from plutus_halo2_verifier_gen_amd import backend, plan as PL, synth, vk as V\n"
+        "vk, td = V.simple_mul_vk()\n"
+        "pl = PL.compile_plan(vk)\n"
+        "b = synth.forge_batch(vk, td, 96, seed=4, plan=pl, workers=1)\n"
+        "b = synth.with_rejects(pl, b, vk.n_public_inputs, fraction=0.3, seed=6, kinds=list(synth.CORRUPTIONS))\n"
+        "dev = torch.device('cuda', 0)\n"
+        "dp = backend.DevicePlan(pl.to_bytes(), 0)\n"
+        "ws = backend.Workspace(dp, 96, lanes=4, chunk=16)\n"
+        "ws.defer_joins(True)\n"
+        "t = lambda x: torch.frombuffer(bytearray(x), dtype=torch.uint8).to(dev)\n"
+        "dpr, dof, din = t(b.proofs), torch.tensor(b.proof_off, dtype=torch.int64).to(dev), t(b.instances)\n"
+        "acc = [torch.zeros(96, dtype=torch.uint8, device=dev) for _ in range(3)]\n"
+        "st = torch.cuda.Stream(device=dev)\n"
+        "for a in acc:\n"
+        "    dp.verify_batch_device(96, dpr.data_ptr(), dof.data_ptr(), din.data_ptr(), None, a.data_ptr(), None, ws=ws, stream=st.cuda_stream)\n"
+        "backend.shutdown(0)          # no join before it: the chunks are still in flight\n"
+        "torch.cuda.synchronize()\n"
+        "for a in acc:\n"
+        "    assert a.cpu().tolist() == b.expected\n"
+        "L = backend.lib()\n"
+        "bb = backend.Batch(96, dpr.data_ptr(), dof.data_ptr(), din.data_ptr(), None)\n"
+        "assert L.h2v_verify_batch_device(dp.handle, C.byref(bb), acc[0].data_ptr(), None, ws.handle, None, None) == -3\n"
+        "assert b'h2v_shutdown' in L.h2v_last_error()\n"
+        "assert L.h2v_workspace_join(ws.handle, None) == -3\n"
+        "h = C.c_void_p()\n"
+        "assert L.h2v_workspace_create(dp.handle, 8, C.byref(h)) == -3\n"
+        "raw = pl.to_bytes()\n"
+        "assert L.h2v_plan_load(raw, len(raw), 0, C.byref(h)) == -3\n"
+        "assert dp.proof_len == pl.proof_len       # host-side facts survive\n"
+        "backend.shutdown(-1)\n"
+        "ws.close(); dp.close()\n"
+        "print('shutdown ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "shutdown ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("lpt", ["1", "2", "8", "tpl2", "tpl3", "tpl4"])

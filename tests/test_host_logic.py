@@ -277,6 +277,23 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert declared == set(backend.EXPORTS)
 
 
+def test_shutdown_is_exported_and_idempotent_without_a_gpu():
+    """h2v_shutdown (include/h2v.h: library lifecycle) is exported, succeeds with nothing to release (no GPU needed), is
+    idempotent, rejects a bad device index, and the process still exits 0 afterwards.  Child process: the call marks the
+    devices shut for the rest of the process."""
+    import subprocess
+    import sys
+    import __graft_entry__ as ge
+    script = ("import ctypes\n"
+              "L = ctypes.CDLL(%r)\n"
+              "L.h2v_shutdown.argtypes = [ctypes.c_int]\n"
+              "assert L.h2v_shutdown(-1) == 0 and L.h2v_shutdown(-1) == 0 and L.h2v_shutdown(0) == 0\n"
+              "assert L.h2v_shutdown(99) == -1 and L.h2v_shutdown(-2) == -1\n"
+              "print('shutdown ok')\n" % ge.build_hip())
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "shutdown ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a GPU the product path fails loudly instead of detouring through a CPU implementation."""
     import torch
