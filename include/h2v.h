@@ -113,14 +113,24 @@ void h2v_workspace_free(h2v_workspace *ws);
  * RLC mode every chunk is its own batch check.
  *   n_lanes = 0 / chunk = 0: the library's choice for this plan (chunk = the batch that gives every kernel one wave per
  *   SIMD: 4096 proofs for 16 MSM terms, 1024 for 60; 16 lanes, of which the per-proof mode cycles through 8 - all 16 for chunks too small to fill the chip: h2v_workspace_depth).  h2v_workspace_create(plan, max_batch) itself
- *   returns a laned workspace when max_batch >= 4 x that chunk.  n_lanes <= 16. */
+ *   returns a laned workspace when max_batch >= 4 x that chunk (an ordinary one below that).  n_lanes <= 16: that is also the
+ *   most host batches h2v_verify_batch_submit keeps in flight on one workspace (h2v::BatchStream / backend.BatchStream: depth
+ *   <= 16).  A laned workspace has no trace buffer (h2v_trace creates its own). */
 int h2v_workspace_create_lanes(const h2v_plan *plan, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk, h2v_workspace **out);
 /* Deferred joins (laned workspaces): with defer = 1 a device-resident verify call returns without making the caller's stream
  * wait for its chunks, so the chunks of CONSECUTIVE calls overlap in the lanes - one workspace then does what five
  * workspaces on five streams did (a stream of batches: DESIGN.md section 6).  The inputs of a call must stay untouched, and
  * its accept[] / status[] unread, until h2v_workspace_join(ws, stream) has been called and `stream` has reached that point
- * (stream = NULL: block the host instead).  Calls still start in submission order, each after whatever was enqueued on its
- * `stream` argument before it. */
+ * (stream = NULL: the HOST blocks until every chunk submitted so far is done; nothing is enqueued on the NULL stream).  Calls
+ * still start in submission order, each after whatever was enqueued on its `stream` argument before it.
+ * THE NULL STREAM (round 4).  The lanes run on library-owned streams with hardware queues of their own
+ * (hipExtStreamCreateWithCUMask), and those have the default flags: they are BLOCKING streams, ordered with the legacy NULL
+ * stream.  Any work a host puts on the NULL stream - PyTorch's default stream is that stream - waits for every lane and holds
+ * every lane back behind it, so the overlap of consecutive calls would be lost without an error.  Therefore, on a workspace
+ * with deferred joins, h2v_verify_batch_device / h2v_verify_batch_rlc_device return H2V_E_ARG for stream = NULL: give the
+ * calls a stream of their own (hipStreamCreateWithFlags(.., hipStreamNonBlocking); torch.cuda.Stream()) and keep other NULL-
+ * stream work (synchronous hipMemcpy included) out of the submission loop.  Without deferred joins NULL is accepted: every
+ * call then waits for its own chunks anyway.  tests/test_gpu_parity.py::test_null_stream_contract_of_deferred_joins. */
 int h2v_workspace_defer_joins(h2v_workspace *ws, int defer);
 int h2v_workspace_join(h2v_workspace *ws, void *stream);
 /* Launch-shape options of a workspace (round 3: what used to be reachable through environment variables only; results never
@@ -225,6 +235,12 @@ int h2v_probe_g1_decompress(int device, uint32_t n, const uint8_t *compressed, u
 /* sum_t s_t * B_t per group: n groups of T terms; scalars n*T*32 B LE, bases n*T*48 B compressed; out n*96 B affine BE */
 int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_t *scalars, const uint8_t *bases_compressed,
                      uint8_t *out_xy_be);
+/* the fixed-base launch of a split MSM on its own: sum over the plan's n_fix VK-base terms of s_t * B_t through the all-window
+ * tables built at h2v_plan_load (k_g1_msm_fixed, bases_per_lane = 1 .. 4 as the launcher would pick); scalars n * n_fix * 32 B
+ * LE in the order of the plan's VK-base terms, out n * 96 B affine BE; *n_fix_out (may be NULL) receives n_fix.  H2V_E_ARG for
+ * plans without such tables (recursive plans).  Edge scalars of the signed-window recoding: tests/test_gpu_parity.py */
+int h2v_probe_g1_msm_fixed(const h2v_plan *plan, uint32_t n, uint32_t bases_per_lane, const uint8_t *scalars, uint8_t *out_xy_be,
+                           uint32_t *n_fix_out);
 /* the bucket (Pippenger) MSM of the RLC mode on its own: sum_n s_n * B_n; scalars n*32 B LE (< r), bases n*48 B compressed
  * (encodings that do not decompress count as infinity); out 96 B affine BE (all-zero = infinity) */
 int h2v_probe_g1_msm_pippenger(int device, uint32_t n, const uint8_t *scalars, const uint8_t *bases_compressed,

@@ -213,8 +213,8 @@ class Workspace {
 class BatchStream {
   public:
     BatchStream(const VerifyingKey &vk, uint64_t max_batch, unsigned depth, bool rlc = false)
-        : depth_(depth), rlc_(rlc), ws_(vk, max_batch, depth == 0 ? 1u : depth, (uint32_t)max_batch) {
-        if (depth == 0) throw Error(H2V_E_ARG, "BatchStream: depth must be at least 1");
+        : depth_(depth), rlc_(rlc), ws_(vk, max_batch, depth == 0 || depth > 16 ? 1u : depth, (uint32_t)max_batch) {
+        if (depth == 0 || depth > 16) throw Error(H2V_E_ARG, "BatchStream: depth must be 1 .. 16 (a laned workspace has at most 16 lanes)");
     }
     BatchStream(const BatchStream &) = delete;
     BatchStream &operator=(const BatchStream &) = delete;

@@ -66,7 +66,7 @@ EXPORTS = [
     "h2v_workspace_join", "h2v_workspace_lanes", "h2v_workspace_depth", "h2v_workspace_set_option",
     "h2v_verify_batch", "h2v_verify_batch_submit", "h2v_verify_batch_wait", "h2v_verify_batch_device", "h2v_verify_batch_rlc", "h2v_verify_batch_rlc_device",
     "h2v_workspace_rlc_result", "h2v_probe_g1_msm_pippenger", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
-    "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_quad_madd", "h2v_probe_pairing", "h2v_probe_pairing_ex",
+    "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_g1_msm_fixed", "h2v_probe_quad_madd", "h2v_probe_pairing", "h2v_probe_pairing_ex",
     "h2v_last_error", "h2v_build_id",
     "h2v_device_count", "h2v_shutdown",
 ]
@@ -124,6 +124,7 @@ def lib():
         L.h2v_probe_blake2b.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p]
         L.h2v_probe_g1_decompress.argtypes = [C.c_int, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p]
         L.h2v_probe_g1_msm.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p]
+        L.h2v_probe_g1_msm_fixed.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_void_p, C.POINTER(C.c_uint32)]
         L.h2v_probe_pairing.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p]
         L.h2v_probe_pairing_ex.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
         L.h2v_shutdown.argtypes = [C.c_int]
@@ -278,7 +279,10 @@ class DevicePlan:
 class Workspace:
     """h2v_workspace.  lanes / chunk given (0 = the library's choice): a LANED workspace (h2v_workspace_create_lanes) -
     calls on it are cut into chunks that are pipelined through library-owned lanes; plain Workspace(plan, n) is laned by
-    itself from twice the plan's chunk size up."""
+    itself from FOUR TIMES the plan's chunk size up (h2v_workspace_create), an ordinary workspace below that.  A laned
+    workspace has at most 16 lanes (= host batches in flight through submit / wait), no trace buffer, and - with deferred
+    joins - refuses the legacy NULL stream: its lanes run on blocking streams, which any NULL-stream work (PyTorch's
+    default stream, a synchronous hipMemcpy) would drain (include/h2v.h: h2v_workspace_defer_joins)."""
 
     def __init__(self, plan: DevicePlan, max_batch: int, lanes: Optional[int] = None, chunk: Optional[int] = None):
         self._h = C.c_void_p()
@@ -361,8 +365,8 @@ class BatchStream:
     first.  The counterpart of h2v::BatchStream.  (Round 2 needed `depth` workspaces for this.)"""
 
     def __init__(self, plan: "DevicePlan", max_batch: int, depth: int, rlc: bool = False, seed: bytes = None):
-        if depth < 1:
-            raise H2VError("BatchStream: depth must be at least 1")
+        if depth < 1 or depth > 16:
+            raise H2VError("BatchStream: depth must be 1 .. 16 (a laned workspace has at most 16 lanes)")
         self.plan, self.rlc, self.seed, self.depth = plan, rlc, seed, depth
         self.ws = Workspace(plan, max_batch, lanes=depth, chunk=max_batch)
         self._n = []          # proofs of the batches in flight, oldest first
@@ -431,6 +435,21 @@ def probe_g1_msm(scalar_groups, base_groups, device: int = 0):
     bs = b"".join(b for g in base_groups for b in g)
     out = C.create_string_buffer(96 * n)
     check(lib().h2v_probe_g1_msm(device, n, T, sc, bs, out))
+    return [_unxy(out.raw[96 * i:96 * i + 96]) for i in range(n)]
+
+
+def probe_g1_msm_fixed(plan: DevicePlan, scalar_rows, bases_per_lane: int = 1):
+    """sum_t s_t * B_t over the plan's VK-base terms through the all-window tables (k_g1_msm_fixed); scalar_rows[i] = the
+    n_fix scalars of proof i (ints < r), in the order of the plan's VK-base terms.  n_fix() = probe_g1_msm_fixed(plan, None)."""
+    nf = C.c_uint32()
+    if scalar_rows is None:
+        lib().h2v_probe_g1_msm_fixed(plan.handle, 0, 1, None, None, C.byref(nf))
+        return nf.value
+    n = len(scalar_rows)
+    sc = b"".join(int(s).to_bytes(32, "little") for row in scalar_rows for s in row)
+    out = C.create_string_buffer(96 * n)
+    check(lib().h2v_probe_g1_msm_fixed(plan.handle, n, bases_per_lane, sc, out, C.byref(nf)))
+    assert all(len(row) == nf.value for row in scalar_rows)
     return [_unxy(out.raw[96 * i:96 * i + 96]) for i in range(n)]
 
 

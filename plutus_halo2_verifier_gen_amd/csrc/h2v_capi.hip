@@ -104,6 +104,7 @@ struct h2v_plan {
     void *fix_tab = nullptr;     // all-window tables of the VK bases (k_vk_fixed_tables at load; non-recursive plans)
     uint32_t n_var = 0, n_fix = 0;  // per-proof terms [0, n_var), VK-base terms [n_var, n_var + n_fix) when the list is so ordered
     uint32_t n_squeezes = 0, stream_len = 0;
+    uint64_t gen = 0;            // process-wide load counter: what caches key on (a freed plan's address may be reused)
     std::vector<uint32_t> trace_slots;
 };
 
@@ -430,6 +431,7 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
     p->n_squeezes = n_sq;
     p->stream_len = w[H2V_HW_STREAM_LEN];
     for (uint32_t k = 0; k < n_trace; k++) p->trace_slots.push_back(rd32(trp + 8 * k));
+    { static std::mutex mu; static uint64_t loads = 0; std::lock_guard<std::mutex> lock(mu); p->gen = ++loads; }
     reg_add(g_plan_live, p);
     *out = p;
     return H2V_OK;
@@ -659,10 +661,25 @@ extern "C" int h2v_workspace_defer_joins(h2v_workspace *ws, int defer) {
     ws->defer_joins = defer != 0;
     return H2V_OK;
 }
+// Deferred joins and the legacy NULL stream do not go together: the pool streams are created with the default flags
+// (hipExtStreamCreateWithCUMask has no non-blocking form), so every operation on the NULL stream - PyTorch's default stream
+// IS that stream - waits for all lanes and holds them back behind it: the pipelining would be lost without a word.  A
+// deferring workspace therefore refuses stream = NULL (H2V_STREAM_CUMASK=0 streams are non-blocking: allowed).
+static int null_stream_check(const h2v_workspace *ws, const void *stream) {
+    static const bool blocking_pool = []() { const char *e = getenv("H2V_STREAM_CUMASK"); return !e || atoi(e) != 0; }();
+    if (ws && ws->n_lanes && ws->defer_joins && stream == nullptr && blocking_pool)
+        return fail(H2V_E_ARG, "a workspace with deferred joins needs a stream of its own: the legacy NULL stream (PyTorch's default stream) is ordered with "
+                               "every library stream and would serialise the lanes - pass a non-default stream, or h2v_workspace_defer_joins(ws, 0)");
+    return H2V_OK;
+}
 // every lane that has work enqueued since the last join: `st` waits for its last chunk
-static int lanes_join(h2v_workspace *w, hipStream_t st) {
+static int lanes_join(h2v_workspace *w, hipStream_t st, bool host_block = false) {
     for (uint32_t l = 0; l < w->n_lanes; l++)
-        if (w->lane_busy[l]) { HIPCHK(hipStreamWaitEvent(st, w->lane_ev[l], 0)); w->lane_busy[l] = false; }
+        if (w->lane_busy[l]) {
+            if (host_block) HIPCHK(hipEventSynchronize(w->lane_ev[l]));
+            else HIPCHK(hipStreamWaitEvent(st, w->lane_ev[l], 0));
+            w->lane_busy[l] = false;
+        }
     return H2V_OK;
 }
 extern "C" int h2v_workspace_join(h2v_workspace *ws, void *stream) {
@@ -670,7 +687,9 @@ extern "C" int h2v_workspace_join(h2v_workspace *ws, void *stream) {
     ALIVE(ws);
     if (!ws->n_lanes) return H2V_OK;   // an ordinary workspace's calls are already ordered on the caller's stream
     HIPCHK(hipSetDevice(ws->device));
-    return lanes_join(ws, (hipStream_t)stream);
+    // stream = NULL: the HOST waits (the legacy NULL stream is never touched: every pool stream is a blocking stream, i.e.
+    // ordered with it, and a wait enqueued there would serialise all lanes)
+    return lanes_join(ws, (hipStream_t)stream, stream == nullptr);
 }
 extern "C" void h2v_workspace_free(h2v_workspace *w) {
     if (!w) return;
@@ -1358,6 +1377,7 @@ extern "C" int h2v_verify_batch_device(const h2v_plan *p, const h2v_batch *b, ui
     }
     if (int rcf = ws_fits(ws, p, b->n, false)) { if (tmp) h2v_workspace_free(tmp); return rcf; }
     if (ws->pending) return fail(H2V_E_ARG, "the workspace has a host batch in flight: call h2v_verify_batch_wait first");
+    if (int rcn = null_stream_check(ws, stream)) { if (tmp) h2v_workspace_free(tmp); return rcn; }
     if (ws->n_lanes) {
         int rcl = run_laned(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, false, nullptr, timings != nullptr);
         if (rcl == H2V_OK && timings) {
@@ -1797,7 +1817,10 @@ struct RlcWs {
     // verdict buffers of the groups, the argument array of their 2 G bucket MSMs and ONE pool for those MSMs' buffers
     struct Grp {
         uint32_t n = 0, G = 0, stride = 0, max_n = 0, acc_blocks = 0;
-        const void *key = nullptr;
+        uint64_t key_gen = 0;          // the plan (load counter) the cached arguments were built for
+        const uint32_t *key_pts = nullptr;
+        uint32_t cap_stride = 0;
+        std::vector<void *> staged;    // pinned host copies of argument arrays whose uploads may still be in flight
         uint32_t *g_scal = nullptr, *g_idx = nullptr, *er_g = nullptr, *el_g = nullptr, *pts_g = nullptr, *status_g = nullptr;
         uint8_t *valid_g = nullptr, *accept_g = nullptr, *pool = nullptr;
         PipArgs *args_d = nullptr;
@@ -1813,6 +1836,7 @@ static void rlc_release(RlcWs *r) {
     void *ptrs[] = {r->r_scal, r->r_idx, r->l_scal, r->l_idx, r->vk_part, r->good, r->sums, r->misc, r->flags, r->grp.g_scal, r->grp.g_idx, r->grp.er_g,
                     r->grp.el_g, r->grp.pts_g, r->grp.status_g, r->grp.valid_g, r->grp.accept_g, r->grp.pool, r->grp.args_d};
     for (void *q : ptrs) if (q) (void)hipFree(q);
+    for (void *q : r->grp.staged) (void)hipHostFree(q);   // (the caller has drained the streams: ws_release)
     pip_free(r->R); pip_free(r->L);
     for (auto &set : r->ring) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
     delete r;
@@ -1853,14 +1877,20 @@ static bool rlc_groups_on(uint32_t n) {
     static const int env = []() { const char *e = getenv("H2V_RLC_GROUPS"); return e ? atoi(e) : 1; }();
     return env != 0 && n >= GRP_MIN_N && (n + 63) / 64 <= GRP_MAX_G;
 }
-static int rlc_groups_ensure(RlcWs *r, const h2v_plan *p, h2v_workspace *w, uint32_t n) {
+// The argument array of the group stage is cached per (batch size, plan, point buffer).  When it has to change, the new one
+// is uploaded ON THE CALL'S STREAM from a pinned host copy: the kernels of an earlier call on that stream read args_d when
+// they run, and a synchronous hipMemcpy (through the NULL stream, not ordered with a non-blocking caller stream) could
+// hand them the new batch size's pointers.  The key is the plan's load counter, not its address.
+static int rlc_groups_ensure(RlcWs *r, const h2v_plan *p, h2v_workspace *w, uint32_t n, hipStream_t st) {
     RlcWs::Grp &g = r->grp;
     const uint32_t G = (n + 63) / 64, slots = H2V_SLOTS(p->d);
-    if (g.n == n && g.key == (const void *)p->blob) return H2V_OK;
     const uint32_t W = 128 / GRP_C + 1, NB = 1u << (GRP_C - 1), nb = W * NB, stride = 64 * p->n_var + p->n_fix;
-    if (G > g.cap_G) {
+    if (g.n == n && g.key_gen == p->gen && g.key_pts == w->pts && g.stride == stride) return H2V_OK;
+    if (G > g.cap_G || stride > g.cap_stride) {
+        HIPCHK(hipStreamSynchronize(st));     // (the buffers about to be freed may be in use by the previous call)
         void *old[] = {g.g_scal, g.g_idx, g.er_g, g.el_g, g.pts_g, g.status_g, g.valid_g, g.accept_g, g.pool, g.args_d};
         for (void *q : old) if (q) (void)hipFree(q);
+        for (void *q : g.staged) (void)hipHostFree(q);
         g = RlcWs::Grp();
         auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t per_r = up((size_t)stride * PIP_PT_DW * 4) + up((size_t)stride * 2 * W * 2) + up((size_t)stride * 2 * W * 4),
@@ -1875,7 +1905,7 @@ static int rlc_groups_ensure(RlcWs *r, const h2v_plan *p, h2v_workspace *w, uint
                   hipMemset(g.valid_g, 1, G) == hipSuccess && hipMalloc((void **)&g.accept_g, G) == hipSuccess &&
                   hipMalloc((void **)&g.pool, g.pool_bytes) == hipSuccess && hipMalloc((void **)&g.args_d, (size_t)2 * G * sizeof(PipArgs)) == hipSuccess;
         if (!ok) return fail(H2V_E_DEVICE, "hipMalloc(RLC group stage) failed");
-        g.cap_G = G;
+        g.cap_G = G; g.cap_stride = stride;
     }
     // the argument array: problem 2 q = the right-hand sum of group q, 2 q + 1 its left-hand sum
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -1914,12 +1944,21 @@ static int rlc_groups_ensure(RlcWs *r, const h2v_plan *p, h2v_workspace *w, uint
         }
     }
     if ((size_t)(cur - g.pool) > g.pool_bytes) return fail(H2V_E_DEVICE, "RLC group pool overrun");
-    HIPCHK(hipMemcpy(g.args_d, args.data(), args.size() * sizeof(PipArgs), hipMemcpyHostToDevice));   // (once per batch size)
-    g.n = n; g.G = G; g.stride = stride; g.max_n = max_n; g.acc_blocks = acc_blocks; g.key = (const void *)p->blob;
+    if (g.staged.size() >= 8) {               // (a workspace whose batch size keeps alternating: drain, then reuse)
+        HIPCHK(hipStreamSynchronize(st));
+        for (void *q : g.staged) (void)hipHostFree(q);
+        g.staged.clear();
+    }
+    void *pinned = nullptr;
+    if (hipHostMalloc(&pinned, args.size() * sizeof(PipArgs), hipHostMallocDefault) != hipSuccess) return fail(H2V_E_DEVICE, "staging allocation failed");
+    g.staged.push_back(pinned);
+    memcpy(pinned, args.data(), args.size() * sizeof(PipArgs));
+    HIPCHK(hipMemcpyAsync(g.args_d, pinned, args.size() * sizeof(PipArgs), hipMemcpyHostToDevice, st));   // behind the earlier call's kernels
+    g.n = n; g.G = G; g.stride = stride; g.max_n = max_n; g.acc_blocks = acc_blocks; g.key_gen = p->gen; g.key_pts = w->pts;
     return H2V_OK;
 }
 static int rlc_groups_launch(RlcWs *r, const h2v_plan *p, h2v_workspace *w, uint32_t n, uint8_t *accept, const H2vDevPlan &d1, hipStream_t st) {
-    int rc = rlc_groups_ensure(r, p, w, n);
+    int rc = rlc_groups_ensure(r, p, w, n, st);
     if (rc) return rc;
     RlcWs::Grp &g = r->grp;
     const uint32_t G = g.G;
@@ -2072,6 +2111,7 @@ extern "C" int h2v_verify_batch_rlc_device(const h2v_plan *p, const h2v_batch *b
     HIPCHK(hipSetDevice(p->device));
     if ((rc = ws_fits(ws, p, b->n, false))) return rc;
     if (ws->pending) return fail(H2V_E_ARG, "the workspace has a host batch in flight: call h2v_verify_batch_wait first");
+    if ((rc = null_stream_check(ws, stream))) return rc;
     // recursive plans fold an accumulator per proof (the challenge hashes that proof's own MSM result): no batch form
     if (!rlc_supported(p)) {
         if (ws->n_lanes) return run_laned(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, false, nullptr, false);
@@ -2298,6 +2338,31 @@ extern "C" int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_
     if (dtab.alloc((size_t)n * T * 448 * 4)) return fail(H2V_E_DEVICE, "hipMalloc failed");
     hipLaunchKernelGGL(k_g1_decompress, dim3((n * T + 63) / 64), dim3(128), 0, nullptr, mp.d, n, din.as<uint8_t>(), doff.as<uint64_t>(), (const uint8_t *)nullptr, (const uint8_t *)nullptr, dpts.as<uint32_t>(), dvalid.as<uint8_t>(), dtab.as<uint32_t>(), 0u, (uint8_t *)nullptr);
     launch_msm(mp.d, n, dsc.as<uint32_t>(), dpts.as<uint32_t>(), dtab.as<uint32_t>(), der.as<uint32_t>(), nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 1, der.as<uint32_t>(), dout.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_xy_be, dout.p, (size_t)n * 96, hipMemcpyDeviceToHost));
+    return H2V_OK;
+}
+
+// the fixed-base launch of a split MSM over the plan's own VK-base terms, scalars given by the caller
+extern "C" int h2v_probe_g1_msm_fixed(const h2v_plan *p, uint32_t n, uint32_t k, const uint8_t *scalars, uint8_t *out_xy_be, uint32_t *n_fix_out) {
+    if (!p) return fail(H2V_E_ARG, "bad argument");
+    ALIVE(p);
+    if (n_fix_out) *n_fix_out = p->n_fix;
+    if (!p->fix_tab || !p->n_fix) return fail(H2V_E_ARG, "this plan has no fixed-base tables");
+    if (!scalars || !out_xy_be || n == 0 || k == 0 || k > 4) return fail(H2V_E_ARG, "bad argument");
+    HIPCHK(hipSetDevice(p->device));
+    const H2vDevPlan &d = p->d;
+    DevBuf dsc, der, dout;
+    if (dsc.alloc((size_t)n * d.n_fix * 32) || der.alloc((size_t)n * 144) || dout.alloc((size_t)n * 96)) return fail(H2V_E_DEVICE, "hipMalloc failed");
+    HIPCHK(hipMemcpy(dsc.p, scalars, (size_t)n * d.n_fix * 32, hipMemcpyHostToDevice));
+    H2vMsmArgs mf = {d.terms, d.n_var, d.n_fix, d.n_fix, 0, (uint32_t)H2V_SLOTS(d), {d.n_fix, d.n_fix, d.n_fix}, {der.as<uint32_t>(), nullptr, nullptr}, nullptr, d.vk_tab,
+                     d.fix_tab, k, (d.n_fix + k - 1) / k};
+    const uint32_t bs = mf.n_fixl <= 64 ? 64u : mf.n_fixl <= 256 ? 256u : 512u;
+    if (mf.n_fixl > bs) return fail(H2V_E_LIMIT, "too many VK bases for one block");
+    const uint32_t pbf = bs / mf.n_fixl;
+    hipLaunchKernelGGL(k_g1_msm_fixed, dim3((n + pbf - 1) / pbf), dim3(bs), (size_t)bs * 172, nullptr, d, mf, n, pbf, dsc.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_export_points, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, 1, der.as<uint32_t>(), dout.as<uint8_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());

@@ -662,9 +662,12 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
         // The accumulator of one base is [a]V with a = the signed-digit prefix read so far (most significant window first),
         // a multiple of B^(w+1), B = 2^c; adding [d B^w]V is exceptional iff a -+ d B^w = 0 mod r.  As integers |a -+ d B^w| <
         // 2^265, so that means a -+ d B^w = m r with |m| small: 0 is excluded by the digits' size (|d| <= B/2 < B) unless
-        // a = d = 0, and m r is not = -+d B^w modulo B^(w+1) for w > 0 (r is odd: m r = 0 mod B^w needs B^w | m), while for
-        // w = 0 a + d_0 is the whole scalar, which is canonical (< r) and not 0 here.  So the additions of a base are
-        // unchecked (c = 4: 65, c = 8: 33, c = 12: 22 of them); sums of different bases meet in complete ones.
+        // a = d = 0, and m r is not = -+d B^w modulo B^(w+1) for w > 0 (r is odd: m r = 0 mod B^w needs B^w | m).  So the
+        // additions of the windows w > 0 are unchecked.  For w = 0 the sum a + d_0 is the whole scalar (canonical, not 0: never
+        // the inverse), but the DOUBLING case a = d_0 mod r is reachable: r = 1 mod 2^32, so the scalar r - 2 recodes to
+        // d_0 = -1 with prefix a = r - 1, i.e. acc = -V and the entry added is -V (the one such scalar, for c = 4, 8 and 12 -
+        // ADVICE r3).  The last window of a base therefore goes through the complete law (one addition in 22 .. 65); sums of
+        // different bases meet in complete ones as well.
         const uint32_t f0 = sub * ma.fix_k;
 #pragma unroll 1
         for (uint32_t j = 0; j < ma.fix_k; j++) {
@@ -710,6 +713,11 @@ H2V_DI void msm_body(const H2vDevPlan &plan, const H2vMsmArgs &ma, uint32_t n, u
                     if (d < 0) { F28_NEG(acc.y, qy, 3, 1); f28_carry(acc.y); }
                     f28_set_one(acc.z);
                     acc_inf = false;
+                } else if (q == 0) {
+                    G1J28 qq;                                        // w = 0: complete (see above)
+                    qq.x = qx; qq.y = qy;
+                    f28_set_one(qq.z);
+                    g1j28_acc_add(acc, acc_inf, qq, d < 0);
                 } else {
                     g1j28_madd_ladder(acc, acc, qx, qy, d < 0);
                 }

@@ -127,6 +127,68 @@ def test_g1_msm(be, orc):
             assert r == orc.g1_msm(ss, ps)
 
 
+def test_g1_msm_fixed_base_edge_scalars(be, orc, circuits):
+    """The fixed-base launch of a split MSM (k_g1_msm_fixed: signed 12-bit windows over all-window tables of the VK bases) on its
+    own, against the oracle's fold, on the scalars at the edges of the recoding - among them r - 2, the ONE scalar whose last
+    window is a doubling (digit -1 onto the prefix r - 1: ADVICE r3), r - 1, 0, 1, window borders, all-ones windows - with 1, 2
+    and 4 bases per lane."""
+    rng = random.Random(21)
+    for name in ("simple_mul", "lookup_table"):
+        vk, td, pl, dp, ov = circuits[name]
+        from plutus_halo2_verifier_gen_amd import plan as PL
+        bases = [pl.vk_bases[idx] for kind, idx in pl.terms if kind == PL.TERM_VK_BASE]
+        nf = be.probe_g1_msm_fixed(dp, None)
+        assert nf == len(bases) and nf > 0
+        edge = [R - 2, R - 1, 0, 1, 2, 2047, 2048, 2049, 4095, 4096, (1 << 12) - 1, (1 << 24) - 1, (1 << 252) + 2048, R - 2049, R - 2048, R - 2047,
+                int("800" * 21, 16) % R, int("7ff" * 21, 16) % R, int("801" * 21, 16) % R, (R - 2) // 2, (R + 1) // 2]
+        rows = []
+        for e in edge:                                   # the edge scalar on every base in turn, random ones elsewhere
+            for t in range(nf):
+                row = [rng.randrange(R) for _ in range(nf)]
+                row[t] = e
+                rows.append(row)
+        rows.append([R - 2] * nf)
+        rows.append([0] * nf)
+        for k in (1, 2, 4):
+            got = be.probe_g1_msm_fixed(dp, rows, bases_per_lane=k)
+            for row, r in zip(rows, got):
+                assert r == orc.g1_msm(row, bases), (name, k, [hex(x) for x in row])
+
+
+def test_null_stream_contract_of_deferred_joins(be, circuits):
+    """include/h2v.h, h2v_workspace_defer_joins: the lanes run on blocking streams, so a deferring workspace refuses the
+    legacy NULL stream (PyTorch's default stream) with H2V_E_ARG instead of silently serialising; without deferred joins NULL
+    is accepted; h2v_workspace_join(ws, NULL) blocks the HOST (results readable right after it, nothing on the NULL stream)."""
+    import torch
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    n = 150
+    b = synth.forge_batch(vk, td, n, seed=8, plan=pl, workers=2)
+    b = synth.with_rejects(pl, b, vk.n_public_inputs, fraction=0.2, seed=9, kinds=list(synth.CORRUPTIONS))
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.frombuffer(bytearray(x), dtype=torch.uint8).to(dev)
+    dpr, din = up(b.proofs), up(b.instances)
+    dof = torch.tensor(b.proof_off, dtype=torch.int64).to(dev)
+    ws = be.Workspace(dp, n, lanes=3, chunk=40)
+    acc = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+    dp.verify_batch_device(n, dpr.data_ptr(), dof.data_ptr(), din.data_ptr(), None, acc.data_ptr(), None, ws=ws, stream=None)   # joins not deferred: fine
+    torch.cuda.synchronize()
+    assert acc.cpu().tolist() == b.expected
+    ws.defer_joins(True)
+    with pytest.raises(be.H2VError, match="NULL stream"):
+        dp.verify_batch_device(n, dpr.data_ptr(), dof.data_ptr(), din.data_ptr(), None, acc.data_ptr(), None, ws=ws, stream=None)
+    with pytest.raises(be.H2VError, match="NULL stream"):
+        dp.verify_batch_rlc_device(n, dpr.data_ptr(), dof.data_ptr(), din.data_ptr(), None, acc.data_ptr(), None, ws=ws, stream=None)
+    s = torch.cuda.Stream(device=dev)
+    accs = [torch.full((n,), 9, dtype=torch.uint8, device=dev) for _ in range(4)]
+    for a in accs:
+        dp.verify_batch_device(n, dpr.data_ptr(), dof.data_ptr(), din.data_ptr(), None, a.data_ptr(), None, ws=ws, stream=s.cuda_stream)
+    ws.join(None)                                    # the host waits; no torch synchronisation before the reads below
+    for a in accs:
+        assert a.cpu().tolist() == b.expected
+    ws.close()
+
+
 def test_batch_stream_keeps_batches_in_flight(be, circuits):
     """backend.BatchStream (depth 4: the in-flight launch shapes) over nine batches of different content and size, per proof
     and RLC: every collected vector is the blocking call's, in order."""

@@ -232,6 +232,53 @@ def test_rlc_fallback_localises_rejects(be, circuits, name, n, n_rej):
     ws.close()
 
 
+def test_rlc_two_batch_sizes_in_flight_on_one_workspace(be, circuits):
+    """the group stage of the fall-back caches its argument array per batch size.  Two RLC calls of
+    DIFFERENT sizes back to back on ONE ordinary workspace and ONE non-default stream, nothing synchronised in between, the
+    first holding a reject only the pairing catches (so its group kernels read the arguments when they finally run): the
+    upload of the second size's arguments is ordered behind them on the stream, and both vectors are the construction's.
+    Then the same workspace with ANOTHER plan whose MSM has more per-proof terms (the cache is keyed on the plan's load
+    counter and on the term-list stride, not on an address)."""
+    import torch
+    from plutus_halo2_verifier_gen_amd import synth
+    dev = torch.device("cuda", 0)
+    up = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) if b else None
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    s = torch.cuda.Stream(device=dev)
+
+    def make(name, n, seed, victims):
+        vk, td, pl, dp, ov = circuits[name]
+        n_pi = vk.n_public_inputs
+        good = synth.forge_batch(vk, td, n, seed=seed, plan=pl, workers=8)
+        rng = random.Random(seed)
+        proofs = [good.proof(i) for i in range(n)]
+        insts = [good.instances[32 * n_pi * i:32 * n_pi * (i + 1)] for i in range(n)]
+        exp = [1] * n
+        for i in victims:
+            proofs[i], insts[i] = synth.corrupt(pl, proofs[i], insts[i], "wrong_pi", rng)
+            exp[i] = 0
+        off = [0]
+        for p_ in proofs:
+            off.append(off[-1] + len(p_))
+        d = (up(b"".join(proofs)), torch.tensor(off, dtype=torch.int64).to(dev), up(b"".join(insts)), up(good.committed))
+        return dp, n, exp, d
+
+    big = make("lookup_table", 1100, 61, [700])
+    ws = be.Workspace(big[0], 1100, lanes=None, chunk=None)
+    assert ws.lanes()[0] == 1
+    seq = [make("simple_mul", 1000, 62, [3]), make("simple_mul", 520, 63, []), make("simple_mul", 777, 64, [600, 601]), big,
+           make("simple_mul", 1000, 65, [999])]
+    outs = []
+    for dp, n, exp, d in seq:
+        acc = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+        dp.verify_batch_rlc_device(n, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), acc.data_ptr(), None, ws=ws, stream=s.cuda_stream, seed=bytes(range(32)))
+        outs.append((acc, exp))
+    s.synchronize()
+    for k, (acc, exp) in enumerate(outs):
+        assert acc.cpu().tolist() == exp, k
+    ws.close()
+
+
 def test_rlc_duplicate_proofs_and_small_batches(be, circuits):
     """The same proof many times in one batch (equal points with different coefficients meet in the buckets), batches of
     1 and 2 proofs, and a recursive plan (no batch form: runs per proof behind the same entry point)."""

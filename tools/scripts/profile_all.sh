@@ -5,6 +5,7 @@
 P=$1
 S=tools/scripts/profile_round.sh
 bash $S ${P} simple_mul 4096 per-proof > gpurun_out/pa_${P}.log 2>&1 || exit 1
+bash $S ${P}_lookup_atms_mixed lookup_atms_mixed 2048 per-proof >> gpurun_out/pa_${P}.log 2>&1 || exit 1   # BASELINE configs[2] as named: both plans in flight
 bash $S ${P}_lookup_mixed lookup_mixed 2048 per-proof >> gpurun_out/pa_${P}.log 2>&1 || exit 1
 bash $S ${P}_atms atms_with_lookups 2048 per-proof >> gpurun_out/pa_${P}.log 2>&1 || exit 1
 bash $S ${P}_sha256_1024 sha256 1024 per-proof >> gpurun_out/pa_${P}.log 2>&1 || exit 1

@@ -35,7 +35,7 @@ for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU" "FET
   n=$(echo $c | cut -d" " -f1)
   timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${TAG}_$n -- python3 bench.py $ARGS --steps 2 --warmup 1 --timed-only --no-alone --pipeline streams --inflight 1 --hint $INF > $O/pmc_${TAG}_$n.log 2>&1 || fail "4 ($n)" $? $O/pmc_${TAG}_$n.log
 done
-{ echo "# workload=$WL batch=$BATCH mode=$MODE tag=$TAG (rocprofv3 --pmc, separate passes; bench.py $ARGS --steps 2 --warmup 1 --timed-only --no-alone --pipeline streams --inflight 1 --hint $INF)"; python tools/pmc_summary.py $O/pmc_${TAG}_*; } > $O/${TAG}_pmc_summary.txt
+{ echo "# workload=$WL batch=$BATCH mode=$MODE pmc_steps=3 tag=$TAG (rocprofv3 --pmc, separate passes; bench.py $ARGS --steps 2 --warmup 1 --timed-only --no-alone --pipeline streams --inflight 1 --hint $INF)"; python tools/pmc_summary.py $O/pmc_${TAG}_*; } > $O/${TAG}_pmc_summary.txt
 cp $O/${TAG}_pmc_summary.txt profiles/${TAG}_pmc_summary.txt    # (on the box: the final line below reads it)
 # 5. the line
 timeout -k 10 400 python bench.py $ARGS > $O/b_$TAG.log 2>&1 || fail 5 $? $O/b_$TAG.log
