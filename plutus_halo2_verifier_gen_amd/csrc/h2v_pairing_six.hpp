@@ -29,6 +29,7 @@
 #include "h2v_pairing_coop.hpp"
 #include "six_tables.h"
 
+#define H2V_NO_TAIL_MARK __attribute__((disable_tail_calls))
 #define SIX_GROUPS 10
 #define SIX_SLOT_DW 14
 #define SIX_GROUP_DW (SIX_N_GROUP_SLOTS * SIX_SLOT_DW)
@@ -131,8 +132,13 @@ H2V_DI void six_reduce(F28 &r, uint64_t (&acc)[28]) {
         r.l[13] = (uint32_t)(carry + acc[27]);
     }
 }
-// NT Karatsuba terms from the lane's table row (4 slot bytes per term: x0 y0 x1 y1) -> (re, im), both below 3p
-H2V_DN SixRegs six_kara(const Six c, const int tab_row_byte, const int nt) {
+// NT Karatsuba terms from the lane's table row (4 slot bytes per term: x0 y0 x1 y1) -> (re, im), both below 3p.
+// The result does not come back through the call: it is written, carried, into the lane's own A slots (2k, 2k + 1) - every
+// operand slot is dead once the last term has been read (one wave per block: the lanes have all read before any writes) -
+// and the caller reads it from there (six_result).  A 28-dword struct is returned through private memory by the calling
+// convention: a store, a wait for it, and a load per engine call, ~550 calls per pairing (round 3: the kernel's scratch
+// traffic).  keep (per lane): leave the A slots as they are - the staged input survives (line steps of a skipped loop).
+H2V_DN void six_kara(const Six c, const int tab_row_byte, const int nt, const bool keep) {
     const uint8_t *tab = reinterpret_cast<const uint8_t *>(coop_lds + SIX_TAB_OFF) + tab_row_byte;
     uint64_t U[28], V[28], W[28];
 #pragma unroll
@@ -156,14 +162,15 @@ H2V_DN SixRegs six_kara(const Six c, const int tab_row_byte, const int nt) {
     SixF2 r;
     six_reduce<false>(r.im, W);
     six_reduce<true>(r.re, U);
-    SixRegs o;
-    o.re = f28_pack(r.re);
-    o.im = f28_pack(r.im);
-    return o;
+    if (c.act && !keep) {
+        six_store(six_slot(c, SIX_SLOT_A + 2 * c.k), r.re);
+        six_store(six_slot(c, SIX_SLOT_A + 2 * c.k + 1), r.im);
+    }
 }
 // cyclotomic squaring: five products (x + x2) y into U, U, V, W, W (3 slot bytes each; gen_six_tables.py: csqr_table) ->
 // re = U - V (signed columns), im = W + V, reduced: re below 2.2p, im below 1.2p.  The lane finishes with 3 r -/+ 2 g (six_csqr).
-H2V_DN SixRegs six_csqr_engine(const Six c, const int tab_row_byte) {
+// Result into the lane's B slots (the doubled operand D, dead by then); the A slots keep g for the caller.
+H2V_DN void six_csqr_engine(const Six c, const int tab_row_byte) {
     const uint8_t *tab = reinterpret_cast<const uint8_t *>(coop_lds + SIX_TAB_OFF) + tab_row_byte;
     uint64_t U[28], V[28], W[28];
 #pragma unroll
@@ -190,10 +197,10 @@ H2V_DN SixRegs six_csqr_engine(const Six c, const int tab_row_byte) {
     SixF2 r;
     six_reduce<true>(r.re, U);
     six_reduce<false>(r.im, W);
-    SixRegs o;
-    o.re = f28_pack(r.re);
-    o.im = f28_pack(r.im);
-    return o;
+    if (c.act) {
+        six_store(six_slot(c, SIX_SLOT_B + 2 * c.k), r.re);
+        six_store(six_slot(c, SIX_SLOT_B + 2 * c.k + 1), r.im);
+    }
 }
 // one product of two staged slots, reduced (< 2p)
 H2V_DN F28Regs six_prod(const Six c, const int xs, const int ys) {
@@ -206,6 +213,12 @@ H2V_DN F28Regs six_prod(const Six c, const int xs, const int ys) {
     F28 r;
     six_reduce<false>(r, acc);
     return f28_pack(r);
+}
+// an engine's result (or a staged value) back from the lane's slots `base + 2k`, `base + 2k + 1`; shadow lanes read group 9's
+H2V_DI SixF2 six_result(const Six &c, const int base) {
+    SixF2 r;
+    six_load_pair(r.re.l, r.im.l, six_slot(c, base + 2 * c.k), six_slot(c, base + 2 * c.k + 1));
+    return r;
 }
 H2V_DI SixF2 six_unpack(const SixRegs &z) {
     SixF2 r;
@@ -247,25 +260,26 @@ H2V_DI SixF2 six_mul(const Six &c, const SixF2 &a, const SixF2 &b) {
     six_stage_a(c, a, 1);
     six_stage_b(c, b);
     __syncthreads();
-    const SixF2 r = six_unpack(six_kara(c, SIX_TAB_MUL_B + c.k * 4 * SIX_N_MUL, SIX_N_MUL));
+    six_kara(c, SIX_TAB_MUL_B + c.k * 4 * SIX_N_MUL, SIX_N_MUL, false);
     __syncthreads();
-    return r;
+    return six_result(c, SIX_SLOT_A);
 }
 H2V_DI SixF2 six_sqr(const Six &c, const SixF2 &a) {
     six_stage_a(c, a, 3);
     six_stage_d(c, a);
     __syncthreads();
-    const SixF2 r = six_unpack(six_kara(c, SIX_TAB_SQR_B + c.k * 4 * SIX_N_SQR, SIX_N_SQR));
+    six_kara(c, SIX_TAB_SQR_B + c.k * 4 * SIX_N_SQR, SIX_N_SQR, false);
     __syncthreads();
-    return r;
+    return six_result(c, SIX_SLOT_A);
 }
+// f times the line of loop LOOP; skip (per proof: that loop's G1 argument is infinity): f comes back unchanged
 template <int LOOP>
-H2V_DI SixF2 six_line(const Six &c, const SixF2 &f) {
+H2V_DI SixF2 six_line(const Six &c, const SixF2 &f, const bool skip) {
     six_stage_a(c, f, 3);
     __syncthreads();
-    const SixF2 r = six_unpack(six_kara(c, (LOOP == 1 ? SIX_TAB_LINE1_B : SIX_TAB_LINE2_B) + c.k * 4 * SIX_N_LINE, SIX_N_LINE));
+    six_kara(c, (LOOP == 1 ? SIX_TAB_LINE1_B : SIX_TAB_LINE2_B) + c.k * 4 * SIX_N_LINE, SIX_N_LINE, skip);
     __syncthreads();
-    return r;
+    return six_result(c, SIX_SLOT_A);
 }
 H2V_DI SixF2 six_csqr(const Six &c, const SixF2 &a) {
     if (c.act) {
@@ -289,14 +303,16 @@ H2V_DI SixF2 six_csqr(const Six &c, const SixF2 &a) {
         }
     }
     __syncthreads();
-    SixF2 r = six_unpack(six_csqr_engine(c, SIX_TAB_CSQR_B + c.k * 16));
+    six_csqr_engine(c, SIX_TAB_CSQR_B + c.k * 16);
     __syncthreads();
+    SixF2 r = six_result(c, SIX_SLOT_B);
+    const SixF2 g = six_result(c, SIX_SLOT_A);      // (a itself, read back: nothing of it stays live across the engine call)
     // h_k = 3 Q_k - 2 g_k (k even) / + 2 g_k (k odd), folded: 3 r + (13p - 2g | 2g) is below 20p (r < 2.2p, g < 6p), the fold
     // brings it below 2p.  (The other engines multiply g by the constants -/+ 2/3 inside the sum: two products more per lane.)
     const bool minus = (c.k & 1) == 0;
 #pragma unroll
     for (int i = 0; i < 14; i++) {
-        const uint32_t g0 = a.re.l[i] << 1, g1 = a.im.l[i] << 1;
+        const uint32_t g0 = g.re.l[i] << 1, g1 = g.im.l[i] << 1;
         r.re.l[i] = 3u * r.re.l[i] + (minus ? F28_BIAS_13_2[i] - g0 : g0);
         r.im.l[i] = 3u * r.im.l[i] + (minus ? F28_BIAS_13_2[i] - g1 : g1);
     }
@@ -335,7 +351,8 @@ H2V_DI SixF2 six_frob(const Six &c, const SixF2 &a) {   // a -> a^p: coefficient
 // lane 0 of the group inverts that one Fp2 element (one Fp inversion), and 1/N = adj / Norm(N).  Four Frobenius maps and four
 // engine products more than the tower inversion the other engines run on their first lane - and 1.2 KB less scratch per lane
 // (Fp6 temporaries and the frames of fp6_inv), which is what a queue's scratch arena is sized by.
-H2V_DN SixRegs six_inv_raw(const Six c, const SixRegs fr, bool &ok) {
+// (H2V_NO_TAIL_MARK: see k_pairing_six)
+H2V_DN H2V_NO_TAIL_MARK SixRegs six_inv_raw(const Six c, const SixRegs fr, bool &ok) {
     const SixF2 f = six_unpack(fr);
     const SixF2 fc = six_conj(c, f);
     const SixF2 nrm = six_mul(c, f, fc);                       // N
@@ -372,7 +389,12 @@ H2V_DI void six_line_store(int shared_slot, const uint2 v, int lane) {
     dst[1] = v.y;
 }
 
-extern "C" __global__ void __launch_bounds__(64, 2)
+// The engines return nothing and take no pointer into their caller's frame, so LLVM would mark their call sites `tail`; a
+// callee with a `tail`-marked call site is excluded from the interprocedural register allocation's no-callee-saved-registers
+// form (TargetFrameLowering::isSafeForNoCSROpt), and six_kara - which uses every register - would save and restore all 112
+// callee-saved VGPRs through private memory on every call (seen: 106 stores + 106 loads per call).  The callers therefore
+// opt out of tail-call marking.
+extern "C" __global__ void __launch_bounds__(64, 2) H2V_NO_TAIL_MARK
 k_pairing_six(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, const uint8_t *__restrict__ valid, const uint8_t *__restrict__ valid_sub,
               const uint32_t *__restrict__ er_jac, const uint32_t *__restrict__ el_jac /* folded el (recursion) or NULL */,
               uint32_t *__restrict__ status, uint8_t *__restrict__ accept, uint32_t *__restrict__ dbg) {
@@ -475,10 +497,8 @@ k_pairing_six(H2vDevPlan plan, uint32_t n, const uint32_t *__restrict__ pts, con
                         const F28Regs z = six_prod(c, (u ? SIX_SLOT_LN2 : SIX_SLOT_LN1) + part, u ? SIX_SLOT_PX2 : SIX_SLOT_PX1);
                         if (c.act && c.k < 4) six_store(six_slot(c, (u ? SIX_SLOT_T2 : SIX_SLOT_T1) + part), f28_unpack(z.a, z.b, z.c, z.d));
                     }
-                    const SixF2 r1 = six_line<1>(c, f);             // (its staging barrier also covers the T slots)
-                    if (!skip1) f = r1;
-                    const SixF2 r2 = six_line<2>(c, f);
-                    if (!skip2) f = r2;
+                    f = six_line<1>(c, f, skip1);                   // (its staging barrier also covers the T slots)
+                    f = six_line<2>(c, f, skip2);
                 }
             }
             vars[COOP_VAR_F] = f;
