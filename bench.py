@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--msm-tpl", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="per-proof MSM: terms per lane (h2v_workspace_set_option; 2 .. 4 share the doublings of a lane's terms)")
     ap.add_argument("--pairing", type=int, default=0, choices=[0, 1, 6, 12, 16, 32, 64], help="pairing engine: lanes per proof (h2v_workspace_set_option; 0: the launcher's choice)")
+    ap.add_argument("--no-tune", action="store_true", help="skip h2v_workspace_tune (the untimed measurement of the candidate launch shapes on this batch before the "
+                                                         "warm-up steps); the launcher's own thresholds then decide")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo = rehearsal of the N > 1 code path on a box with one GPU "
                          "(every rank on the device H2V_BENCH_DEVICE names, accept bytes gathered through host memory)")
@@ -277,11 +279,11 @@ def main():
         return (P.B, P.d_proofs.data_ptr(), P.d_off.data_ptr(), P.d_inst.data_ptr(), P.d_ci.data_ptr() if P.d_ci is not None else None,
                 acc.data_ptr() + P.off, st_.data_ptr() + 4 * P.off)
 
-    def apply_options(ws):
-        if args.msm_tpl:
-            ws.set_option(backend.Workspace.OPT_MSM_TERMS_PER_LANE, args.msm_tpl)
-        if args.pairing:
-            ws.set_option(backend.Workspace.OPT_PAIRING_ENGINE, args.pairing)
+    def apply_options(ws, P):
+        """forced shapes (--msm-tpl / --pairing), else what h2v_workspace_tune chose for this part's plan in the timed run"""
+        tpl, eng = args.msm_tpl or getattr(P, "tuned", (0, 0))[1], args.pairing or getattr(P, "tuned", (0, 0))[0]
+        ws.set_option(backend.Workspace.OPT_MSM_TERMS_PER_LANE, tpl)
+        ws.set_option(backend.Workspace.OPT_PAIRING_ENGINE, eng)
 
     class Run:
         """what a timed run leaves behind: elapsed seconds, the last step's accept bytes, per-step kernel timings per part"""
@@ -323,13 +325,21 @@ def main():
         """--pipeline lanes: every step is one call per part on that part's ONE laned workspace; joins are deferred, so the
         library keeps as many steps in flight as it has lanes.  One workspace per plan, one caller stream."""
         wss = [backend.Workspace(P.dp, P.B, lanes=args.lanes if lanes is None else lanes, chunk=0) for P in parts]
-        for ws in wss:
+        for ws, P in zip(wss, parts):
             ws.defer_joins(True)
-            apply_options(ws)
+            apply_options(ws, P)
             if args.hint:
                 ws.hint_in_flight(args.hint)
         n_lanes = max(ws.lanes()[0] for ws in wss)
         in_flight = min(ws.depth(P.B, mode == "rlc") for ws, P in zip(wss, parts))
+        if mode == "per-proof" and not args.no_tune and not args.msm_tpl and not args.pairing and not any(hasattr(P, "tuned") for P in parts):
+            # untimed: the library measures its candidate launch shapes on this very batch, in this very regime (all lanes busy)
+            tuned_state.clear()
+            for P, ws in zip(parts, wss):
+                r_ = ws.tune(P.dp, P.B, P.d_proofs.data_ptr(), P.d_off.data_ptr(), P.d_inst.data_ptr(), P.d_ci.data_ptr() if P.d_ci is not None else None, caller.cuda_stream)
+                P.tuned = (r_.pairing_engine, r_.msm_terms_per_lane)
+                tuned_state.append({"circuit": P.name, "pairing_engine": r_.pairing_engine, "msm_terms_per_lane": r_.msm_terms_per_lane, "configurations_measured": r_.n_measured,
+                                    "ms_per_call_launchers_rule": round(r_.default_ms, 4), "ms_per_call_chosen": round(r_.best_ms, 4)})
         d_accepts = [torch.zeros(B, dtype=torch.uint8, device=dev) for _ in range(RING)]
         d_statuses = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(RING)]
         cs = caller.cuda_stream
@@ -372,9 +382,9 @@ def main():
         """--pipeline streams (round 2): `inflight` workspaces per part on `inflight` torch streams, driven from here"""
         wss = [[backend.Workspace(P.dp, P.B) for P in parts] for _ in range(inflight)]
         for row in wss:
-            for w_ in row:
+            for w_, P in zip(row, parts):
                 w_.hint_in_flight(args.hint or inflight)     # (from 4 up the library prefers launch shapes that issue fewer instructions)
-                apply_options(w_)
+                apply_options(w_, P)
         # (the same few torch streams in every measurement of this process: every stream that was ever created keeps a
         #  hardware queue busy in the runtime's round-robin, and later measurements would collide with the earlier ones')
         while len(stream_pool) < inflight:
@@ -480,6 +490,7 @@ def main():
                                                                                 all_batch_ok=None, var_lpt=var_lpt)
 
     gather_state = {"ok": None}
+    tuned_state = []
     if args.timed_only:
         args.no_cpu_baseline = args.no_rlc_secondary = True
         inflight_candidates = inflight_candidates[:1]
@@ -558,6 +569,7 @@ def main():
     if rank == 0:
         result = report(args, parts, per_part, per_part_alone, alone, elapsed, inflight, inflight_probe, label, B, B_total, world, ranks_seen, backend_seen,
                         timed_expected, ok_all, gather_state["ok"], reject_check, t_forge, PL)
+        result["config"]["tuned_launch_shapes"] = tuned_state or None    # h2v_workspace_tune per plan (0 = the launcher's rule was not beaten by 1.5 %)
         if rlc_secondary is not None:
             result["rlc_mode"] = rlc_secondary
         if not args.no_cpu_baseline and world == 1:

@@ -83,6 +83,15 @@ typedef struct {
  * h2v_plan_load: parse + validate the plan blob (plutus_halo2_verifier_gen_amd.plan.compile_plan(vk).to_bytes())
  * and upload it to `device`.  Immutable after load; may be shared by threads (each with its own workspace). */
 int h2v_plan_load(const uint8_t *plan, size_t len, int device, h2v_plan **out);
+/* (round 4) the same with load-time options (what the environment variable H2V_FIX_C used to select): opts = NULL or all-zero
+ * fields = h2v_plan_load.  fixed_base_window_bits: window width of the all-window tables of the VK bases that the split MSM's
+ * fixed-base launch reads - 0: the library's choice (12 bits: 22 additions per base and proof, 5 MB of tables per base; 8
+ * when 12 would take more than 2 GB), or 4 / 8 / 12.  Results never depend on it. */
+typedef struct {
+    uint32_t fixed_base_window_bits;
+    uint32_t reserved[7];   /* zero */
+} h2v_plan_opts;
+int h2v_plan_load_ex(const uint8_t *plan, size_t len, int device, const h2v_plan_opts *opts, h2v_plan **out);
 /* (round 3) The plan compiler behind the boundary: a verifying-key description - the JSON form frozen as docs/vk_schema.json
  * ("h2v-vk/1": what `extract_circuit` reads out of a midnight_proofs VerifyingKey + ParamsVerifierKZG,
  * /root/reference/src/plutus_gen/extraction/mod.rs:31-232, instantiation_data.rs:26-41; the serde exporter is in
@@ -139,7 +148,40 @@ int h2v_workspace_join(h2v_workspace *ws, void *stream);
 #define H2V_OPT_MSM_TERMS_PER_LANE 1u /* per-proof MSM: 1 .. 4 terms per lane on one accumulator (shared doublings) */
 #define H2V_OPT_PAIRING_ENGINE 2u     /* lanes per proof of the pairing kernel: 6 (ten proofs per wave), 12 (five), 16 (narrow: four), 32, 64 (wide), 1 (the one-lane cross-check kernel) */
 #define H2V_OPT_STREAMS 3u            /* -1 auto, 0: three library streams per call, 1: everything on the caller's stream, 2: + one side stream */
+/* (round 4) every remaining shape dimension, formerly H2V_* environment variables read once per process: */
+#define H2V_OPT_MSM_LANES_PER_TERM 4u /* ladder launches: 1 (both GLV halves on one lane), 2 (one lane per half), 8 (a quad of lanes per half) */
+#define H2V_OPT_MSM_BLOCK_SIZE 5u     /* threads per block of the MSM launches: 64 .. 512 in steps of 64 */
+#define H2V_OPT_MSM_FIXED_SPLIT 6u    /* VK-base terms through the all-window tables beside the ladders: 1 .. 4 bases per lane; -1: never split */
+#define H2V_OPT_COMBINER_SCHEDULE 7u  /* transcript + combiner kernel: 1 the plan's narrow bundle schedule, 2 the wide one */
+#define H2V_OPT_COMBINER_PROOFS_PER_BLOCK 8u /* proofs per one-wave block of that kernel (a power of two <= what fits LDS) */
+#define H2V_OPT_DECOMPRESS_FORM 9u    /* 0: one launch that takes 64-point units from a queue; 1: square roots and subgroup tests as two launches; 2: one launch of paired 128-thread blocks */
+#define H2V_OPT_PIPES 10u             /* an ordinary workspace cuts a call into 2 .. 4 sub-pipelines on streams of their own (0 / 1: one) */
+#define H2V_OPT_RLC_GROUP_STAGE 11u   /* RLC fall-back: -1 skips the group checks (straight to the per-proof kernels) */
+#define H2V_OPT_RLC_WINDOW_BITS 12u   /* bucket MSM: window width */
+#define H2V_OPT_RLC_CHAIN 13u         /* bucket MSM: most entries one lane sums */
+#define H2V_OPT_COUNT 14u
 int h2v_workspace_set_option(h2v_workspace *ws, uint32_t option, int32_t value);
+int h2v_workspace_get_option(const h2v_workspace *ws, uint32_t option, int32_t *value);
+/* (round 4) MEASURED launch shapes.  The launcher's own rules are thresholds calibrated on five circuit shapes; a circuit or a
+ * batch size in between gets the nearest rule, unmeasured.  h2v_workspace_tune runs `batch` (device-resident, as for
+ * h2v_verify_batch_device; its verdicts are discarded) repeatedly in the way the workspace is used - a laned workspace with as
+ * many calls in flight as it has lanes for that size, an ordinary one call by call -, times the launcher's choice and its
+ * neighbours (pairing engine, then MSM terms per lane: <= 7 configurations, about 40 calls in all), and leaves the fastest on
+ * the workspace as H2V_OPT_PAIRING_ENGINE / H2V_OPT_MSM_TERMS_PER_LANE (0 = the launcher's rule stays: a candidate must be
+ * 1.5 % faster to replace it).  Call it once per (plan, batch size, workspace) at start-up, on `stream` (not NULL for a laned
+ * workspace); it returns when the measurements are done.  flags: 0.  Results of later calls do not depend on it. */
+typedef struct {
+    uint32_t n_measured;          /* configurations timed */
+    uint32_t calls_in_flight;     /* how the batch was run: calls kept in flight */
+    float default_ms, best_ms;    /* ms per call: the launcher's own choice / the configuration now set */
+    int32_t pairing_engine;       /* H2V_OPT_PAIRING_ENGINE now set (0: the launcher's rule) */
+    int32_t msm_terms_per_lane;   /* H2V_OPT_MSM_TERMS_PER_LANE now set (0: the launcher's rule) */
+    uint32_t reserved[4];
+} h2v_tune_report;
+int h2v_workspace_tune(const h2v_plan *plan, const h2v_batch *batch, h2v_workspace *ws, void *stream, uint32_t flags,
+                       h2v_tune_report *report /* or NULL */);
+/* the same options for the h2v_probe_* calls of the calling thread (they have no workspace) */
+int h2v_probe_set_option(uint32_t option, int32_t value);
 /* lanes and chunk size of a workspace (1 lane = not laned) */
 int h2v_workspace_lanes(const h2v_workspace *ws, uint32_t *n_lanes, uint32_t *chunk);
 /* how many calls of n proofs each (rlc != 0: RLC mode) the workspace keeps in flight before a call has to wait for a lane:

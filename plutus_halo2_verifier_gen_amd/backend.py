@@ -43,6 +43,20 @@ class RlcTimings(C.Structure):
                 ("window_bits", C.c_uint32), ("windows", C.c_uint32), ("max_chain", C.c_uint32)]
 
 
+class PlanOpts(C.Structure):
+    _fields_ = [("fixed_base_window_bits", C.c_uint32), ("reserved", C.c_uint32 * 7)]
+
+
+class TuneReport(C.Structure):
+    _fields_ = [("n_measured", C.c_uint32), ("calls_in_flight", C.c_uint32), ("default_ms", C.c_float), ("best_ms", C.c_float),
+                ("pairing_engine", C.c_int32), ("msm_terms_per_lane", C.c_int32), ("reserved", C.c_uint32 * 4)]
+
+
+# h2v_workspace_set_option / h2v_probe_set_option ids (include/h2v.h)
+OPT_MSM_TERMS_PER_LANE, OPT_PAIRING_ENGINE, OPT_STREAMS, OPT_MSM_LANES_PER_TERM, OPT_MSM_BLOCK_SIZE, OPT_MSM_FIXED_SPLIT = 1, 2, 3, 4, 5, 6
+OPT_COMBINER_SCHEDULE, OPT_COMBINER_PROOFS_PER_BLOCK, OPT_DECOMPRESS_FORM, OPT_PIPES, OPT_RLC_GROUP_STAGE, OPT_RLC_WINDOW_BITS, OPT_RLC_CHAIN = 7, 8, 9, 10, 11, 12, 13
+OPT_COUNT = 14
+
 RLC_SEED_GIVEN = 1
 RLC_ONE_STREAM = 2
 SUBMIT_RLC = 1
@@ -61,9 +75,9 @@ def _rlc_opts(seed, one_stream: bool = False):
 
 
 EXPORTS = [
-    "h2v_plan_load", "h2v_plan_free", "h2v_plan_info", "h2v_plan_compile", "h2v_blob_free", "h2v_workspace_create", "h2v_workspace_free",
+    "h2v_plan_load", "h2v_plan_load_ex", "h2v_plan_free", "h2v_plan_info", "h2v_plan_compile", "h2v_blob_free", "h2v_workspace_create", "h2v_workspace_free",
     "h2v_workspace_timings", "h2v_workspace_hint_in_flight", "h2v_workspace_create_lanes", "h2v_workspace_defer_joins",
-    "h2v_workspace_join", "h2v_workspace_lanes", "h2v_workspace_depth", "h2v_workspace_set_option",
+    "h2v_workspace_join", "h2v_workspace_lanes", "h2v_workspace_depth", "h2v_workspace_set_option", "h2v_workspace_get_option", "h2v_workspace_tune", "h2v_probe_set_option",
     "h2v_verify_batch", "h2v_verify_batch_submit", "h2v_verify_batch_wait", "h2v_verify_batch_device", "h2v_verify_batch_rlc", "h2v_verify_batch_rlc_device",
     "h2v_workspace_rlc_result", "h2v_probe_g1_msm_pippenger", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
     "h2v_probe_blake2b", "h2v_probe_g1_decompress", "h2v_probe_g1_msm", "h2v_probe_g1_msm_fixed", "h2v_probe_quad_madd", "h2v_probe_pairing", "h2v_probe_pairing_ex",
@@ -93,6 +107,7 @@ def lib():
         L.h2v_last_error.restype = C.c_char_p
         L.h2v_build_id.restype = C.c_char_p
         L.h2v_plan_load.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+        L.h2v_plan_load_ex.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(PlanOpts), C.POINTER(C.c_void_p)]
         L.h2v_plan_free.argtypes = [C.c_void_p]
         L.h2v_plan_compile.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.h2v_blob_free.argtypes = [C.c_void_p]
@@ -105,6 +120,9 @@ def lib():
         L.h2v_workspace_lanes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.h2v_workspace_depth.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint32)]
         L.h2v_workspace_set_option.argtypes = [C.c_void_p, C.c_uint32, C.c_int32]
+        L.h2v_workspace_get_option.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]
+        L.h2v_probe_set_option.argtypes = [C.c_uint32, C.c_int32]
+        L.h2v_workspace_tune.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(TuneReport)]
         L.h2v_workspace_timings.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Timings)]
         L.h2v_verify_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
         L.h2v_verify_batch_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -142,6 +160,11 @@ def check(rc: int):
         raise H2VError("h2v error %d: %s" % (rc, (lib().h2v_last_error() or b"").decode()))
 
 
+def probe_set_option(option: int, value: int) -> None:
+    """h2v_probe_set_option: the launch-shape option the h2v_probe_* calls of this thread run with (0 = the launcher's choice)"""
+    check(lib().h2v_probe_set_option(option, value))
+
+
 def plan_compile(vk_json: str) -> bytes:
     """h2v_plan_compile: the C++ plan compiler behind the C-ABI (host-only; byte-identical with plan.compile_plan)."""
     raw = vk_json.encode()
@@ -165,10 +188,15 @@ def shutdown(device: int = -1) -> None:
 class DevicePlan:
     """A plan uploaded to one GPU (h2v_plan*)."""
 
-    def __init__(self, plan_bytes: bytes, device: int = 0):
+    def __init__(self, plan_bytes: bytes, device: int = 0, fixed_base_window_bits: int = 0):
+        """fixed_base_window_bits (h2v_plan_load_ex): 0 = the library's choice, or 4 / 8 / 12"""
         self._h = C.c_void_p()
         self.device = device
-        check(lib().h2v_plan_load(plan_bytes, len(plan_bytes), device, C.byref(self._h)))
+        if fixed_base_window_bits:
+            opts = PlanOpts(fixed_base_window_bits, (C.c_uint32 * 7)())
+            check(lib().h2v_plan_load_ex(plan_bytes, len(plan_bytes), device, C.byref(opts), C.byref(self._h)))
+        else:
+            check(lib().h2v_plan_load(plan_bytes, len(plan_bytes), device, C.byref(self._h)))
         v = [C.c_uint32() for _ in range(4)]
         check(lib().h2v_plan_info(self._h, *[C.byref(x) for x in v]))
         self.proof_len, self.n_pi, self.n_ci, self.n_terms = [x.value for x in v]
@@ -309,6 +337,18 @@ class Workspace:
     def set_option(self, option: int, value: int) -> None:
         """h2v_workspace_set_option: a launch shape instead of the launcher's choice (0 = back to its choice)"""
         check(lib().h2v_workspace_set_option(self._h, option, value))
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int32()
+        check(lib().h2v_workspace_get_option(self._h, option, C.byref(v)))
+        return v.value
+
+    def tune(self, plan: "DevicePlan", n, d_proofs, d_off, d_inst, d_ci, stream) -> "TuneReport":
+        """h2v_workspace_tune: measure the candidate launch shapes on this device-resident batch, keep the fastest"""
+        b = Batch(n, d_proofs, d_off, d_inst, d_ci)
+        rep = TuneReport()
+        check(lib().h2v_workspace_tune(plan.handle, C.byref(b), self._h, stream, 0, C.byref(rep)))
+        return rep
 
     def defer_joins(self, on: bool = True) -> None:
         """h2v_workspace_defer_joins: device-resident calls return without making the caller's stream wait, so that

@@ -150,7 +150,7 @@ struct h2v_workspace {
     uint8_t ring_pipes[RING] = {}, ring_split[RING] = {}, ring_lpt[RING] = {}, ring_pair[RING] = {}, ring_var[RING] = {};
     uint64_t calls = 0;
     struct RlcWs *rlc = nullptr;   // buffers of the RLC batch mode, created by its first call
-    int opt_msm_tpl = 0, opt_pairing = 0;   // h2v_workspace_set_option: 0 = the launcher's choice
+    int32_t opt[H2V_OPT_COUNT] = {};   // h2v_workspace_set_option / h2v_workspace_tune: 0 = the launcher's choice
     int one_stream_mode = -1;      // lanes: 1 = the whole pipeline on the stream it is given (-1: decided from the hint)
     // ---- lanes (h2v_workspace_create_lanes): a laned workspace owns no kernel buffers of its own, only n_lanes ordinary
     // workspaces of `chunk` proofs and one library-owned stream per lane.  A verify call is cut into chunks that go round
@@ -193,8 +193,11 @@ struct h2v_workspace {
 #define H2V_VM_LDS_BYTES ((size_t)160 * 1024 - 8192 - 1024)
 static uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 // ---------------------------------------------------------------------------------------------- plan
-extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_plan **out) {
+extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_plan **out) { return h2v_plan_load_ex(blob, len, device, nullptr, out); }
+extern "C" int h2v_plan_load_ex(const uint8_t *blob, size_t len, int device, const h2v_plan_opts *opts, h2v_plan **out) {
     if (!blob || !out) return fail(H2V_E_ARG, "null argument");
+    const uint32_t opt_fix_c = opts ? opts->fixed_base_window_bits : 0u;
+    if (opt_fix_c != 0 && opt_fix_c != 4 && opt_fix_c != 8 && opt_fix_c != 12) return fail(H2V_E_ARG, "fixed_base_window_bits: 0 (auto), 4, 8 or 12");
     *out = nullptr;
     const size_t hdr = 8 + 4 * H2V_PLAN_HDR_WORDS;
     if (len < hdr || memcmp(blob, H2V_PLAN_MAGIC, 8) != 0) return fail(H2V_E_PLAN, "bad magic / truncated header");
@@ -400,10 +403,9 @@ extern "C" int h2v_plan_load(const uint8_t *blob, size_t len, int device, h2v_pl
         for (uint32_t k = nv; k < n_terms; k++) tail_ok = tail_ok && rd32(patched.data() + w[H2V_HW_OFF_TERMS] + 8 * k) == H2V_TERM_VK_BASE;
         if (tail_ok) {
             // window width of the tables: 12 bits (22 additions per VK term in every proof, 5 MB per base) unless that would
-            // take more than 2 GB; H2V_FIX_C = 4 / 8 / 12 forces it (tests run all three)
-            static const int env_c = []() { const char *e = getenv("H2V_FIX_C"); return e ? atoi(e) : 0; }();
+            // take more than 2 GB; h2v_plan_opts.fixed_base_window_bits = 4 / 8 / 12 forces it (tests run all three)
             uint32_t fc = (size_t)n_bases * 22 * 2048 * 112 <= ((size_t)2 << 30) ? 12u : 8u;
-            if (env_c == 4 || env_c == 8 || env_c == 12) fc = (uint32_t)env_c;
+            if (opt_fix_c) fc = opt_fix_c;
             const uint32_t fW = fc == 4 ? 65u : fc == 8 ? 33u : 22u, fE = 1u << (fc - 1);
             const size_t fix_bytes = (size_t)n_bases * fW * fE * 28 * 4;
             void *wbase = nullptr;
@@ -585,7 +587,7 @@ static int ensure_lane(h2v_workspace *w, uint32_t l) {
     if (rc) return rc;
     lw->one_stream_mode = 2;            // (set per call: laned_depth)
     lw->in_flight_hint = w->in_flight_hint > w->n_lanes ? w->in_flight_hint : w->n_lanes;
-    lw->opt_msm_tpl = w->opt_msm_tpl; lw->opt_pairing = w->opt_pairing;
+    memcpy(lw->opt, w->opt, sizeof lw->opt);
     w->lane[l] = lw;
     return H2V_OK;
 }
@@ -625,20 +627,44 @@ extern "C" int h2v_workspace_create(const h2v_plan *p, uint64_t max_batch, h2v_w
     if (rc == H2V_OK) reg_add(g_ws_live, *out);
     return rc;
 }
+static int option_check(uint32_t option, int32_t value) {
+    auto bad = [](const char *m) { return fail(H2V_E_ARG, m); };
+    switch (option) {
+    case H2V_OPT_MSM_TERMS_PER_LANE: if (value < 0 || value > 4) return bad("terms per lane: 0 (auto) .. 4"); break;
+    case H2V_OPT_PAIRING_ENGINE:
+        if (value != 0 && value != 1 && value != 6 && value != 12 && value != 16 && value != 32 && value != 64)
+            return bad("pairing engine: 0 (auto), 6, 12, 16, 32, 64 lanes per proof, or 1 (the one-lane cross-check kernel)");
+        break;
+    case H2V_OPT_STREAMS: if (value < -1 || value > 2) return bad("streams: -1 (auto), 0 (three), 1 (the caller's), 2 (the caller's + one for the decompression)"); break;
+    case H2V_OPT_MSM_LANES_PER_TERM: if (value != 0 && value != 1 && value != 2 && value != 8) return bad("MSM lanes per term: 0 (auto), 1, 2, 8"); break;
+    case H2V_OPT_MSM_BLOCK_SIZE: if (value < 0 || value > 512 || value % 64) return bad("MSM block size: 0 (auto), 64 .. 512 in steps of 64"); break;
+    case H2V_OPT_MSM_FIXED_SPLIT: if (value < -1 || value > 4) return bad("fixed-base split: 0 (auto), 1 .. 4 bases per lane, -1 (never)"); break;
+    case H2V_OPT_COMBINER_SCHEDULE: if (value < 0 || value > 2) return bad("combiner schedule: 0 (auto), 1 (narrow), 2 (wide)"); break;
+    case H2V_OPT_COMBINER_PROOFS_PER_BLOCK: if (value < 0 || value > 64 || (value & (value - 1))) return bad("combiner proofs per block: 0 (auto) or a power of two <= 64"); break;
+    case H2V_OPT_DECOMPRESS_FORM: if (value < 0 || value > 2) return bad("decompression: 0 (auto: one queue launch), 1 (two launches), 2 (one launch of paired blocks)"); break;
+    case H2V_OPT_PIPES: if (value < 0 || value > h2v_workspace::MAXP) return bad("pipes: 0 / 1 (one pipeline) .. 4"); break;
+    case H2V_OPT_RLC_GROUP_STAGE: if (value < -1 || value > 0) return bad("RLC group stage: 0 (auto), -1 (off)"); break;
+    case H2V_OPT_RLC_WINDOW_BITS: if (value != 0 && (value < 3 || value > (int32_t)PIP_MAX_C)) return bad("RLC window bits: 0 (auto), 3 .. the bucket MSM's maximum"); break;
+    case H2V_OPT_RLC_CHAIN: if (value != 0 && (value < 2 || value > 1024)) return bad("RLC entries per lane: 0 (auto), 2 .. 1024"); break;
+    default: return bad("unknown option");
+    }
+    return H2V_OK;
+}
 extern "C" int h2v_workspace_set_option(h2v_workspace *ws, uint32_t option, int32_t value) {
     if (!ws) return fail(H2V_E_ARG, "null argument");
     ALIVE(ws);
+    if (int rc = option_check(option, value)) return rc;
     auto apply = [&](h2v_workspace *w) {
-        if (option == H2V_OPT_MSM_TERMS_PER_LANE) w->opt_msm_tpl = value;
-        else if (option == H2V_OPT_PAIRING_ENGINE) w->opt_pairing = value;
-        else if (option == H2V_OPT_STREAMS) w->one_stream_mode = value;
+        if (option == H2V_OPT_STREAMS) w->one_stream_mode = value;
+        else w->opt[option] = value;
     };
-    if (option == H2V_OPT_MSM_TERMS_PER_LANE) { if (value < 0 || value > 4) return fail(H2V_E_ARG, "terms per lane: 0 (auto) .. 4"); }
-    else if (option == H2V_OPT_PAIRING_ENGINE) { if (value != 0 && value != 1 && value != 6 && value != 12 && value != 16 && value != 32 && value != 64) return fail(H2V_E_ARG, "pairing engine: 0 (auto), 6, 12, 16, 32, 64 lanes per proof, or 1 (the one-lane cross-check kernel)"); }
-    else if (option == H2V_OPT_STREAMS) { if (value < -1 || value > 2) return fail(H2V_E_ARG, "streams: -1 (auto), 0 (three), 1 (the caller's), 2 (the caller's + one for the decompression)"); }
-    else return fail(H2V_E_ARG, "unknown option");
     apply(ws);
     for (uint32_t l = 0; l < (uint32_t)h2v_workspace::MAXL; l++) if (ws->lane[l] && option != H2V_OPT_STREAMS) apply(ws->lane[l]);
+    return H2V_OK;
+}
+extern "C" int h2v_workspace_get_option(const h2v_workspace *ws, uint32_t option, int32_t *value) {
+    if (!ws || !value || option == 0 || option >= H2V_OPT_COUNT) return fail(H2V_E_ARG, "bad argument");
+    *value = option == H2V_OPT_STREAMS ? ws->one_stream_mode : ws->opt[option];
     return H2V_OK;
 }
 extern "C" int h2v_workspace_lanes(const h2v_workspace *ws, uint32_t *n_lanes, uint32_t *chunk) {
@@ -814,8 +840,17 @@ static int ws_streams(h2v_workspace *w, int k, bool need_main, bool need_side, b
 
 // launch-shape options of the workspace a call runs on (h2v_workspace_set_option): the launchers below run on the calling
 // host thread, inside run_pipeline / run_rlc, which set this for their duration
-struct LaunchOptions { int msm_tpl = 0, pairing = 0; uint32_t in_flight = 1; };
+struct LaunchOptions { int32_t v[H2V_OPT_COUNT] = {}; uint32_t in_flight = 1; };
 static thread_local LaunchOptions g_opts;
+static thread_local LaunchOptions g_probe_opts;     // h2v_probe_set_option: the shape options the probes of this thread launch with
+static void opts_from(const h2v_workspace *w) { memcpy(g_opts.v, w->opt, sizeof g_opts.v); g_opts.in_flight = w->in_flight_hint; }
+struct ProbeOpts { ProbeOpts() { g_opts = g_probe_opts; } ~ProbeOpts() { g_opts = LaunchOptions(); } };
+extern "C" int h2v_probe_set_option(uint32_t option, int32_t value) {
+    if (option == H2V_OPT_STREAMS) return fail(H2V_E_ARG, "the probes run on the NULL stream");
+    if (int rc = option_check(option, value)) return rc;
+    g_probe_opts.v[option] = value;
+    return H2V_OK;
+}
 // Transcript + combiner launch.  A block is one wave; its 64 lanes are P proofs x L lanes per proof (the plan's
 // bundles have L records), the Fr register file of the P proofs lives in LDS (160 KB per CU).  A single-lane plan whose
 // register file does not fit 64 proofs runs P = 32 / 16 / 8 proofs per block with the other lanes idle, or - below 8 -
@@ -830,8 +865,8 @@ static int launch_vm(const H2vDevPlan &d0, uint32_t n, uint32_t stride, const ui
                      const uint8_t *ci, uint32_t *regs, uint32_t *scalars, uint32_t *status, uint32_t *trace, hipStream_t st) {
     // The wide schedule (more lanes per proof: shorter chain, more waves) when the launch would leave most of the chip
     // idle anyway - at most a quarter of the SIMDs get a wave - and nobody asked for the trace (its register numbers are
-    // the narrow schedule's).  H2V_VM_WIDE = 0 / 1 forces the choice.
-    static const int env_wide = []() { const char *e = getenv("H2V_VM_WIDE"); return e ? atoi(e) : -1; }();
+    // the narrow schedule's).  H2V_OPT_COMBINER_SCHEDULE forces the choice.
+    const int env_wide = g_opts.v[H2V_OPT_COMBINER_SCHEDULE] - 1;   // -1 auto, 0 narrow, 1 wide
     H2vDevPlan d = d0;
     const bool wide_ok = d.wide_lanes && !trace;
     // (eight or more batches in flight: the chip is full anyway and the wide schedule's extra instructions count - only launches
@@ -847,8 +882,8 @@ static int launch_vm(const H2vDevPlan &d0, uint32_t n, uint32_t stride, const ui
     }
     // Fewer proofs per block than the wave could serve (the spare lanes shadow): the register file of P proofs is what
     // decides how many blocks a CU holds (simple_mul, P = 32: 79 + 8 KB = ONE block per CU = one wave on one of its four
-    // SIMDs), and a wave's chain is as long with 16 proofs as with 32.  H2V_VM_P forces P (power of two).
-    static const int env_p = []() { const char *e = getenv("H2V_VM_P"); return e ? atoi(e) : 0; }();
+    // SIMDs), and a wave's chain is as long with 16 proofs as with 32.  H2V_OPT_COMBINER_PROOFS_PER_BLOCK forces P.
+    const int env_p = g_opts.v[H2V_OPT_COMBINER_PROOFS_PER_BLOCK];
     if (env_p >= 1 && (env_p & (env_p - 1)) == 0 && (uint32_t)env_p <= P) P = (uint32_t)env_p;
     const size_t lds = (size_t)d.n_regs * 32 * P;
     HIPCHK(hipFuncSetAttribute((const void *)k_transcript_combiner_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -891,15 +926,15 @@ static void msm_try_shape(MsmShape &best, uint32_t lpt, uint32_t lpp, double cha
     }
 }
 static MsmShape msm_ladder_shape(uint32_t n_terms, uint32_t n, double other_waves, bool quad_ok = false) {
-    static const int env_lpt = []() { const char *e = getenv("H2V_MSM_LPT"); return e ? atoi(e) : 0; }();
-    static const uint32_t env_bs = []() { const char *e = getenv("H2V_MSM_BS"); return e ? (uint32_t)atoi(e) : 0u; }();
+    const int env_lpt = g_opts.v[H2V_OPT_MSM_LANES_PER_TERM];
+    const uint32_t env_bs = (uint32_t)g_opts.v[H2V_OPT_MSM_BLOCK_SIZE];
     MsmShape best = {2, 512, 1e300, 0};
     for (uint32_t cl = 2; cl >= 1; cl--) {
         if (env_lpt && (uint32_t)env_lpt != cl) continue;
         msm_try_shape(best, cl, cl * n_terms, cl == 2 ? 1250.0 : 1600.0, n, other_waves, env_bs);
     }
     // a quad per GLV half (h2v_kernels.hip: msm_body, LPT = 8)
-    // Only on request (H2V_MSM_LPT=8): alone it shortens a T = 16 launch of 64-512 proofs from 1.35 to 1.17-1.27 ms, but it issues
+    // Only on request (H2V_OPT_MSM_LANES_PER_TERM = 8): alone it shortens a T = 16 launch of 64-512 proofs from 1.35 to 1.17-1.27 ms, but it issues
     // four times the instructions, and with four steps in flight - how small batches are run for throughput - the step got
     // slower at 64 and 512 proofs (1.30 -> 1.40, 1.66 -> 1.90 ms) and faster only at 256 (1.57 -> 1.47).
     if (quad_ok && 8 * n_terms <= 512 && env_lpt == 8) {
@@ -927,9 +962,9 @@ static uint32_t launch_msm_ladders(const H2vDevPlan &d, const H2vMsmArgs &ma, ui
     else hipLaunchKernelGGL(k_g1_msm, dim3(blocks), dim3(sh.bs), (size_t)sh.bs * 172, st, d, ma, n, per_block, scalars, pts, tabws);
     return sh.lpt;
 }
-// H2V_MSM_TPL = 2 .. 4: k_g1_msm_multi (several terms per lane share the doublings: less work, fewer and longer waves;
-// for callers that keep several batches in flight - bench.py sets it then).  Single-group launches with prebuilt tables only.
-// Without the variable the caller's hint decides (h2v_workspace_hint_in_flight): a caller that keeps >= 4 batches in flight is
+// H2V_OPT_MSM_TERMS_PER_LANE = 2 .. 4: k_g1_msm_multi (several terms per lane share the doublings: less work, fewer and longer waves;
+// for callers that keep several batches in flight).  Single-group launches with prebuilt tables only.
+// Without the option the caller's hint decides (h2v_workspace_hint_in_flight): a caller that keeps >= 4 batches in flight is
 // bound by the instructions issued, not by chain length, and two terms per lane issue 26 % fewer multiply-adds per proof
 // (measured, simple_mul x 4096: 5 in flight 5.12 -> 4.66 ms per step; with 3 in flight 5.04 -> 5.01).
 // Terms per lane of the ladder kernel for callers that keep the chip full: more terms per lane share more doublings and make
@@ -938,9 +973,7 @@ static uint32_t launch_msm_ladders(const H2vDevPlan &d, const H2vMsmArgs &ma, ui
 // lookup_table x 2048 (25 terms: 416 / 288 / 224) 3.42 / 3.36 / -; x 4096 6.82 / 6.71 / 6.59; atms x 2048 (20 terms: 320 / 224 /
 // 160) 3.55 / 3.72 / 4.05; sha256 shape in chunks of 1024 (25 terms: 208 / 144) 2.26 / 2.35.
 static int msm_terms_per_lane(uint32_t in_flight_hint, uint32_t n = 0, uint32_t n_terms = 0) {
-    static const int v = []() { const char *e = getenv("H2V_MSM_TPL"); const int t = e ? atoi(e) : 0; return t >= 1 && t <= 4 ? t : 0; }();
-    if (g_opts.msm_tpl >= 1 && g_opts.msm_tpl <= 4) return g_opts.msm_tpl;
-    if (v) return v;
+    if (g_opts.v[H2V_OPT_MSM_TERMS_PER_LANE] >= 1) return g_opts.v[H2V_OPT_MSM_TERMS_PER_LANE];
     if (in_flight_hint < 4) return 1;
     for (int t = 4; t > 2; t--)
         if ((double)n * ((n_terms + t - 1) / t) / 64.0 >= msm_n_simd() / 4.0) return t;
@@ -955,7 +988,7 @@ static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint
     // (eight or more batches in flight: from an eighth - sha256 / secp256k1 shape x 256, sixteen shares in flight: 1.05 / 1.08 ->
     //  0.89 / 0.91 ms per share with two terms per lane; x 128 and x 64 stay with the shortest chain: 0.66 -> 0.74, 0.54 -> 0.64)
     const bool fills = (double)n * ma.n_terms / 64.0 >= msm_n_simd() / (in_flight_hint >= 8 ? 8.0 : 4.0);
-    const bool tpl_forced = getenv("H2V_MSM_TPL") != nullptr || g_opts.msm_tpl > 0;
+    const bool tpl_forced = g_opts.v[H2V_OPT_MSM_TERMS_PER_LANE] > 0;
     if (tpl > 1 && (fills || tpl_forced) && ma.pt_tab && !ma.skip && ma.grp_end[0] == ma.n_terms && ma.n_terms >= (uint32_t)tpl && ma.n_terms <= 256u * tpl) {
         // lanes per proof as for `tpl` whole terms per lane, then the proof's 2 T GLV halves dealt out evenly over them: ten terms
         // on four lanes are 5 + 5 + 5 + 5 halves, not 6 + 6 + 6 + 2 (a forced tpl keeps its 2 tpl halves per lane)
@@ -974,11 +1007,12 @@ static uint32_t launch_msm_range(const H2vDevPlan &d, const H2vMsmArgs &ma, uint
 // T = 34 with 9 VK bases 3.42 -> 2.68 ms; but where the single launch already has every SIMD to itself the split is
 // slower (simple_mul x 4096: 1.87 -> 2.50 ms, sha256 shape x 1024: 1.99 -> 2.56 ms) - waves of two concurrent launches
 // pair up on SIMDs even when there would be room for all of them alone.  So the rule is: split (one base per lane) only
-// when the single launch cannot have one wave per SIMD and most terms are VK bases.  H2V_MSM_FIX = k forces a split with k bases per lane, 0 forbids it.
+// when the single launch cannot have one wave per SIMD and most terms are VK bases.  H2V_OPT_MSM_FIXED_SPLIT = k forces a split with k bases per lane, -1 forbids it.
 struct MsmSplit { bool on; MsmShape var, fix; uint32_t k; };
 static MsmSplit msm_split_shape(const H2vDevPlan &d, uint32_t n, const MsmShape &single, uint32_t in_flight_hint = 1) {
-    static const int env_fix = []() { const char *e = getenv("H2V_MSM_FIX"); return e ? atoi(e) : -1; }();
-    static const uint32_t env_bs = []() { const char *e = getenv("H2V_MSM_BS"); return e ? (uint32_t)atoi(e) : 0u; }();
+    const int opt_fix = g_opts.v[H2V_OPT_MSM_FIXED_SPLIT];                  // 0 auto, 1 .. 4 bases per lane, -1 never
+    const int env_fix = opt_fix == 0 ? -1 : opt_fix < 0 ? 0 : opt_fix;       // (-1 auto, 0 never, k forced: the form the rule below is written in)
+    const uint32_t env_bs = (uint32_t)g_opts.v[H2V_OPT_MSM_BLOCK_SIZE];
     MsmSplit out = {false, {}, {}, 0};
     if (!d.fix_tab || !d.n_fix || !d.n_var || d.ivc || env_fix == 0) return out;
     // (and only when the VK bases are the majority of the terms: with 9 of 34 the MSM gained 0.8 ms and the pairing kernel
@@ -1025,28 +1059,25 @@ static void launch_ivc_fold(const H2vDevPlan &d, uint32_t n, const uint32_t *pts
     launch_msm_range(d, fold, n, b.fold_scal, b.fold_pts, tabws, st);
 }
 // Pairing kernel selection: the cooperative 16-lanes-per-proof kernel is the product path; the one-lane-per-proof
-// kernel stays as a cross-check (H2V_PAIRING=legacy, or impl = 0 in the probe).
+// kernel stays as a cross-check (H2V_OPT_PAIRING_ENGINE = 1, or impl = 0 in the probe).
 static uint32_t launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
                                 const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st, const uint32_t *skip = nullptr,
                                 bool prefer_narrow = false, double wide_up_to = -1.0, bool prefer_six = false, bool prefer_twelve = false) {
     if (wide_up_to < 0) wide_up_to = msm_n_simd();
     // The WIDE engine (one proof per wave, four lanes per coefficient: 3 / 2 / 1 terms per lane and call instead of 6 / 4 / 2)
     // when even one wave per proof leaves SIMDs free: n <= #SIMDs.  Above that the two-proofs-per-wave kernel does less
-    // total work.  H2V_PAIRING_WIDE = 0 / 1 forces the choice; the conditional (RLC fall-back) launch is never wide.
-    static const int env_wide = []() { const char *e = getenv("H2V_PAIRING_WIDE"); return e ? atoi(e) : -1; }();
-    static const int env_narrow = []() { const char *e = getenv("H2V_PAIRING_NARROW"); return e ? atoi(e) : -1; }();
-    static const int env_six = []() { const char *e = getenv("H2V_PAIRING_SIX"); return e ? atoi(e) : -1; }();
-    // impl 2 / 3 / 5 (probe): the narrow / the wide / the six-lane kernel whatever n
-    static const int env_twelve = []() { const char *e = getenv("H2V_PAIRING_TWELVE"); return e ? atoi(e) : -1; }();
-    if (impl == 1 && g_opts.pairing) impl = g_opts.pairing == 1 ? 0 : g_opts.pairing == 16 ? 2 : g_opts.pairing == 64 ? 3 : g_opts.pairing == 6 ? 5 : g_opts.pairing == 12 ? 6 : 4;   // 4: the two-proofs-per-wave engine
-    if (impl == 5 || (impl == 1 && !skip && (env_six > 0 || (env_six < 0 && prefer_six)))) {
+    // total work.  H2V_OPT_PAIRING_ENGINE forces an engine; the conditional (RLC fall-back) launch is never wide.
+    // impl 2 / 3 / 5 / 6 (probe): the narrow / the wide / the six-lane / the twelve-lane kernel whatever n
+    const int forced = g_opts.v[H2V_OPT_PAIRING_ENGINE];
+    if (impl == 1 && forced) impl = forced == 1 ? 0 : forced == 16 ? 2 : forced == 64 ? 3 : forced == 6 ? 5 : forced == 12 ? 6 : 4;   // 4: the two-proofs-per-wave engine
+    if (impl == 5 || (impl == 1 && !skip && prefer_six)) {
         hipLaunchKernelGGL(k_pairing_six, dim3((n + SIX_GROUPS - 1) / SIX_GROUPS), dim3(64), SIX_LDS_BYTES, st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
         return 6u;
     }
-    const bool wide = !skip && impl != 2 && impl != 4 && impl != 6 && (impl == 3 || (env_wide >= 0 ? env_wide != 0 : (double)n <= wide_up_to));
-    const bool narrow = !skip && !wide && impl != 4 && (impl == 2 || env_narrow > 0 || (env_narrow < 0 && prefer_narrow));
-    // the narrow engine packed five proofs to a wave (impl 6, option 12, H2V_PAIRING_TWELVE = 0 / 1): wherever the narrow one would run
-    if (impl == 6 || (narrow && impl != 2 && env_twelve != 0 && (env_twelve > 0 || prefer_twelve))) {
+    const bool wide = !skip && impl != 2 && impl != 4 && impl != 6 && (impl == 3 || (double)n <= wide_up_to);
+    const bool narrow = !skip && !wide && impl != 4 && (impl == 2 || prefer_narrow);
+    // the narrow engine packed five proofs to a wave (impl 6, option 12): wherever the narrow one would run
+    if (impl == 6 || (narrow && impl != 2 && prefer_twelve)) {
         hipLaunchKernelGGL(k_pairing_coop_twelve, dim3((n + COOP_GROUPS_TWELVE - 1) / COOP_GROUPS_TWELVE), dim3(64), COOP_LDS_BYTES(COOP_GROUPS_TWELVE), st, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg);
         return 12u;
     }
@@ -1062,10 +1093,10 @@ static uint32_t launch_pairing_impl(int impl, const H2vDevPlan &d, uint32_t n, c
 //   n = 3072: 2.99 / 3.71, 2.63 / 3.46     n = 4096: 3.00 / 4.81, 2.66 / 4.50     n = 8192: 5.65 / 9.59, 6.59 / 8.91
 // (a narrow block needs 22.5 KB of LDS: seven per CU, so its second wave per SIMD does not fit everywhere).  Rule: a caller
 // that keeps the chip full (hint >= 4) takes it from 2 * #SIMDs proofs up; one step at a time takes it exactly where the
-// normal kernel needs a second wave per SIMD and the narrow one does not.  H2V_PAIRING_NARROW = 0 / 1 forces the choice.
+// normal kernel needs a second wave per SIMD and the narrow one does not.  H2V_OPT_PAIRING_ENGINE forces the choice.
 static uint32_t launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *pts, const uint8_t *valid, const uint8_t *valid_sub, const uint32_t *er,
                            const uint32_t *el_jac, uint32_t *status, uint8_t *accept, uint32_t *dbg, hipStream_t st, uint32_t in_flight_hint = 1) {
-    static const int impl = []() { const char *e = getenv("H2V_PAIRING"); return (e && strcmp(e, "legacy") == 0) ? 0 : 1; }();
+    const int impl = 1;
     const double S = msm_n_simd();
     // Eight or more batches in flight (the library's lanes): the chip is full whatever one launch brings, so the engine with the
     // fewest instructions that still has waves to spread wins much earlier - wide (2 x the normal engine's instructions) only up
@@ -1083,7 +1114,7 @@ static uint32_t launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *
     // The SIX-lane engine (ten proofs per wave, h2v_pairing_six.hpp: a quarter fewer instructions per pairing than the narrow
     // one, a chain almost twice as long) wherever a caller that keeps the chip full would take the narrow one
     // from 4 * #SIMDs proofs up (410 waves; with eight or more batches in flight from 3 * #SIMDs: simple_mul x 3072 2.85 -> 2.69 ms per
-    // batch against the twelve-lane engine, x 2048 the same either way; H2V_PAIRING_SIX = 0 / 1 forces the choice).  ms per step, narrow -> six: simple_mul x 4096
+    // batch against the twelve-lane engine, x 2048 the same either way).  ms per step, narrow -> six: simple_mul x 4096
     // 4.06 -> 3.88 with six batches in flight, 3.76 with eight; below that size its few long waves lose: lookup_table x 2048
     // 3.48 -> 3.65, atms x 2048 3.92 -> 5.10.
     return launch_pairing_impl(impl, d, n, pts, valid, valid_sub, er, el_jac, status, accept, dbg, st, nullptr, prefer_narrow,
@@ -1097,7 +1128,7 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
 static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst,
                         const uint8_t *ci, uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st,
                         h2v_timings *tm, bool want_trace) {
-    g_opts.msm_tpl = w->opt_msm_tpl; g_opts.pairing = w->opt_pairing; g_opts.in_flight = w->in_flight_hint;
+    opts_from(w);
     struct Reset { ~Reset() { g_opts = LaunchOptions(); } } reset_opts;
     const uint32_t slots = H2V_SLOTS(d);
     const uint32_t vm_blocks = (n + 63) / 64;
@@ -1125,11 +1156,12 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
         if (status_out) HIPCHK(hipMemcpyAsync(status_out, status, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         return H2V_OK;
     }
-    // number of chunks (H2V_PIPES).  Default 1: measured on MI355X, 2/3/4 concurrent pipelines of a 4096-proof batch
+    // number of chunks (H2V_OPT_PIPES).  Default 1: measured on MI355X, 2/3/4 concurrent pipelines of a 4096-proof batch
     // took 14.2 / 20.7 / 29.1 ms against 13.5 ms for one (kernels with different private-segment sizes alternating on
     // several queues cost more than the idle SIMDs they fill), so the split is kept as an experiment knob only.
-    static const bool split_dec = []() { const char *e = getenv("H2V_SPLIT_DEC"); return e ? atoi(e) != 0 : true; }();
-    static const int env_pipes = []() { const char *e = getenv("H2V_PIPES"); return e ? atoi(e) : 0; }();
+    const int dec_form = w->opt[H2V_OPT_DECOMPRESS_FORM];     // 0 / 1: two roles (queue launch / two launches); 2: one launch of paired blocks
+    const bool split_dec = dec_form != 2;
+    const int env_pipes = w->opt[H2V_OPT_PIPES];
     int pipes = env_pipes > 0 ? env_pipes : 1;
     if (pipes > h2v_workspace::MAXP) pipes = h2v_workspace::MAXP;
     if (want_trace || (uint32_t)pipes > n) pipes = 1;
@@ -1141,13 +1173,12 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
     for (int k = 0; k < pipes; k++) {
         const uint32_t lo = (uint32_t)((uint64_t)n * k / pipes), hi = (uint32_t)((uint64_t)n * (k + 1) / pipes), m = hi - lo;
         hipEvent_t *ev = w->ring[slot][k];
-        static const bool dec_queue_on = []() { const char *e = getenv("H2V_DEC_QUEUE"); return e ? atoi(e) != 0 : true; }();
+        const bool dec_queue_on = dec_form == 0;
         // A caller that keeps >= 6 batches in flight (h2v_workspace_hint_in_flight) gets the whole pipeline on ITS stream: the
         // other batches fill the chip, and one stream per batch keeps many batches within the 16 hardware queues (three
         // streams per batch collide from the sixth batch on).  Measured, 40 steps of simple_mul x 4096: three streams 5 / 8 / 11
-        // in flight 4.46 / 4.66 / 4.75 ms per step, one stream 4.80 / 4.39 / 4.50.  H2V_ONE_STREAM = 0 / 1 forces the choice.
-        static const int env_one = []() { const char *e = getenv("H2V_ONE_STREAM"); return e ? atoi(e) : -1; }();
-        const bool one_stream = pipes == 1 && (w->one_stream_mode >= 0 ? w->one_stream_mode == 1 : env_one >= 0 ? env_one != 0 : w->in_flight_hint >= 6);
+        // in flight 4.46 / 4.66 / 4.75 ms per step, one stream 4.80 / 4.39 / 4.50.  H2V_OPT_STREAMS forces the choice.
+        const bool one_stream = pipes == 1 && (w->one_stream_mode >= 0 ? w->one_stream_mode == 1 : w->in_flight_hint >= 6);
         // one_stream_mode 2 (lanes): the pipeline on the stream it is given, only the decompression beside it on a side stream
         const bool two_stream = pipes == 1 && w->one_stream_mode == 2;
         if (!one_stream || two_stream)
@@ -1173,10 +1204,10 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
             return 0;
         };
         // Decompression: by default ONE launch whose waves (at most one per SIMD) take 64-point units from a queue - all
-        // subgroup tests, then all square roots (k_g1_decompress_queue); H2V_DEC_QUEUE = 0: the two halves as two
-        // launches of 64-thread blocks on two streams; H2V_SPLIT_DEC = 0: one launch of 128-thread blocks, a root wave and
-        // a subgroup wave per block.
-        static const bool dec_queue = []() { const char *e = getenv("H2V_DEC_QUEUE"); return e ? atoi(e) != 0 : true; }();
+        // subgroup tests, then all square roots (k_g1_decompress_queue); H2V_OPT_DECOMPRESS_FORM = 1: the two halves as two
+        // launches of 64-thread blocks on two streams; = 2: one launch of 128-thread blocks, a root wave and a subgroup
+        // wave per block.
+        const bool dec_queue = dec_form == 0;
         auto sqrt_half = [&]() {
             HIPCHK(hipEventRecord(ev[2], ps));
             if (split_dec && dec_queue) {
@@ -1280,15 +1311,14 @@ static const uint32_t *rlc_flags_of(const h2v_workspace *w);
 // decompression on a side stream.  Measured (ms per batch; 8 lanes two streams each -> 16 lanes one stream each): secp256k1
 // shape x 64 0.87 -> 0.57, x 128 1.12 -> 0.74; sha256 shape x 128 0.94 -> 0.74, x 256 1.29 -> 0.90, x 512 1.45 -> 1.24, secp256k1
 // x 512 1.51 -> 1.34, simple_mul x 1024 1.48 -> 1.23; simple_mul x 2048 and sha256 x 1024: the same either way (2.16 / 2.18).
-// An explicit lane count (h2v_workspace_create_lanes) is kept; H2V_OPT_STREAMS / H2V_LANE_ONE_STREAM force the streams.
+// An explicit lane count (h2v_workspace_create_lanes) is kept; H2V_OPT_STREAMS forces the streams.
 static uint32_t laned_depth(const h2v_workspace *w, uint64_t n, bool rlc, int *stream_mode) {
     if (stream_mode) *stream_mode = 1;
     if (rlc) return w->n_lanes;
     const uint64_t m = n < w->chunk ? n : w->chunk;
     const bool small = (double)m * w->lane_plan.n_terms / 64.0 <= msm_n_simd() / 2.0;
     if (stream_mode) {
-        static const int env_mode = []() { const char *e = getenv("H2V_LANE_ONE_STREAM"); return e ? atoi(e) : -1; }();
-        *stream_mode = w->one_stream_mode >= 0 ? w->one_stream_mode : env_mode >= 0 ? env_mode : small ? 1 : 2;
+        *stream_mode = w->one_stream_mode >= 0 ? w->one_stream_mode : small ? 1 : 2;
     }
     return (small || w->lanes_per_proof >= w->n_lanes) ? w->n_lanes : w->lanes_per_proof;
 }
@@ -1303,7 +1333,9 @@ static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const
     // eight lanes: chunks of 4096 24.0 ms, 2560 22.5 ms, 2048 27.7 ms.  (RLC mode: every chunk is a batch check of its own and
     // 4096 measured best - 45 056 proofs in 4096s 19.3 ms, in 2816s 20.6 ms.)
     uint32_t chunk = w->chunk;
-    if (!rlc && n > chunk && (uint64_t)n < (uint64_t)L * chunk) {
+    // (only for a call that waits for its own chunks: with deferred joins or streamed host batches the NEXT call fills the lanes,
+    //  and whole chunks keep the full-chip launch shapes - a stream of 16 384-proof calls: 15.9 ms per call cut in 2048s, ~13 in 4096s)
+    if (!rlc && !w->defer_joins && !never_join && n > chunk && (uint64_t)n < (uint64_t)L * chunk) {
         const uint32_t c2 = (uint32_t)(((n + L - 1) / L + 511) / 512 * 512);
         if (c2 >= 2048 && c2 < chunk) chunk = c2;
     }
@@ -1391,6 +1423,104 @@ extern "C" int h2v_verify_batch_device(const h2v_plan *p, const h2v_batch *b, ui
     if (tmp) {
         if (rc == H2V_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = fail(H2V_E_DEVICE, "stream synchronize failed");
         h2v_workspace_free(tmp);
+    }
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------- measured launch shapes
+// h2v_workspace_tune: instead of trusting the launcher's thresholds (calibrated on five shapes on one chip), MEASURE the
+// candidate shapes for THIS plan, batch size and workspace regime once and leave the winner on the workspace.  The batch is
+// run repeatedly in the way the workspace will be used - a laned workspace with as many calls in flight as it has lanes for
+// that size (deferred joins), an ordinary one call by call - because the shapes interact: the six-lane pairing engine is the
+// slowest engine alone and the fastest one in a full pipeline.  Coordinate descent over the two dimensions that matter per
+// call (pairing engine, MSM terms per lane): the launcher's own choice first, then each neighbouring engine, then each
+// terms-per-lane value with the best engine.  A candidate replaces the incumbent only if it is more than 1.5 % faster.
+// accept[] goes to a scratch buffer: verdicts do not depend on shapes (tests/test_gpu_parity.py).
+extern "C" int h2v_workspace_tune(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws, void *stream, uint32_t flags, h2v_tune_report *rep) {
+    if (!p || !b || !ws) return fail(H2V_E_ARG, "null argument");
+    ALIVE(p); ALIVE(ws);
+    if (flags != 0) return fail(H2V_E_ARG, "flags must be 0 (the per-proof mode is what is tuned)");
+    if (b->n == 0 || !b->proofs || !b->proof_off) return fail(H2V_E_ARG, "tuning needs a representative device-resident batch");
+    if (p->d.n_pi && !b->instances) return fail(H2V_E_ARG, "plan has public inputs but instances == NULL");
+    if (p->d.n_ci && !b->committed) return fail(H2V_E_ARG, "plan has a committed instance but committed == NULL");
+    HIPCHK(hipSetDevice(p->device));
+    if (int rcf = ws_fits(ws, p, b->n, false)) return rcf;
+    if (ws->pending) return fail(H2V_E_ARG, "the workspace has a host batch in flight: call h2v_verify_batch_wait first");
+    hipStream_t st = (hipStream_t)stream;
+    const bool laned = ws->n_lanes != 0;
+    if (laned && !st) return fail(H2V_E_ARG, "tuning a laned workspace keeps calls in flight: it needs a stream of its own, not the legacy NULL stream");
+    const uint32_t n = (uint32_t)b->n;
+    const uint32_t depth = laned ? laned_depth(ws, n, false, nullptr) : 1u;
+    const uint32_t m = laned && n > ws->chunk ? ws->chunk : n;         // proofs per launch
+    const double S = msm_n_simd();
+    uint8_t *acc_tmp = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipMalloc((void **)&acc_tmp, n) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (acc_tmp) (void)hipFree(acc_tmp);
+        if (e0) (void)hipEventDestroy(e0);
+        return fail(H2V_E_DEVICE, "tuning: allocation failed");
+    }
+    const bool saved_defer = ws->defer_joins;
+    const int32_t saved_pair = ws->opt[H2V_OPT_PAIRING_ENGINE], saved_tpl = ws->opt[H2V_OPT_MSM_TERMS_PER_LANE];
+    int rc = H2V_OK;
+    auto set2 = [&](int32_t pairing, int32_t tpl) {
+        (void)h2v_workspace_set_option(ws, H2V_OPT_PAIRING_ENGINE, pairing);
+        (void)h2v_workspace_set_option(ws, H2V_OPT_MSM_TERMS_PER_LANE, tpl);
+    };
+    auto round_of_calls = [&](uint32_t calls) -> int {
+        for (uint32_t k = 0; k < calls; k++) {
+            int r = laned ? run_laned(p, n, b->proofs, b->proof_off, b->instances, b->committed, acc_tmp, nullptr, ws, st, false, nullptr, false)
+                          : run_pipeline(p->d, n, b->proofs, b->proof_off, b->instances, b->committed, acc_tmp, nullptr, ws, st, nullptr, false);
+            if (r) return r;
+        }
+        return laned ? lanes_join(ws, st) : H2V_OK;
+    };
+    uint32_t n_meas = 0;
+    auto measure = [&](int32_t pairing, int32_t tpl, float *ms) -> int {
+        set2(pairing, tpl);
+        if (laned) ws->defer_joins = true;
+        int r = round_of_calls(depth);                                  // fills the lanes (and creates them)
+        if (r) return r;
+        const uint32_t calls = laned ? 2 * depth : 3;
+        if (hipEventRecord(e0, st) != hipSuccess) return fail(H2V_E_DEVICE, "event record failed");
+        if ((r = round_of_calls(calls))) return r;
+        if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return fail(H2V_E_DEVICE, "tuning: the measured calls failed");
+        float t = 0;
+        if (hipEventElapsedTime(&t, e0, e1) != hipSuccess) return fail(H2V_E_DEVICE, "event timing failed");
+        *ms = t / (float)calls;
+        n_meas++;
+        return H2V_OK;
+    };
+    float best_ms = 0, def_ms = 0;
+    int32_t best_pair = 0, best_tpl = 0;
+    do {
+        if ((rc = measure(0, 0, &def_ms))) break;
+        best_ms = def_ms;
+        const int32_t full[] = {6, 12, 16}, mid[] = {12, 16, 32}, low[] = {32, 64};
+        const int32_t *eng = (double)m >= 2.0 * S ? full : (double)m >= S / 4.0 ? mid : low;
+        const int n_eng = (double)m >= S / 4.0 ? 3 : 2;
+        for (int k = 0; k < n_eng && !rc; k++) {
+            float t;
+            if ((rc = measure(eng[k], 0, &t))) break;
+            if (t < best_ms * 0.985f) { best_ms = t; best_pair = eng[k]; }
+        }
+        if (rc) break;
+        const bool ladders_share = !p->d.ivc && (double)m * p->d.n_main_terms / 64.0 >= S / 8.0;   // (k_g1_msm_multi's own preconditions)
+        for (int32_t tpl = 2; tpl <= 4 && ladders_share && !rc; tpl++) {
+            float t;
+            if ((rc = measure(best_pair, tpl, &t))) break;
+            if (t < best_ms * 0.985f) { best_ms = t; best_tpl = tpl; }
+        }
+    } while (0);
+    ws->defer_joins = saved_defer;
+    if (rc == H2V_OK) set2(best_pair, best_tpl); else set2(saved_pair, saved_tpl);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(acc_tmp);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc == H2V_OK && rep) {
+        memset(rep, 0, sizeof *rep);
+        rep->n_measured = n_meas; rep->default_ms = def_ms; rep->best_ms = best_ms; rep->calls_in_flight = depth;
+        rep->pairing_engine = best_pair; rep->msm_terms_per_lane = best_tpl;
     }
     return rc;
 }
@@ -1752,10 +1882,9 @@ static int pip_alloc(PipWs &w, uint32_t cap_n, uint32_t halves) {
 // Window width for n terms.  Larger windows mean fewer windows (W = floor(128 / c) + 1 per GLV half) but 2^(c-1) buckets
 // per window, capped at 512 so that one block's LDS holds a window in k_pip_reduce; at least ~24 entries per bucket on
 // average.  chain = the most entries one lane of k_pip_accumulate sums (a bucket of more gets 2, 4, ... 256 lanes): short
-// chains mean more lanes and deeper trees of complete additions.  H2V_PIP_C / H2V_PIP_CHAIN force a shape (tests, tuning).
+// chains mean more lanes and deeper trees of complete additions.  H2V_OPT_RLC_WINDOW_BITS / _CHAIN force a shape (tests, tuning).
 static void pip_shape(PipArgs &a) {
-    static const int env_c = []() { const char *e = getenv("H2V_PIP_C"); return e ? atoi(e) : 0; }();
-    static const int env_chain = []() { const char *e = getenv("H2V_PIP_CHAIN"); return e ? atoi(e) : 0; }();
+    const int env_c = g_opts.v[H2V_OPT_RLC_WINDOW_BITS], env_chain = g_opts.v[H2V_OPT_RLC_CHAIN];
     const double entries_per_window = (double)a.n * a.halves;
     uint32_t c = PIP_MAX_C;
     while (c > 4 && entries_per_window / (double)(1u << (c - 1)) < 24.0) c--;
@@ -1867,15 +1996,14 @@ static bool rlc_supported(const h2v_plan *p) { return !p->d.ivc && p->n_var > 0 
 // is two small bucket MSMs (right: 64 n_var + n_fix terms, 255-bit scalars; left: 64 terms, 128-bit) with 7-bit windows
 // (64 buckets x 19 windows: ~20 entries per bucket on the right).  Batches below GRP_MIN_N proofs or above GRP_MAX_G groups
 // go straight to the per-proof kernels.  Everything here is enqueued behind the batch check and returns at once when it
-// passed.  H2V_RLC_GROUPS=0 switches the stage off (measurements).  (Window width 5 / 6 / 7 / 8 bits, one rejecting proof per
+// passed.  H2V_OPT_RLC_GROUP_STAGE = -1 switches the stage off (measurements).  (Window width 5 / 6 / 7 / 8 bits, one rejecting proof per
 // 4096-proof batch, sixteen batches in flight: 2.90 / 2.72 / 2.86 / 2.80 ms per batch - the three pairing stages in a row are
 // what the fall-back waits for, not these sums.)
 #define GRP_MIN_N 256u
 #define GRP_MAX_G 512u
 #define GRP_C 7u
 static bool rlc_groups_on(uint32_t n) {
-    static const int env = []() { const char *e = getenv("H2V_RLC_GROUPS"); return e ? atoi(e) : 1; }();
-    return env != 0 && n >= GRP_MIN_N && (n + 63) / 64 <= GRP_MAX_G;
+    return g_opts.v[H2V_OPT_RLC_GROUP_STAGE] >= 0 && n >= GRP_MIN_N && (n + 63) / 64 <= GRP_MAX_G;
 }
 // The argument array of the group stage is cached per (batch size, plan, point buffer).  When it has to change, the new one
 // is uploaded ON THE CALL'S STREAM from a pinned host copy: the kernels of an earlier call on that stream read args_d when
@@ -1986,16 +2114,16 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     const H2vDevPlan &d = p->d;
     int rc = rlc_ensure(w, p);
     if (rc) return rc;
-    g_opts.msm_tpl = w->opt_msm_tpl; g_opts.pairing = w->opt_pairing; g_opts.in_flight = w->in_flight_hint;
+    opts_from(w);
+    struct Reset { ~Reset() { g_opts = LaunchOptions(); } } reset_opts;
     RlcWs *r = w->rlc;
     const uint32_t slots = H2V_SLOTS(d);
     hipEvent_t *ev = r->ring[r->calls % h2v_workspace::RING];
     r->calls++;
     // two streams per batch: the caller's (transcript + combiner, then everything else) and one for the decompression
-    // one_stream (h2v_rlc_opts.flags & H2V_RLC_ONE_STREAM, or the environment variable of that name = 1 / 0): everything on
+    // one_stream (h2v_rlc_opts.flags & H2V_RLC_ONE_STREAM, or H2V_OPT_STREAMS = 1): everything on
     // the caller's stream, decompression before the combiner - one stream per batch in flight instead of two
-    static const int env_one = []() { const char *e = getenv("H2V_RLC_ONE_STREAM"); return e ? atoi(e) : -1; }();
-    const bool one_stream = w->one_stream_mode >= 0 ? w->one_stream_mode != 0 : env_one >= 0 ? env_one != 0 : (one_stream_opt || w->in_flight_hint >= 3);   // (the flag, or the caller's in-flight hint)
+    const bool one_stream = w->one_stream_mode >= 0 ? w->one_stream_mode != 0 : (one_stream_opt || w->in_flight_hint >= 3);   // (H2V_OPT_STREAMS, the flag, or the caller's in-flight hint)
     if (!one_stream && (rc = ws_streams(w, 0, false, true, false))) return rc;
     hipStream_t pm = st, ps = one_stream ? st : w->pside[0];
     if (!one_stream) {
@@ -2009,8 +2137,7 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
         uint32_t blocks = (units + 3) / 4;
         if (blocks > max_blocks) blocks = max_blocks;
         HIPCHK(hipMemsetAsync(w->dec_ctr, 0, 4, ps));
-        static const bool dbg_tables = getenv("H2V_RLC_TABLES") != nullptr;   // experiment knob: build the (unused) window tables as the per-proof mode does
-        hipLaunchKernelGGL(k_g1_decompress_queue, dim3(blocks), dim3(256), 0, ps, d, n, proofs, off, ci, inst, w->pts, w->valid, dbg_tables ? w->pt_tab : (uint32_t *)nullptr, w->valid_sub, w->dec_ctr, dec_grid);
+        hipLaunchKernelGGL(k_g1_decompress_queue, dim3(blocks), dim3(256), 0, ps, d, n, proofs, off, ci, inst, w->pts, w->valid, (uint32_t *)nullptr, w->valid_sub, w->dec_ctr, dec_grid);
     }
     HIPCHK(hipEventRecord(ev[1], ps));
     HIPCHK(hipEventRecord(w->ev_join[0], ps));
@@ -2328,6 +2455,7 @@ extern "C" int h2v_probe_g1_msm(int device, uint32_t n, uint32_t T, const uint8_
     int rc = pick_device(device);
     if (rc) return rc;
     if (!scalars || !bases_compressed || !out_xy_be || n == 0 || T == 0 || T > 64) return fail(H2V_E_ARG, "bad argument");
+    ProbeOpts probe_opts;
     MiniPlan mp;
     DevBuf din, doff, dsc, dpts, dvalid, der, dout, dtab;
     if (mp.build(T, T, nullptr, nullptr) || upload_offsets(doff, n, 48 * T) || din.alloc((size_t)n * T * 48) || dsc.alloc((size_t)n * T * 32) ||
@@ -2375,6 +2503,7 @@ extern "C" int h2v_probe_g1_msm_pippenger(int device, uint32_t n, const uint8_t 
     int rc = pick_device(device);
     if (rc) return rc;
     if (!scalars || !bases_compressed || !out_xy_be || n == 0 || n > (1u << 24)) return fail(H2V_E_ARG, "bad argument");
+    ProbeOpts probe_opts;
     MiniPlan mp;
     DevBuf din, doff, dsc, dpts, dvalid, dres, dout;
     if (mp.build(1, 0, nullptr, nullptr) || upload_offsets(doff, n, 48) || din.alloc((size_t)n * 48) || dsc.alloc((size_t)n * 32) ||
@@ -2406,6 +2535,7 @@ extern "C" int h2v_probe_pairing(const h2v_plan *p, uint32_t n, const uint8_t *p
 extern "C" int h2v_probe_pairing_ex(const h2v_plan *p, uint32_t n, const uint8_t *p1c, const uint8_t *p2c, uint8_t *out, int impl, uint8_t *dbg) {
     if (!p || !p1c || !p2c || !out || n == 0) return fail(H2V_E_ARG, "bad argument");
     ALIVE(p);
+    ProbeOpts probe_opts;
     DevBuf ddbg;
     HIPCHK(hipSetDevice(p->device));
     MiniPlan mp;

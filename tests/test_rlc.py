@@ -414,14 +414,26 @@ def test_rlc_infinity_points(be, circuits):
     assert want[3] == 0 and want[7] == 0 and sum(want) >= n - 3
 
 
-def test_rlc_one_stream_form(be):
-    """H2V_RLC_ONE_STREAM (the form for callers with many batches in flight: decompression ahead of the combiner on the
-    caller's stream) is read once per process: the corruption and mixed-batch tests again in a child process with it set."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_rlc.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "single_corruptions or mixed_batch or duplicate"],
-                       env={**os.environ, "H2V_RLC_ONE_STREAM": "1"}, cwd=root, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+def test_rlc_one_stream_form(be, circuits):
+    """The one-stream form of the RLC mode (decompression ahead of the combiner on the caller's stream: for callers with many
+    batches in flight) through H2V_OPT_STREAMS = 1 and through h2v_rlc_opts.flags & H2V_RLC_ONE_STREAM, in-process: a batch with
+    every corruption kind gives the construction's vector, as the two-stream form does."""
+    import torch
+    from plutus_halo2_verifier_gen_amd import synth
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.frombuffer(bytearray(x), dtype=torch.uint8).to(dev) if x else None
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    for name in ("simple_mul", "lookup_table", "sha256"):
+        vk, td, pl, dp, ov = circuits[name]
+        n = 300
+        b = synth.forge_batch(vk, td, n, seed=17, plan=pl, workers=4, ci_identity=(name == "sha256"))
+        b = synth.with_rejects(pl, b, vk.n_public_inputs, fraction=0.1, seed=18, kinds=list(synth.CORRUPTIONS))
+        d = (up(b.proofs), torch.tensor(b.proof_off, dtype=torch.int64).to(dev), up(b.instances), up(b.committed))
+        for streams, flag in ((1, False), (0, False), (-1, True)):
+            ws = be.Workspace(dp, n)
+            ws.set_option(be.OPT_STREAMS, streams)
+            acc = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+            dp.verify_batch_rlc_device(n, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), acc.data_ptr(), None, ws=ws, stream=None, seed=bytes(range(32)), one_stream=flag)
+            torch.cuda.synchronize()
+            assert acc.cpu().tolist() == b.expected, (name, streams, flag)
+            ws.close()
