@@ -462,9 +462,17 @@ def main():
         """averages of the event-timed kernel durations of part p over the last k_steps steps of a run"""
         info = {}
         if mode == "rlc":
+            # steps that the workspace ROUTED to the per-proof kernels (include/h2v.h: ROUTING) have no batch-check record
+            routed = [j for j in range(k_steps) if run.rlc_result(j, p)[1].total_ms == 0 and not run.rlc_result(j, p)[0]]
+            routed_state[p] = len(routed) / float(k_steps)
+            if len(routed) * 2 > k_steps:
+                return kernel_times(run, "per-proof", k_steps, p)
+        if mode == "rlc":
             acc = {k: 0.0 for k in RLC_KEYS}
             span, all_ok = 0.0, True
-            for j in range(k_steps):
+            steps_rlc = [j for j in range(k_steps) if j not in routed]
+            k_steps = len(steps_rlc)
+            for j in steps_rlc:
                 ok, tm = run.rlc_result(j, p)
                 all_ok = all_ok and ok
                 for nm, v in zip(RLC_KEYS, [tm.transcript_combiner_ms, tm.g1_decompress_ms, tm.prepare_ms, tm.bucket_sort_ms,
@@ -491,6 +499,7 @@ def main():
 
     gather_state = {"ok": None}
     tuned_state = []
+    routed_state = {}
     if args.timed_only:
         args.no_cpu_baseline = args.no_rlc_secondary = True
         inflight_candidates = inflight_candidates[:1]
@@ -569,6 +578,8 @@ def main():
     if rank == 0:
         result = report(args, parts, per_part, per_part_alone, alone, elapsed, inflight, inflight_probe, label, B, B_total, world, ranks_seen, backend_seen,
                         timed_expected, ok_all, gather_state["ok"], reject_check, t_forge, PL)
+        if args.mode == "rlc":
+            result["config"]["rlc_steps_routed_to_the_per_proof_kernels"] = round(max(routed_state.values()), 3) if routed_state else 0.0
         result["config"]["tuned_launch_shapes"] = tuned_state or None    # h2v_workspace_tune per plan (0 = the launcher's rule was not beaten by 1.5 %)
         if rlc_secondary is not None:
             result["rlc_mode"] = rlc_secondary
@@ -680,7 +691,9 @@ def report(args, parts, per_part, per_part_alone, alone, elapsed, inflight, infl
     """The one JSON line: aggregates the parts of the workload (one part unless the workload is a mixed batch)."""
     ms_per_step = elapsed / args.steps * 1e3
     own = per_part_alone if per_part_alone is not None else per_part
-    models = [part_model(P, PL, args.mode, own[i][2]) for i, P in enumerate(parts)]
+    # (an RLC run whose steps the workspace routed to the per-proof kernels is modelled as what ran)
+    mode = "rlc" if args.mode == "rlc" and own[0][2]["rlc_shape"] else "per-proof"
+    models = [part_model(P, PL, mode, own[i][2]) for i, P in enumerate(parts)]
     msm_key = models[0][3]
     keys = []
     for i in range(len(parts)):
@@ -699,7 +712,7 @@ def report(args, parts, per_part, per_part_alone, alone, elapsed, inflight, infl
     msm_lpt, pair_lanes, var_lpt = own[0][2]["msm_lpt"], own[0][2]["pair_lanes"], own[0][2]["var_lpt"]
     rlc_shape, all_batch_ok = own[0][2]["rlc_shape"], own[0][2]["all_batch_ok"]
     pmc_batch = parts[0].B
-    tab, hdr, pmc_src = pmc_table(args.workload, pmc_batch, args.mode)
+    tab, hdr, pmc_src = pmc_table(args.workload, pmc_batch, mode)
 
     def traffic_of(k):
         vals = [pmc_traffic(tab, nm) for nm in names_of[k]]
@@ -730,7 +743,7 @@ def report(args, parts, per_part, per_part_alone, alone, elapsed, inflight, infl
                 "unit": "T lane-mad/s", "frac": round(tops / IMAD_PEAK_TOPS, 4) if IMAD_PEAK_TOPS else None,
                 "mads_per_launch": mads[k] // launches_of[k]}
 
-    if args.mode == "rlc":
+    if mode == "rlc":
         # the longest launches of an RLC batch are lone-wave chains (the ONE pairing, the bucket reduction): "dominant" is
         # the longest of the launches that fill the chip
         dominant = max(("g1_decompress", "transcript_combiner", "bucket_accumulate", "rlc_prepare", "bucket_sort"), key=kernel_ms.get)
@@ -816,7 +829,7 @@ def report(args, parts, per_part, per_part_alone, alone, elapsed, inflight, infl
                               "achieved": round(sum(mads.values()) / (elapsed / args.steps) / 1e12, 3), "peak": round(IMAD_PEAK_TOPS, 2) if IMAD_PEAK_TOPS else None,
                               "unit": "T lane-mad/s", "frac": round(sum(mads.values()) / (elapsed / args.steps) / 1e12 / IMAD_PEAK_TOPS, 4) if IMAD_PEAK_TOPS else None},
         "batch_latency_ms": round(batch_latency_ms, 4),
-        "pipelines_per_step": launches, "msm_lanes_per_term": msm_lpt, "msm_ladder_shape_of_a_split": var_lpt if msm_lpt == 3 else None, "pairing_lanes_per_proof": pair_lanes if args.mode == "per-proof" else None,
+        "pipelines_per_step": launches, "msm_lanes_per_term": msm_lpt, "msm_ladder_shape_of_a_split": var_lpt if msm_lpt == 3 else None, "pairing_lanes_per_proof": pair_lanes if mode == "per-proof" else None,
         "shapes_per_part": [{"circuit": P.name, "msm_lanes_per_term": own[i][2]["msm_lpt"], "msm_ladder_shape_of_a_split": own[i][2]["var_lpt"],
                              "pairing_lanes_per_proof": own[i][2]["pair_lanes"]} for i, P in enumerate(parts)] if len(parts) > 1 else None,
         "all_accepted": ok_all if timed_expected is None else None,
@@ -825,7 +838,7 @@ def report(args, parts, per_part, per_part_alone, alone, elapsed, inflight, infl
         "reject_dataset": reject_check,
         "forge_seconds": round(t_forge, 2),
     }
-    if args.mode == "rlc":
+    if mode == "rlc":
         result["rlc"] = dict(rlc_shape, batch_check_passed_every_step=all_batch_ok,
                              soundness="accept[] equals the per-proof mode's except with probability <= 2^-128 over the seed")
     return result

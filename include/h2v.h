@@ -159,7 +159,8 @@ int h2v_workspace_join(h2v_workspace *ws, void *stream);
 #define H2V_OPT_RLC_GROUP_STAGE 11u   /* RLC fall-back: -1 skips the group checks (straight to the per-proof kernels) */
 #define H2V_OPT_RLC_WINDOW_BITS 12u   /* bucket MSM: window width */
 #define H2V_OPT_RLC_CHAIN 13u         /* bucket MSM: most entries one lane sums */
-#define H2V_OPT_COUNT 14u
+#define H2V_OPT_RLC_ROUTE 14u         /* RLC calls are routed by the observed rate of failing groups (h2v_verify_batch_rlc below); -1: always the batch check first */
+#define H2V_OPT_COUNT 15u
 int h2v_workspace_set_option(h2v_workspace *ws, uint32_t option, int32_t value);
 int h2v_workspace_get_option(const h2v_workspace *ws, uint32_t option, int32_t *value);
 /* (round 4) MEASURED launch shapes.  The launcher's own rules are thresholds calibrated on five circuit shapes; a circuit or a
@@ -236,7 +237,13 @@ int h2v_verify_batch_device(const h2v_plan *plan, const h2v_batch *batch, uint8_
  * individually and take no part in the combination.  If the batch check fails, the per-proof MSM and pairing kernels run
  * for the whole batch, so accept[] is always what the per-proof mode returns, except with probability <= 2^-128 over the
  * seed (a rejecting proof hidden by the combination).  Recursive (IVC) plans have no batch form and run per proof.
- * ws must not be NULL for the device form. */
+ * ws must not be NULL for the device form.
+ * ROUTING (round 4): a failed batch check costs more than the per-proof mode it falls back to, so a workspace keeps a running
+ * estimate of the rate of FAILING GROUPS (64 proofs each) among the groups its RLC calls have met, and while that rate is
+ * above 0.10 it sends RLC calls straight to the per-proof kernels (back to the batch check below 0.05; the estimate moves a
+ * quarter of the way per call: one rejecting proof per batch - one group in 64 - never switches, a batch in which half the
+ * groups fail switches the next call, and some ten clean calls switch back).  accept[] is the same either way;
+ * fell_back = 1 / batch_accepted = 0 say that the per-proof kernels produced it.  H2V_OPT_RLC_ROUTE = -1 switches routing off. */
 #define H2V_RLC_SEED_GIVEN 1u /* TEST ONLY: soundness rests on the seed being unpredictable to the provers; without this flag
                                * the library draws 32 bytes from the OS per call (getrandom) and fails closed.  With it, a
                                * process-wide call counter is still mixed into the seed, so repeated calls differ. */

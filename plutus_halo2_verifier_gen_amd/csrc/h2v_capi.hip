@@ -181,6 +181,13 @@ struct h2v_workspace {
     bool copy_streams_owned = false;        // laned: hs / hs_down carry copies only and are plain streams of this workspace (host_stream)
     uint32_t *rlc_fail = nullptr;           // RING counters: failed batch checks among the chunks of a call (RLC mode)
     uint32_t *rlc_fail_ptr = nullptr;       // (a lane: where its batch check reports a failure; set by the parent per call)
+    // routing of RLC calls by what earlier calls met (rlc_route): cumulative device counters [groups seen, groups failed], a
+    // pinned host mirror refreshed behind every call, and the running estimate of the failing-group rate
+    uint32_t *rlc_stats = nullptr, *rlc_stats_ptr = nullptr, *h_rlc_stats = nullptr;
+    uint32_t seen_groups = 0, seen_failed = 0;
+    float fail_rate = 0.0f;
+    bool routed = false;                    // the most recent RLC call ran the per-proof kernels directly
+    uint8_t lring_routed[64] = {};          // (per call slot)
     // per call (ring): number of chunks, first lane, and every lane's call counters when the call had been enqueued -
     // what h2v_workspace_timings / _rlc_result need to find the chunks' event sets in the lanes' own rings
     uint32_t lring_chunks[RING] = {}, lring_first[RING] = {}, lring_mod[RING] = {};
@@ -488,7 +495,8 @@ static void ws_release(h2v_workspace *w) {
     }
     w->n_lanes = 0;
     if (w->rlc) { rlc_release(w->rlc); w->rlc = nullptr; }
-    void *ptrs[] = {w->rlc_fail, w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->er_fix, w->dec_ctr, w->accept, w->in_block, w->msm_tab,
+    if (w->h_rlc_stats) (void)hipHostFree(w->h_rlc_stats);
+    void *ptrs[] = {w->rlc_stats, w->rlc_fail, w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->er_fix, w->dec_ctr, w->accept, w->in_block, w->msm_tab,
                     w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2, w->pt_tab};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (w->h_block) (void)hipHostFree(w->h_block);
@@ -646,6 +654,7 @@ static int option_check(uint32_t option, int32_t value) {
     case H2V_OPT_RLC_GROUP_STAGE: if (value < -1 || value > 0) return bad("RLC group stage: 0 (auto), -1 (off)"); break;
     case H2V_OPT_RLC_WINDOW_BITS: if (value != 0 && (value < 3 || value > (int32_t)PIP_MAX_C)) return bad("RLC window bits: 0 (auto), 3 .. the bucket MSM's maximum"); break;
     case H2V_OPT_RLC_CHAIN: if (value != 0 && (value < 2 || value > 1024)) return bad("RLC entries per lane: 0 (auto), 2 .. 1024"); break;
+    case H2V_OPT_RLC_ROUTE: if (value < -1 || value > 0) return bad("RLC routing: 0 (by the observed rate of failing groups), -1 (never)"); break;
     default: return bad("unknown option");
     }
     return H2V_OK;
@@ -1297,6 +1306,45 @@ static int run_pipeline(const H2vDevPlan &d, uint32_t n, const uint8_t *proofs, 
 
 static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
                    uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, const uint32_t seed[8], bool one_stream_opt);
+// ROUTING of RLC calls (round 4).  The batch-accept mode pays for every batch whose check fails: with 1 % rejecting proofs
+// nearly half of the groups of 64 fail, and the call costs 1.3 x the per-proof mode it falls back to.  A workspace therefore
+// keeps a running estimate of the rate of FAILING GROUPS among the groups its RLC calls have seen - cumulative device
+// counters written by the batch / group checks (or, for a routed call, by k_rlc_count_groups from the status words), mirrored
+// into pinned host memory behind every chunk and read without synchronisation at the head of the next call - and sends a
+// call straight to the per-proof kernels while that rate is above 0.10 (back to the batch check below 0.05).  Break-even,
+// measured (simple_mul x 4096, sixteen calls in flight, ms per call): honest 1.37; one failing group (1 reject) 2.74; 17 % of the
+// groups failing (0.3 % rejects) 3.72; the per-proof mode 3.25 whatever it meets: about 2.6 + 6.4 x rate, equal at a rate of 0.1.
+// Same accept[] either way; fell_back / h2v_workspace_rlc_result report which path ran.  H2V_OPT_RLC_ROUTE = -1: never route.
+static int rlc_stats_ensure(h2v_workspace *w) {
+    if (w->rlc_stats) return H2V_OK;
+    if (hipMalloc((void **)&w->rlc_stats, 8) != hipSuccess || hipMemset(w->rlc_stats, 0, 8) != hipSuccess ||
+        hipHostMalloc((void **)&w->h_rlc_stats, 8, hipHostMallocDefault) != hipSuccess)
+        return fail(H2V_E_DEVICE, "allocation of the routing counters failed");
+    w->h_rlc_stats[0] = w->h_rlc_stats[1] = 0;
+    return H2V_OK;
+}
+static bool rlc_route(h2v_workspace *w) {
+    if (w->opt[H2V_OPT_RLC_ROUTE] < 0 || !w->h_rlc_stats) return false;
+    const volatile uint32_t *h = w->h_rlc_stats;
+    const uint32_t g = h[0], f = h[1];
+    const uint32_t dg = g - w->seen_groups, df = f - w->seen_failed;
+    if (dg) {
+        const float rate = df >= dg ? 1.0f : (float)df / (float)dg;
+        w->fail_rate = 0.75f * w->fail_rate + 0.25f * rate;
+        w->seen_groups = g; w->seen_failed = f;
+    }
+    w->routed = w->routed ? w->fail_rate > 0.05f : w->fail_rate > 0.10f;
+    return w->routed;
+}
+// a routed chunk / call: the per-proof pipeline, then the counters from its status words
+static int run_routed(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
+                      uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, uint32_t *stats) {
+    int rc = run_pipeline(p->d, n, proofs, off, inst, ci, accept, status_out, w, st, nullptr, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rlc_count_groups, dim3(((n + 63) / 64 + 63) / 64), dim3(64), 0, st, n, w->status, stats);
+    HIPCHK(hipGetLastError());
+    return H2V_OK;
+}
 static uint64_t rlc_calls_of(const h2v_workspace *w);
 static const uint32_t *rlc_flags_of(const h2v_workspace *w);
 // A call on a laned workspace: chunks of at most w->chunk proofs, round robin through the lanes (continuing where the
@@ -1347,7 +1395,13 @@ static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const
     const int slot = (int)(w->calls % h2v_workspace::RING);
     w->calls++;
     w->lring_chunks[slot] = nch; w->lring_first[slot] = (uint32_t)(w->next_lane % L); w->lring_mod[slot] = L; w->lring_rlc[slot] = rlc ? 1 : 0;
-    if (rlc) HIPCHK(hipMemsetAsync(w->rlc_fail + slot, 0, 4, st));
+    bool routed = false;
+    if (rlc) {
+        if (int rcs = rlc_stats_ensure(w)) return rcs;
+        routed = rlc_route(w);
+        w->lring_routed[slot] = routed ? 1 : 0;
+        HIPCHK(hipMemsetAsync(w->rlc_fail + slot, routed ? 1 : 0, 4, st));      // (routed: "a batch check failed" = the per-proof kernels produce accept[])
+    }
     HIPCHK(hipEventRecord(w->ev_fork, st));
     for (uint32_t c = 0; c < nch; c++) {
         const uint32_t l = (uint32_t)(w->next_lane++ % L);
@@ -1363,8 +1417,16 @@ static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const
             for (int k = 0; k < 8; k++) sd[k] = seed[k];
             sd[7] ^= 0x9e3779b9u * (c + 1);      // (a chunk is its own batch check: its own coefficients)
             lw->rlc_fail_ptr = w->rlc_fail + slot;
+            lw->rlc_stats_ptr = w->rlc_stats;
             lw->in_flight_hint = call_hint;
-            rc = run_rlc(p, m, proofs, off + lo, inst_c, ci_c, accept + lo, status_out ? status_out + lo : nullptr, lw, ls, sd, true);
+            lw->opt[H2V_OPT_RLC_GROUP_STAGE] = w->opt[H2V_OPT_RLC_GROUP_STAGE];
+            if (routed) {
+                lw->one_stream_mode = 1;
+                rc = run_routed(p, m, proofs, off + lo, inst_c, ci_c, accept + lo, status_out ? status_out + lo : nullptr, lw, ls, w->rlc_stats);
+            } else {
+                rc = run_rlc(p, m, proofs, off + lo, inst_c, ci_c, accept + lo, status_out ? status_out + lo : nullptr, lw, ls, sd, true);
+            }
+            if (rc == H2V_OK && hipMemcpyAsync(w->h_rlc_stats, w->rlc_stats, 8, hipMemcpyDeviceToHost, ls) != hipSuccess) rc = fail(H2V_E_DEVICE, "routing counters: copy failed");
         } else {
             lw->one_stream_mode = stream_mode;
             lw->in_flight_hint = call_hint;
@@ -1535,7 +1597,7 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
     const int slot = (int)((w->calls - 1 - calls_back) % h2v_workspace::RING);
     if (w->n_lanes) {
         // sums over the call's chunks (h2v_timings: `launches` = chunks); total_ms = first chunk's start .. the last end
-        if (w->lring_rlc[slot]) return fail(H2V_E_ARG, "that call ran in RLC mode: h2v_workspace_rlc_result");
+        if (w->lring_rlc[slot] && !w->lring_routed[slot]) return fail(H2V_E_ARG, "that call ran in RLC mode: h2v_workspace_rlc_result");
         memset(tm, 0, sizeof *tm);
         const uint32_t nch = w->lring_chunks[slot];
         hipEvent_t first = nullptr;
@@ -1666,6 +1728,8 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
                    uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, const uint32_t seed[8], bool one_stream_opt);
 static bool rlc_supported(const h2v_plan *p);
 static int rlc_seed(const h2v_rlc_opts *o, uint32_t seed[8]);
+static int run_rlc_or_routed(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
+                             uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, const uint32_t seed[8], bool one_stream_opt);
 
 extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, uint32_t *batch_accepted, h2v_rlc_timings *tm);
 // Host-buffer batches on a LANED workspace: as many in flight as the mode has lanes, on ONE workspace.  Every batch gets a
@@ -1790,8 +1854,8 @@ extern "C" int h2v_verify_batch_submit(const h2v_plan *p, const h2v_batch *b, h2
         if (ws->n_lanes) {
             rc = run_laned(p, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, ws->hs, rlc, seed, true);
         } else if (rlc) {
-            rc = run_rlc(p, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, ws->hs, seed,
-                         opts && (opts->flags & H2V_RLC_ONE_STREAM));
+            rc = run_rlc_or_routed(p, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, ws->hs, seed,
+                                   opts && (opts->flags & H2V_RLC_ONE_STREAM));
         } else {
             rc = run_pipeline(p->d, (uint32_t)b->n, ws->in_proofs, ws->in_off, ws->in_inst, ws->in_ci, ws->accept, nullptr, ws, ws->hs, nullptr, false);
         }
@@ -1960,6 +2024,8 @@ struct RlcWs {
     hipEvent_t ring[h2v_workspace::RING][NEV] = {};
     uint64_t calls = 0;
     uint32_t last_c = 0, last_W = 0, last_chain = 0, last_terms = 0;
+    bool last_routed = false;   // the most recent call on this (ordinary) workspace went straight to the per-proof kernels
+    uint8_t routed_ring[64] = {};
 };
 static void rlc_release(RlcWs *r) {
     void *ptrs[] = {r->r_scal, r->r_idx, r->l_scal, r->l_idx, r->vk_part, r->good, r->sums, r->misc, r->flags, r->grp.g_scal, r->grp.g_idx, r->grp.er_g,
@@ -2102,7 +2168,7 @@ static int rlc_groups_launch(RlcWs *r, const h2v_plan *p, h2v_workspace *w, uint
     hipLaunchKernelGGL(k_pip_wsum_many, dim3((2 * G * Wg * 4 + 63) / 64), dim3(64), 0, st, g.args_d, 2 * G, Wg, r->flags);
     hipLaunchKernelGGL(k_pip_horner_many, dim3(2 * G), dim3(64), 0, st, g.args_d, r->flags);
     hipLaunchKernelGGL(k_pairing_rlc_groups, dim3(G), dim3(64), COOP_LDS_BYTES(1), st, d1, g.pts_g, g.valid_g, g.er_g, g.el_g, g.status_g, g.accept_g, G, n,
-                       r->good, accept, r->flags);
+                       r->good, accept, r->flags, w->rlc_stats_ptr ? w->rlc_stats_ptr : w->rlc_stats);
     HIPCHK(hipGetLastError());
     return H2V_OK;
 }
@@ -2172,7 +2238,7 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     HIPCHK(hipMemsetAsync(valid1, 1, 1, pm));
     const uint32_t n_groups = (n + 63) / 64;
     hipLaunchKernelGGL(k_pairing_rlc, dim3(1), dim3(64), COOP_LDS_BYTES(1), pm, d1, r->misc, valid1, r->sums, r->sums + 36, st1, acc1, n, r->good, accept, skip,
-                       n_groups, w->rlc_fail_ptr);
+                       n_groups, w->rlc_fail_ptr, w->rlc_stats_ptr ? w->rlc_stats_ptr : w->rlc_stats, rlc_groups_on(n) ? 1u : 0u);
     HIPCHK(hipEventRecord(ev[9], pm));
     // fall-back, skipped on the device when the batch check passed.  Stage 1 finds the groups of 64 proofs that hold a failing
     // proof (everything else is final); stage 2 - window tables, per-proof MSM, per-proof pairing - decides inside those
@@ -2228,6 +2294,25 @@ static int rlc_check_batch(const h2v_plan *p, const h2v_batch *b, const uint8_t 
     if (b->n > (1ull << 22)) return fail(H2V_E_LIMIT, "RLC batches are limited to 2^22 proofs");
     return H2V_OK;
 }
+// an RLC call on an ORDINARY workspace: the batch check, or - routed - the per-proof pipeline (flags[0] = 0: "fell back")
+static int run_rlc_or_routed(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const uint64_t *off, const uint8_t *inst, const uint8_t *ci,
+                             uint8_t *accept, uint32_t *status_out, h2v_workspace *w, hipStream_t st, const uint32_t seed[8], bool one_stream_opt) {
+    int rc = rlc_stats_ensure(w);
+    if (rc) return rc;
+    if (rlc_route(w)) {
+        if ((rc = rlc_ensure(w, p))) return rc;
+        HIPCHK(hipMemsetAsync(w->rlc->flags, 0, 4, st));
+        w->rlc->routed_ring[w->rlc->calls % h2v_workspace::RING] = 1;   // (its event set stays unrecorded: h2v_workspace_rlc_result reports zeros)
+        w->rlc->calls++;
+        w->rlc->last_routed = true;
+        rc = run_routed(p, n, proofs, off, inst, ci, accept, status_out, w, st, w->rlc_stats);
+    } else {
+        rc = run_rlc(p, n, proofs, off, inst, ci, accept, status_out, w, st, seed, one_stream_opt);
+        if (rc == H2V_OK) { w->rlc->last_routed = false; w->rlc->routed_ring[(w->rlc->calls - 1) % h2v_workspace::RING] = 0; }
+    }
+    if (rc == H2V_OK) HIPCHK(hipMemcpyAsync(w->h_rlc_stats, w->rlc_stats, 8, hipMemcpyDeviceToHost, st));
+    return rc;
+}
 extern "C" int h2v_verify_batch_rlc_device(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, uint32_t *status, h2v_workspace *ws,
                                            void *stream, const h2v_rlc_opts *opts) {
     int rc = rlc_check_batch(p, b, accept);
@@ -2247,8 +2332,8 @@ extern "C" int h2v_verify_batch_rlc_device(const h2v_plan *p, const h2v_batch *b
     uint32_t seed[8];
     if ((rc = rlc_seed(opts, seed))) return rc;
     if (ws->n_lanes) return run_laned(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, true, seed, false);
-    return run_rlc(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, seed,
-                   opts && (opts->flags & H2V_RLC_ONE_STREAM));
+    return run_rlc_or_routed(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, seed,
+                             opts && (opts->flags & H2V_RLC_ONE_STREAM));
 }
 extern "C" int h2v_verify_batch_rlc(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, h2v_workspace *ws, const h2v_rlc_opts *opts,
                                     int *fell_back) {
@@ -2265,6 +2350,11 @@ extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, u
         if (w->calls == 0 || calls_back >= h2v_workspace::RING || calls_back >= w->calls) return fail(H2V_E_ARG, "no such call in the event ring");
         const int slot = (int)((w->calls - 1 - calls_back) % h2v_workspace::RING);
         if (!w->lring_rlc[slot]) return fail(H2V_E_ARG, "that call did not run in RLC mode");
+        if (w->lring_routed[slot]) {       // routed to the per-proof kernels: no batch check ran (h2v_workspace_timings has no record either)
+            if (batch_accepted) *batch_accepted = 0;
+            if (tm) memset(tm, 0, sizeof *tm);
+            return H2V_OK;
+        }
         if (batch_accepted) {
             uint32_t failed = 0;
             HIPCHK(hipMemcpy(&failed, w->rlc_fail + slot, 4, hipMemcpyDeviceToHost));
@@ -2301,6 +2391,7 @@ extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, u
         if (calls_back >= h2v_workspace::RING || calls_back >= r->calls) return fail(H2V_E_ARG, "no such call in the event ring");
         hipEvent_t *ev = r->ring[(r->calls - 1 - calls_back) % h2v_workspace::RING];
         memset(tm, 0, sizeof *tm);
+        if (r->routed_ring[(r->calls - 1 - calls_back) % h2v_workspace::RING]) return H2V_OK;   // routed: no batch check ran
         HIPCHK(hipEventSynchronize(ev[9]));
         HIPCHK(hipEventElapsedTime(&tm->g1_decompress_ms, ev[0], ev[1]));
         HIPCHK(hipEventElapsedTime(&tm->transcript_combiner_ms, ev[2], ev[3]));

@@ -749,10 +749,15 @@ extern "C" __global__ void __launch_bounds__(64, 2)
 k_pairing_rlc(H2vDevPlan plan, const uint32_t *__restrict__ pts1, const uint8_t *__restrict__ valid1, const uint32_t *__restrict__ er_jac,
               const uint32_t *__restrict__ el_jac, uint32_t *__restrict__ status1, uint8_t *__restrict__ accept1,
               uint32_t n_batch, const uint8_t *__restrict__ good, uint8_t *__restrict__ accept, uint32_t *__restrict__ flags,
-              uint32_t n_groups, uint32_t *__restrict__ fail_ctr) {
+              uint32_t n_groups, uint32_t *__restrict__ fail_ctr, uint32_t *__restrict__ stats /* [0] groups seen, [1] groups that failed (cumulative) or NULL */,
+              uint32_t groups_follow /* the group stage runs behind a failed check and counts by itself */) {
     bool ok = false;
     pairing_coop_body<true>(plan, 1u, pts1, valid1, nullptr, er_jac, el_jac, status1, accept1, nullptr, 0u, &ok);
     if (threadIdx.x == 0) flags[0] = ok ? 1u : 0u;
+    if (threadIdx.x == 0 && stats && (ok || !groups_follow)) {       // what the workspace routes its next calls by (h2v_capi.hip: rlc_route)
+        atomicAdd(stats, n_groups);
+        if (!ok) atomicAdd(stats + 1, n_groups);
+    }
     for (uint32_t g = threadIdx.x; g < n_groups; g += 64) flags[1 + g] = ok ? 1u : 0u;
     // (laned calls: one counter per call, shared by its chunks - how many batch checks of the call failed)
     if (threadIdx.x == 0 && !ok && fail_ctr) atomicAdd(fail_ctr, 1u);
@@ -767,12 +772,17 @@ k_pairing_rlc(H2vDevPlan plan, const uint32_t *__restrict__ pts1, const uint8_t 
 extern "C" __global__ void __launch_bounds__(64, 2)
 k_pairing_rlc_groups(H2vDevPlan plan, const uint32_t *__restrict__ pts_g, const uint8_t *__restrict__ valid_g, const uint32_t *__restrict__ er_g,
                      const uint32_t *__restrict__ el_g, uint32_t *__restrict__ status_g, uint8_t *__restrict__ accept_g, uint32_t n_groups,
-                     uint32_t n_batch, const uint8_t *__restrict__ good, uint8_t *__restrict__ accept, uint32_t *__restrict__ flags) {
+                     uint32_t n_batch, const uint8_t *__restrict__ good, uint8_t *__restrict__ accept, uint32_t *__restrict__ flags,
+                     uint32_t *__restrict__ stats) {
     if (flags[0]) return;
     const uint32_t g = blockIdx.x;
     bool ok = false;
     pairing_coop_body<true>(plan, n_groups, pts_g, valid_g, nullptr, er_g, el_g, status_g, accept_g, nullptr, g, &ok);
     if (threadIdx.x == 0) flags[1 + g] = ok ? 1u : 0u;
+    if (threadIdx.x == 0 && stats) {
+        atomicAdd(stats, 1u);
+        if (!ok) atomicAdd(stats + 1, 1u);
+    }
     if (ok) {
         const uint32_t i = g * 64 + threadIdx.x;
         if (i < n_batch) accept[i] = good[i];

@@ -135,6 +135,22 @@ k_build_tables(uint32_t n_points, const uint32_t *__restrict__ pts, const uint8_
     }
 }
 
+// A call that was routed to the per-proof kernels (h2v_capi.hip: rlc_route) still reports what the RLC mode would have met:
+// groups of 64 proofs seen, and groups holding a proof that only the pairing rejects (everything rejected earlier takes no
+// part in a combination).  One lane per group.
+extern "C" __global__ void __launch_bounds__(64)
+k_rlc_count_groups(uint32_t n, const uint32_t *__restrict__ status, uint32_t *__restrict__ stats) {
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x, n_groups = (n + 63) / 64;
+    uint32_t failed = 0;
+    if (g < n_groups)
+        for (uint32_t i = g * 64; i < n && i < g * 64 + 64; i++) failed |= (status[i] == H2V_ST_PAIRING) ? 1u : 0u;
+    const unsigned long long bal = __ballot(failed != 0), live = __ballot(g < n_groups);
+    if (threadIdx.x == 0) {
+        atomicAdd(stats, (uint32_t)__popcll(live));
+        atomicAdd(stats + 1, (uint32_t)__popcll(bal));
+    }
+}
+
 // Fall-back, stage 1 (after a failed batch check): the term list of every GROUP of 64 proofs - group g is block g of
 // k_rlc_prepare - for its own right-hand bucket MSM: the group's slice of the batch's per-proof terms, then the VK bases
 // with the group's own scalar sums (vk_part[g], still in Montgomery form).  stride = 64 n_var + n_fix terms per group.

@@ -133,6 +133,7 @@ def test_rlc_single_corruptions(be, circuits, name):
     n = 40
     good = synth.forge_batch(vk, td, n, seed=33, plan=pl, workers=1, ci_identity=(name == "sha256"))
     ws = be.Workspace(dp, n)
+    ws.set_option(be.OPT_RLC_ROUTE, -1)      # every call takes the batch check first, whatever the calls before it met
     n_pi = vk.n_public_inputs
     for kind in PRE_PAIRING + AT_PAIRING:
         rng = random.Random(sum(kind.encode()))
@@ -166,6 +167,7 @@ def test_rlc_mixed_batch_and_status(be, circuits):
     kinds = [k for k in synth.CORRUPTIONS if not k.startswith("acc_")]
     batch = synth.with_rejects(pl, batch, vk.n_public_inputs, fraction=0.4, seed=11, kinds=kinds)
     ws = be.Workspace(dp, n)
+    ws.set_option(be.OPT_RLC_ROUTE, -1)      # (the second call below must meet the batch check, not the routing)
     got, fell_back = dp.verify_batch_rlc(batch.proofs, batch.proof_off, batch.instances, batch.committed, ws=ws)
     want = ov.verify_batch(batch.proofs, batch.proof_off, batch.instances, batch.committed, threads=8)
     assert list(got) == list(want) == batch.expected
@@ -277,6 +279,60 @@ def test_rlc_two_batch_sizes_in_flight_on_one_workspace(be, circuits):
     for k, (acc, exp) in enumerate(outs):
         assert acc.cpu().tolist() == exp, k
     ws.close()
+
+
+@pytest.mark.parametrize("laned", [False, True])
+def test_rlc_calls_are_routed_by_the_observed_failing_group_rate(be, circuits, laned):
+    """include/h2v.h, ROUTING: batches in which most groups of 64 hold a pairing-only reject make the workspace send RLC calls
+    straight to the per-proof kernels (rlc_result: batch_accepted = 0 and no batch-check timings) from the second such call on;
+    a dozen clean batches bring it back to the batch check; every vector is the construction's throughout; with
+    H2V_OPT_RLC_ROUTE = -1 nothing is ever routed."""
+    import torch
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    n, n_pi = 1024, vk.n_public_inputs
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.frombuffer(bytearray(x), dtype=torch.uint8).to(dev)
+    good = synth.forge_batch(vk, td, n, seed=81, plan=pl, workers=8)
+    rng = random.Random(82)
+    proofs = [good.proof(i) for i in range(n)]
+    insts = [good.instances[32 * n_pi * i:32 * n_pi * (i + 1)] for i in range(n)]
+    exp_dirty = [1] * n
+    for i in rng.sample(range(n), 24):            # 24 rejects in 16 groups: most groups fail
+        proofs[i], insts[i] = synth.corrupt(pl, proofs[i], insts[i], "wrong_pi", rng)
+        exp_dirty[i] = 0
+    off = [0]
+    for p_ in proofs:
+        off.append(off[-1] + len(p_))
+    d_dirty = (up(b"".join(proofs)), torch.tensor(off, dtype=torch.int64).to(dev), up(b"".join(insts)))
+    d_clean = (up(good.proofs), torch.tensor(good.proof_off, dtype=torch.int64).to(dev), up(good.instances))
+    s = torch.cuda.Stream(device=dev)
+
+    def run(ws, d, want):
+        acc = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+        dp.verify_batch_rlc_device(n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), None, acc.data_ptr(), None, ws=ws, stream=s.cuda_stream, seed=bytes(range(32)))
+        s.synchronize()
+        torch.cuda.synchronize()
+        assert acc.cpu().tolist() == want
+        ok, tm = ws.rlc_result()
+        return ok, tm.total_ms
+
+    for route_off in (False, True):
+        ws = be.Workspace(dp, n, lanes=2, chunk=n) if laned else be.Workspace(dp, n)
+        if route_off:
+            ws.set_option(be.OPT_RLC_ROUTE, -1)
+        seen = [run(ws, d_dirty, exp_dirty) for _ in range(5)]
+        assert all(not ok for ok, _t in seen)
+        routed = [t == 0 for _ok, t in seen]
+        if route_off:
+            assert not any(routed)
+        else:
+            assert not routed[0] and routed[-1], routed                   # the estimate moves a quarter of the way per call
+        back = [run(ws, d_clean, [1] * n) for _ in range(14)]
+        assert back[-1][0] and back[-1][1] > 0, back                       # the batch check runs (and passes) again
+        if not route_off:
+            assert not back[0][0] and back[0][1] == 0                      # ... but the first clean call was still routed
+        ws.close()
 
 
 def test_rlc_duplicate_proofs_and_small_batches(be, circuits):
