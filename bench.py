@@ -580,7 +580,7 @@ def main():
                         timed_expected, ok_all, gather_state["ok"], reject_check, t_forge, PL)
         if args.mode == "rlc":
             result["config"]["rlc_steps_routed_to_the_per_proof_kernels"] = round(max(routed_state.values()), 3) if routed_state else 0.0
-        result["config"]["tuned_launch_shapes"] = tuned_state or None    # h2v_workspace_tune per plan (0 = the launcher's rule was not beaten by 1.5 %)
+        result["config"]["tuned_launch_shapes"] = tuned_state or None    # h2v_workspace_tune per plan (0 = the launcher's rule was not beaten by 3 %)
         if rlc_secondary is not None:
             result["rlc_mode"] = rlc_secondary
         if not args.no_cpu_baseline and world == 1:

@@ -169,7 +169,7 @@ int h2v_workspace_get_option(const h2v_workspace *ws, uint32_t option, int32_t *
  * many calls in flight as it has lanes for that size, an ordinary one call by call -, times the launcher's choice and its
  * neighbours (pairing engine, then MSM terms per lane: <= 7 configurations, about 40 calls in all), and leaves the fastest on
  * the workspace as H2V_OPT_PAIRING_ENGINE / H2V_OPT_MSM_TERMS_PER_LANE (0 = the launcher's rule stays: a candidate must be
- * 1.5 % faster to replace it).  Call it once per (plan, batch size, workspace) at start-up, on `stream` (not NULL for a laned
+ * 3 % faster to replace it).  Call it once per (plan, batch size, workspace) at start-up, on `stream` (not NULL for a laned
  * workspace); it returns when the measurements are done.  flags: 0.  Results of later calls do not depend on it. */
 typedef struct {
     uint32_t n_measured;          /* configurations timed */

@@ -1496,7 +1496,7 @@ extern "C" int h2v_verify_batch_device(const h2v_plan *p, const h2v_batch *b, ui
 // that size (deferred joins), an ordinary one call by call - because the shapes interact: the six-lane pairing engine is the
 // slowest engine alone and the fastest one in a full pipeline.  Coordinate descent over the two dimensions that matter per
 // call (pairing engine, MSM terms per lane): the launcher's own choice first, then each neighbouring engine, then each
-// terms-per-lane value with the best engine.  A candidate replaces the incumbent only if it is more than 1.5 % faster.
+// terms-per-lane value with the best engine.  A candidate replaces the incumbent only if it is more than 3 % faster.
 // accept[] goes to a scratch buffer: verdicts do not depend on shapes (tests/test_gpu_parity.py).
 extern "C" int h2v_workspace_tune(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws, void *stream, uint32_t flags, h2v_tune_report *rep) {
     if (!p || !b || !ws) return fail(H2V_E_ARG, "null argument");
@@ -1543,7 +1543,7 @@ extern "C" int h2v_workspace_tune(const h2v_plan *p, const h2v_batch *b, h2v_wor
         if (laned) ws->defer_joins = true;
         int r = round_of_calls(depth);                                  // fills the lanes (and creates them)
         if (r) return r;
-        const uint32_t calls = laned ? 2 * depth : 3;
+        const uint32_t calls = laned ? 3 * depth : 4;
         if (hipEventRecord(e0, st) != hipSuccess) return fail(H2V_E_DEVICE, "event record failed");
         if ((r = round_of_calls(calls))) return r;
         if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return fail(H2V_E_DEVICE, "tuning: the measured calls failed");
@@ -1564,14 +1564,14 @@ extern "C" int h2v_workspace_tune(const h2v_plan *p, const h2v_batch *b, h2v_wor
         for (int k = 0; k < n_eng && !rc; k++) {
             float t;
             if ((rc = measure(eng[k], 0, &t))) break;
-            if (t < best_ms * 0.985f) { best_ms = t; best_pair = eng[k]; }
+            if (t < best_ms * 0.97f) { best_ms = t; best_pair = eng[k]; }
         }
         if (rc) break;
         const bool ladders_share = !p->d.ivc && (double)m * p->d.n_main_terms / 64.0 >= S / 8.0;   // (k_g1_msm_multi's own preconditions)
         for (int32_t tpl = 2; tpl <= 4 && ladders_share && !rc; tpl++) {
             float t;
             if ((rc = measure(best_pair, tpl, &t))) break;
-            if (t < best_ms * 0.985f) { best_ms = t; best_tpl = tpl; }
+            if (t < best_ms * 0.97f) { best_ms = t; best_tpl = tpl; }
         }
     } while (0);
     ws->defer_joins = saved_defer;
