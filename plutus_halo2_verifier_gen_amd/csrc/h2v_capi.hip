@@ -1432,7 +1432,14 @@ static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const
             lw->in_flight_hint = call_hint;
             rc = run_pipeline(d, m, proofs, off + lo, inst_c, ci_c, accept + lo, status_out ? status_out + lo : nullptr, lw, ls, nullptr, false);
         }
-        if (rc) { (void)hipStreamSynchronize(ls); return rc; }
+        if (rc) {
+            // earlier chunks of this call (and of calls before it) are still in flight on other lanes: nothing of the caller's may
+            // be reused before they have drained, so an error return waits for every lane
+            const std::string e = g_err;
+            for (uint32_t q = 0; q < w->n_lanes; q++) if (w->lane_st[q]) (void)hipStreamSynchronize(w->lane_st[q]);
+            for (uint32_t q = 0; q < w->n_lanes; q++) w->lane_busy[q] = false;
+            return fail(rc, e);
+        }
         HIPCHK(hipEventRecord(w->lane_ev[l], ls));
         w->lane_busy[l] = true;
     }

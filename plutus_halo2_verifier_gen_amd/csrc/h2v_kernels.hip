@@ -962,6 +962,19 @@ template <bool COMPLETE>
 H2V_DN void msm_multi_ladder(G1J28 &out, bool &out_inf, const int8_t (&dg)[MSM_MAX_HALVES][33], const uint32_t *const (&tab)[MSM_MAX_HALVES], const int H) {
     G1J28 lad;
     bool lad_inf = true;
+    // The table entry of the NEXT addition slot is fetched one slot ahead (round 4): a slot's entry is a scattered 112-byte read
+    // out of a 73 MB table whose address hangs on a digit in private memory - two dependent round trips (~2 k cycles) in front of
+    // every 11-multiplication addition otherwise.  The first slot of the next window is fetched across the four doublings.
+    F28 nx, ny;
+    int nd;
+    auto fetch = [&](const int q, const int h) {
+        nd = dg[h][q];
+        const int e = nd < 0 ? -nd : nd;
+        const uint32_t *ent = tab[h] + (e ? e - 1 : 0) * 28;      // (a zero digit reads entry 0 and does not use it)
+#pragma unroll
+        for (int k = 0; k < 14; k++) { nx.l[k] = ent[k]; ny.l[k] = ent[14 + k]; }
+    };
+    fetch(32, 0);
 #pragma unroll 1
     for (int q = 32; q >= 0; q--) {
         if (q != 32 && !lad_inf) {
@@ -970,12 +983,11 @@ H2V_DN void msm_multi_ladder(G1J28 &out, bool &out_inf, const int8_t (&dg)[MSM_M
         }
 #pragma unroll 1
         for (int h = 0; h < H; h++) {
-            const int d = dg[h][q];
+            const F28 qx = nx, qy = ny;
+            const int d = nd;
+            if (h + 1 < H) fetch(q, h + 1);
+            else if (q > 0) fetch(q - 1, 0);
             if (d == 0) continue;
-            const uint32_t *ent = tab[h] + ((d < 0 ? -d : d) - 1) * 28;
-            F28 qx, qy;
-#pragma unroll
-            for (int k = 0; k < 14; k++) { qx.l[k] = ent[k]; qy.l[k] = ent[14 + k]; }
             if (lad_inf) {
                 lad.x = qx;
                 lad.y = qy;
