@@ -27,6 +27,7 @@ static uint32_t rd32(const std::vector<uint8_t> &b, size_t &o) {
 
 int main(int argc, char **argv) {
     if (argc != 3) { std::fprintf(stderr, "usage: %s plan.bin batch.bin\n", argv[0]); return 64; }
+    h2v::ShutdownGuard shutdown_last;   // h2v_shutdown(-1) after every other local is gone: the library's pool streams do not outlive main()
     try {
         std::vector<uint8_t> blob = slurp(argv[1]);
         const std::vector<uint8_t> bb = slurp(argv[2]);
