@@ -332,7 +332,9 @@ def main():
                 ws.hint_in_flight(args.hint)
         n_lanes = max(ws.lanes()[0] for ws in wss)
         in_flight = min(ws.depth(P.B, mode == "rlc") for ws, P in zip(wss, parts))
-        if mode == "per-proof" and not args.no_tune and not args.msm_tpl and not args.pairing and not any(hasattr(P, "tuned") for P in parts):
+        # (--timed-only: the profiled form launches warm-up + timed steps and nothing else - the tuner's candidate engines would show
+        #  up in the kernel statistics; profile_round.sh forces the shapes the untimed first run chose instead)
+        if mode == "per-proof" and not args.no_tune and not args.timed_only and not args.msm_tpl and not args.pairing and not any(hasattr(P, "tuned") for P in parts):
             # untimed: the library measures its candidate launch shapes on this very batch, in this very regime (all lanes busy)
             tuned_state.clear()
             for P, ws in zip(parts, wss):

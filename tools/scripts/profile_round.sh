@@ -31,7 +31,7 @@ import json
 t=json.load(open('$O/${TAG}_bench0.json'))['config'].get('tuned_launch_shapes') or []
 print(('--pairing %d --msm-tpl %d' % (t[0]['pairing_engine'], t[0]['msm_terms_per_lane'])) if len(t) == 1 and (t[0]['pairing_engine'] or t[0]['msm_terms_per_lane']) else '')")
 # 2. the timed steps under rocprofv3 (nothing but warm-up + timed steps)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py $ARGS --steps 60 --warmup 5 --timed-only --no-alone > $O/prof_$TAG.log 2>&1 || fail 2 $? $O/prof_$TAG.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py $ARGS $FORCE --steps 60 --warmup 5 --timed-only --no-alone > $O/prof_$TAG.log 2>&1 || fail 2 $? $O/prof_$TAG.log
 cp $O/prof_$TAG/*/*kernel_stats.csv $O/${TAG}_kernel_stats.csv
 # 3. one step at a time, same launch shapes: the kernels' own durations
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profa_$TAG -- python3 bench.py $ARGS --steps 20 --warmup 3 --timed-only --no-alone --pipeline streams --inflight 1 --hint $INF $FORCE > $O/profa_$TAG.log 2>&1 || fail 3 $? $O/profa_$TAG.log
