@@ -18,13 +18,17 @@
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) {
     g_err = msg;
+    if (code == H2V_E_DEVICE && msg.find("hip: ") == std::string::npos) {      // what the runtime said last on this thread, if anything
+        const hipError_t e = hipPeekAtLastError();
+        if (e != hipSuccess) g_err += std::string(" [hip: ") + hipGetErrorString(e) + "]";
+    }
     return code;
 }
 #define HIPCHK(expr)                                                                                     \
     do {                                                                                                 \
         hipError_t e_ = (expr);                                                                          \
         if (e_ != hipSuccess)                                                                            \
-            return fail(H2V_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+            return fail(H2V_E_DEVICE, std::string(#expr) + ": hip: " + hipGetErrorString(e_));                \
     } while (0)
 
 extern "C" const char *h2v_last_error(void) { return g_err.c_str(); }
@@ -1692,6 +1696,8 @@ static int host_stream(h2v_workspace *ws) {
     if (!ws->ev_host) HIPCHK(hipEventCreateWithFlags(&ws->ev_host, hipEventDisableTiming));
     return H2V_OK;
 }
+// bytes a host-buffer call's verdicts take in its pinned download block: accept[n], then the RLC verdict word at the next multiple of 8
+static inline size_t accept_extent(uint64_t n) { return (size_t)((n + 7) & ~(uint64_t)7) + 8; }
 // Packs the caller's host buffers into the pinned block and enqueues ONE upload on ws->hs.
 static int stage_inputs(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws) {
     const uint64_t n = b->n;
@@ -1713,11 +1719,15 @@ static int stage_inputs(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws
             return fail(H2V_E_DEVICE, "staging allocation failed");
         ws->in_block_cap = cap;
     }
-    if (n > ws->h_accept_cap) {
+    // (accept bytes, then - RLC mode - the verdict word at the next multiple of 8: the capacity is compared with THAT extent;
+    //  comparing it with n let a batch within 8 proofs of an earlier, smaller batch's slack put the word past the end of the
+    //  pinned block: hipMemcpyAsync "invalid argument", found by tools/soak.py)
+    if (accept_extent(n) > ws->h_accept_cap) {
         if (ws->h_accept) (void)hipHostFree(ws->h_accept);
         ws->h_accept = nullptr; ws->h_accept_cap = 0;
-        if (hipHostMalloc((void **)&ws->h_accept, n + n / 4 + 64, hipHostMallocDefault) != hipSuccess) return fail(H2V_E_DEVICE, "staging allocation failed");
-        ws->h_accept_cap = n + n / 4 + 64;
+        const size_t cap = accept_extent(n) + n / 4 + 64;
+        if (hipHostMalloc((void **)&ws->h_accept, cap, hipHostMallocDefault) != hipSuccess) return fail(H2V_E_DEVICE, "staging allocation failed");
+        ws->h_accept_cap = cap;
     }
     memcpy(ws->h_block + o_off, b->proof_off, (n + 1) * 8);
     if (p->d.n_pi) memcpy(ws->h_block + o_inst, b->instances, n * p->d.n_pi * 32);
@@ -1768,11 +1778,11 @@ static int submit_laned(const h2v_plan *p, const h2v_batch *b, h2v_workspace *ws
                 return fail(H2V_E_DEVICE, "staging allocation failed");
             sl.in_cap = cap;
         }
-        if (n > sl.acc_cap) {
+        if (accept_extent(n) > sl.acc_cap) {
             if (sl.h_accept) (void)hipHostFree(sl.h_accept);
             if (sl.d_accept) (void)hipFree(sl.d_accept);
             sl.h_accept = nullptr; sl.d_accept = nullptr; sl.acc_cap = 0;
-            const size_t cap = n + n / 4 + 64;     // (+ the verdict word behind the accept bytes)
+            const size_t cap = accept_extent(n) + n / 4 + 64;
             if (hipHostMalloc((void **)&sl.h_accept, cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&sl.d_accept, cap) != hipSuccess)
                 return fail(H2V_E_DEVICE, "staging allocation failed");
             sl.acc_cap = cap;

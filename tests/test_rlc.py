@@ -361,6 +361,38 @@ def test_rlc_duplicate_proofs_and_small_batches(be, circuits):
     assert list(got) == b2.expected and not fb
 
 
+def test_rlc_host_batches_growing_into_the_download_block_slack(be, circuits):
+    """A host-buffer RLC call downloads accept[n] and, at the next multiple of 8 behind it, the batch verdict word.  The pinned
+    block of a workspace grows with slack (n + n / 4 + 64): after a 100-proof call a 186-proof call still "fitted" by its accept
+    bytes alone and put the word past the end of the block (hipMemcpyAsync: invalid argument -> H2V_E_DEVICE; found by
+    tools/soak.py).  Ordinary workspace (h2v_verify_batch_rlc) and a one-lane submit / wait stream, every size around the
+    old block's end."""
+    from plutus_halo2_verifier_gen_amd import synth
+    vk, td, pl, dp, ov = circuits["simple_mul"]
+    pool = synth.forge_batch(vk, td, 200, seed=61, plan=pl, workers=4)
+    n_pi = vk.n_public_inputs
+
+    def first(m):
+        return pool.proofs[:pool.proof_off[m]], pool.proof_off[:m + 1], pool.instances[:32 * n_pi * m]
+
+    ws = be.Workspace(dp, 256)
+    bs = be.BatchStream(dp, 256, 1, rlc=True, seed=b"\x05" * 32)
+    keep = []
+    for m in [100] + list(range(180, 200)):          # 100 proofs: a block of 189 bytes
+        pr, off, ins = first(m)
+        got, fb = dp.verify_batch_rlc(pr, off, ins, None, ws=ws, seed=b"\x03" * 32)
+        assert list(got) == [1] * m and not fb, m
+        hb, k_ = dp.host_batch(pr, off, ins, None)
+        keep.append(k_)
+        out = bs.push(hb, m)
+        if out is not None:
+            assert list(out[0]) == [1] * len(out[0]) and not out[1]
+    for out in bs.drain():
+        assert list(out[0]) == [1] * len(out[0]) and not out[1]
+    bs.close()
+    ws.close()
+
+
 def test_rlc_full_size_batch(be, circuits):
     """BASELINE configs[1] size through the batch mode: 4096 accepting proofs -> one bucket MSM of 40 966 terms + one
     pairing; then with 1 % byte flips (the reference example's corruption): the flipped proofs, and only they, reject."""
