@@ -3,8 +3,11 @@
 batches of several circuits at once - random sizes (1 .. --max-n, ragged), random mixes of forged and corrupted proofs
 (every corruption kind of synth.CORRUPTIONS), through every calling form of include/h2v.h: host buffers with and without a
 caller-owned workspace, h2v_verify_batch_submit / _wait streams, device pointers on laned workspaces with deferred joins and
-several calls in flight, per-proof and RLC mode.  Every accept vector is compared with the construction (a forged proof
-accepts, a corrupted one rejects).  The plans are shared by the threads (h2v.h: "may be shared by threads, each with its
+several calls in flight, per-proof and RLC mode, and workspaces with randomly forced launch shapes (pairing engine, MSM terms
+per lane).  Every accept vector is compared with the construction (a forged proof accepts, a corrupted one rejects); the
+"fuzz" form mutates proofs at random (bit flips, random bytes, 48-byte windows spliced in from other proofs, encodings of
+the point at infinity, changed lengths) and takes the expected verdicts of the mutated proofs from the ORACLE (which is why
+this file lives under tests/).  The plans are shared by the threads (h2v.h: "may be shared by threads, each with its
 own workspace"); the pool of sixteen library streams is shared by all their laned workspaces.
 Exit code 0: every call agreed.  usage: soak.py [--minutes M] [--threads T] [--max-n N] [--seed S] [--circuits a,b] [--forms host,host_ws,host_laned,host_rlc,submit,device,device_rlc]"""
 import argparse
@@ -33,13 +36,16 @@ def main():
     ap.add_argument("--threads", type=int, default=3)
     ap.add_argument("--max-n", type=int, default=4096)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--circuits", default="simple_mul,lookup_table,atms_with_lookups,trashcan_mix,phased,secp256k1")
-    ap.add_argument("--forms", default="host,host_ws,host_laned,host_rlc,submit,device,device_rlc")
+    ap.add_argument("--circuits", default="simple_mul,lookup_table,atms_with_lookups,trashcan_mix,phased,secp256k1,ivc,sha256")
+    ap.add_argument("--forms", default="host,host_ws,host_laned,host_rlc,submit,device,device_rlc,fuzz")
     args = ap.parse_args()
+    import json
     import torch
     from plutus_halo2_verifier_gen_amd import backend, plan as PL, synth, vk as V
+    from oracle import binding as orc
     dev = torch.device("cuda", 0)
-    pools = {}
+    pools, oracles = {}, {}
+    oracle_lock = threading.Lock()
     t0 = time.time()
     for k, name in enumerate(args.circuits.split(",")):
         vk, td = V.BUILDERS[name]()
@@ -49,6 +55,7 @@ def main():
         b = synth.forge_batch(vk, td, m, seed=900 + k, plan=pl, workers=8)
         b = synth.with_rejects(pl, b, vk.n_public_inputs, fraction=0.12, seed=950 + k, kinds=list(synth.CORRUPTIONS))
         pools[name] = (vk, pl, dp, b)
+        oracles[name] = orc.OracleVK(orc.vk_desc(json.loads(vk.to_json()), vk.omega, vk.omega_inv, vk.barycentric_weight))
     print("pools forged in %.1f s: %s" % (time.time() - t0, {k: v[3].n for k, v in pools.items()}), flush=True)
     deadline = time.time() + 60.0 * args.minutes
     stats = {"calls": 0, "proofs": 0, "bad": 0}
@@ -76,8 +83,56 @@ def main():
                 w.defer_joins(True)
             else:           # the library's own choice of lanes and chunk
                 w = backend.Workspace(dp, cap)
+            if rng.random() < 0.5:      # a forced launch shape: the verdicts may not depend on it
+                w.set_option(backend.Workspace.OPT_PAIRING_ENGINE, rng.choice([0, 6, 12, 16, 32, 64]))
+                w.set_option(backend.Workspace.OPT_MSM_TERMS_PER_LANE, rng.choice([0, 1, 2, 3, 4]))
             wss[key] = w
             return w
+
+        def mutate(name, b):
+            """b with about 5 % of its proofs mutated at random; expected verdicts of those from the oracle"""
+            vk, pl, dp, pool = pools[name]
+            n_pi = vk.n_public_inputs
+            proofs = [bytearray(b.proof(i)) for i in range(b.n)]
+            inst = bytearray(b.instances)
+            ci = bytearray(b.committed) if b.committed else None
+            touched = sorted(rng.sample(range(b.n), max(1, b.n // 20)))
+            for i in touched:
+                kind = rng.choice(["bit", "bit", "byte", "splice", "infinity", "shorter", "longer", "instance", "committed"])
+                pr = proofs[i]
+                if kind == "instance" and n_pi:
+                    inst[32 * n_pi * i + rng.randrange(32 * n_pi)] ^= 1 << rng.randrange(8)
+                elif kind == "committed" and ci is not None:
+                    ci[48 * i + rng.randrange(48)] ^= 1 << rng.randrange(8)
+                elif kind == "byte":
+                    pr[rng.randrange(len(pr))] = rng.randrange(256)
+                elif kind == "splice":
+                    other = pool.proof(rng.randrange(pool.n))
+                    o = 48 * rng.randrange(max(1, min(len(pr), len(other)) // 48))
+                    pr[o:o + 48] = other[o:o + 48]
+                elif kind == "infinity":
+                    o = rng.choice(pl.points)
+                    pr[o:o + 48] = bytes([rng.choice([0xC0, 0xC0, 0xE0, 0x40])]) + bytes(47)
+                elif kind == "shorter":
+                    del pr[len(pr) - rng.randrange(1, 49):]
+                elif kind == "longer":
+                    pr.extend(rng.randrange(256) for _ in range(rng.randrange(1, 49)))
+                else:
+                    pr[rng.randrange(len(pr))] ^= 1 << rng.randrange(8)
+            off = [0]
+            for pr in proofs:
+                off.append(off[-1] + len(pr))
+            sub_off = [0]
+            for i in touched:
+                sub_off.append(sub_off[-1] + len(proofs[i]))
+            sub_inst = b"".join(bytes(inst[32 * n_pi * i:32 * n_pi * (i + 1)]) for i in touched)
+            sub_ci = None if ci is None else b"".join(bytes(ci[48 * i:48 * i + 48]) for i in touched)
+            with oracle_lock:
+                want = oracles[name].verify_batch(b"".join(bytes(proofs[i]) for i in touched), sub_off, sub_inst, sub_ci, threads=8)
+            exp = list(b.expected)
+            for i, v in zip(touched, want):
+                exp[i] = int(v)
+            return synth.Batch(n=b.n, proofs=b"".join(bytes(pr) for pr in proofs), proof_off=off, instances=bytes(inst), committed=bytes(ci) if ci is not None else None, expected=exp)
 
         def draw(name, cap=None):
             vk, pl, dp, pool = pools[name]
@@ -115,7 +170,13 @@ def main():
             vk, pl, dp, pool = pools[name]
             form = rng.choice(args.forms.split(","))
             try:
-                if form == "host":
+                if form == "fuzz":
+                    b = mutate(name, draw(name, cap=512))
+                    w = ws_for(name, rng.choice(["plain", "auto"]), b.n)
+                    report(form, name, b, dp.verify_batch(b.proofs, b.proof_off, b.instances, b.committed, ws=w), "per-proof")
+                    got, fb = dp.verify_batch_rlc(b.proofs, b.proof_off, b.instances, b.committed, ws=w, seed=bytes(rng.randrange(256) for _ in range(32)))
+                    report(form, name, b, got, "rlc fell_back=%s" % fb)
+                elif form == "host":
                     b = draw(name)
                     report(form, name, b, dp.verify_batch(b.proofs, b.proof_off, b.instances, b.committed))
                 elif form in ("host_ws", "host_laned"):

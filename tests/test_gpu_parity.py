@@ -904,6 +904,21 @@ def test_debug_sync_path_in_a_child_process(be):
     assert r.returncode == 0 and "modes ok" in r.stdout and "launching k_g1_msm" in r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_threads_sharing_plans_and_the_stream_pool(be):
+    """include/h2v.h: a plan "may be shared by threads (each with its own workspace)".  Three host threads for twenty seconds
+    through tests/soak.py (its own process: it ends with h2v_shutdown): random circuits, sizes, reject mixes and calling forms -
+    host buffers, submit / wait streams, device pointers with deferred joins, RLC, forced launch shapes, randomly mutated proofs
+    judged by the oracle - every accept vector as constructed.  (Minutes of the same on four threads: profiles/r04_soak_*.log;
+    it found the download-block overrun that test_rlc_host_batches_growing_into_the_download_block_slack pins.)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "soak.py"), "--minutes", "0.33", "--threads", "3", "--circuits", "simple_mul,lookup_table,ivc,trashcan_mix",
+                        "--max-n", "2048"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "every verdict as constructed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_tuned_shapes_are_measured_not_guessed(be, circuits):
     """h2v_workspace_tune: for the five BASELINE shapes at reduced sizes and two shapes no rule was calibrated on (T = 25 x 3000,
     T = 44 x 700), on laned workspaces with deferred joins: the tuner leaves a configuration whose measured time is at most the
