@@ -9,7 +9,7 @@ per lane).  Every accept vector is compared with the construction (a forged proo
 the point at infinity, changed lengths) and takes the expected verdicts of the mutated proofs from the ORACLE (which is why
 this file lives under tests/).  The plans are shared by the threads (h2v.h: "may be shared by threads, each with its
 own workspace"); the pool of sixteen library streams is shared by all their laned workspaces.
-Exit code 0: every call agreed.  usage: soak.py [--minutes M] [--threads T] [--max-n N] [--seed S] [--circuits a,b] [--forms host,host_ws,host_laned,host_rlc,submit,device,device_rlc]"""
+Exit code 0: every call agreed.  usage: soak.py [--minutes M] [--threads T] [--max-n N] [--seed S] [--circuits a,b] [--forms host,host_ws,host_laned,host_rlc,submit,device,device_rlc,fuzz,churn]"""
 import argparse
 import os
 import random
@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--max-n", type=int, default=4096)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--circuits", default="simple_mul,lookup_table,atms_with_lookups,trashcan_mix,phased,secp256k1,ivc,sha256")
-    ap.add_argument("--forms", default="host,host_ws,host_laned,host_rlc,submit,device,device_rlc,fuzz")
+    ap.add_argument("--forms", default="host,host_ws,host_laned,host_rlc,submit,device,device_rlc,fuzz,churn")
     args = ap.parse_args()
     import json
     import torch
@@ -170,7 +170,17 @@ def main():
             vk, pl, dp, pool = pools[name]
             form = rng.choice(args.forms.split(","))
             try:
-                if form == "fuzz":
+                if form == "churn":                     # a plan and a workspace that live for one call (the registry under concurrency)
+                    b = draw(name, cap=300)
+                    dp2 = backend.DevicePlan(pl.to_bytes(), 0, fixed_base_window_bits=rng.choice([0, 0, 4, 8, 12]))
+                    w2 = backend.Workspace(dp2, b.n) if rng.random() < 0.5 else backend.Workspace(dp2, b.n, lanes=rng.choice([1, 2, 5]), chunk=max(1, b.n // 3))
+                    if rng.random() < 0.5:
+                        report(form, name, b, dp2.verify_batch(b.proofs, b.proof_off, b.instances, b.committed, ws=w2))
+                    else:
+                        report(form, name, b, dp2.verify_batch_rlc(b.proofs, b.proof_off, b.instances, b.committed, ws=w2)[0], "rlc")
+                    w2.close()
+                    dp2.close()
+                elif form == "fuzz":
                     b = mutate(name, draw(name, cap=512))
                     w = ws_for(name, rng.choice(["plain", "auto"]), b.n)
                     report(form, name, b, dp.verify_batch(b.proofs, b.proof_off, b.instances, b.committed, ws=w), "per-proof")
