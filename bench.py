@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--msm-tpl", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="per-proof MSM: terms per lane (h2v_workspace_set_option; 2 .. 4 share the doublings of a lane's terms)")
     ap.add_argument("--pairing", type=int, default=0, choices=[0, 1, 6, 12, 16, 32, 64], help="pairing engine: lanes per proof (h2v_workspace_set_option; 0: the launcher's choice)")
+    ap.add_argument("--shared-workspace", action="store_true", help="mixed workloads, --pipeline lanes: ONE laned workspace for all the parts' plans (h2v_workspace_create_multi) instead of one per plan")
     ap.add_argument("--no-tune", action="store_true", help="skip h2v_workspace_tune (the untimed measurement of the candidate launch shapes on this batch before the "
                                                          "warm-up steps); the launcher's own thresholds then decide")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -324,7 +325,12 @@ def main():
     def lanes_run(mode, steps, warmup, gather, lanes=None):
         """--pipeline lanes: every step is one call per part on that part's ONE laned workspace; joins are deferred, so the
         library keeps as many steps in flight as it has lanes.  One workspace per plan, one caller stream."""
-        wss = [backend.Workspace(P.dp, P.B, lanes=args.lanes if lanes is None else lanes, chunk=0) for P in parts]
+        shared = args.shared_workspace and len(parts) > 1
+        if shared:
+            one = backend.Workspace.multi([P.dp for P in parts], max(P.B for P in parts), lanes=args.lanes if lanes is None else lanes, chunk=0)
+            wss = [one] * len(parts)
+        else:
+            wss = [backend.Workspace(P.dp, P.B, lanes=args.lanes if lanes is None else lanes, chunk=0) for P in parts]
         for ws, P in zip(wss, parts):
             ws.defer_joins(True)
             apply_options(ws, P)
@@ -356,7 +362,7 @@ def main():
 
         for k in range(max(warmup, n_lanes)):   # untimed; at least one step on every lane (a lane's first use creates it)
             step(k)
-        for ws in wss:
+        for ws in set(wss):
             ws.join(cs)
         if world > 1:
             dist.barrier()
@@ -364,7 +370,7 @@ def main():
         t0 = time.perf_counter()
         for k in range(steps):
             step(k)
-        for ws in wss:
+        for ws in set(wss):
             ws.join(cs)
         recv = None
         if gather and world > 1:
@@ -376,9 +382,11 @@ def main():
         ok = all(expected_ok(d_accepts[(steps - 1 - j) % RING].cpu().numpy()) for j in range(min(steps, RING)))
 
         def close():
-            for ws in wss:
+            for ws in set(wss):
                 ws.close()
-        return Run(el, d_accepts[(steps - 1) % RING].cpu().numpy(), lambda j, p: wss[p].timings(j), lambda j, p: wss[p].rlc_result(calls_back=j), close, in_flight, ok)
+        nP = len(parts)
+        back = (lambda j, p: j * nP + (nP - 1 - p)) if shared else (lambda j, p: j)     # (a shared workspace sees the parts' calls interleaved)
+        return Run(el, d_accepts[(steps - 1) % RING].cpu().numpy(), lambda j, p: wss[p].timings(back(j, p)), lambda j, p: wss[p].rlc_result(calls_back=back(j, p)), close, in_flight, ok)
 
     def streams_run(mode, inflight, steps, warmup, gather, sync_every_step=False):
         """--pipeline streams (round 2): `inflight` workspaces per part on `inflight` torch streams, driven from here"""
@@ -513,7 +521,7 @@ def main():
         run = lanes_run(args.mode, args.steps, args.warmup, not args.no_gather)
         inflight = run.in_flight
     elapsed, accept = run.el, run.accept
-    k_steps = min(args.steps, 48)
+    k_steps = min(args.steps, 48 if not (args.shared_workspace and len(parts) > 1) else 48 // len(parts))   # (the library's event ring holds 64 calls per workspace)
     per_part = [kernel_times(run, args.mode, k_steps, p) for p in range(len(parts))]   # [(kernel_ms overlapped, latency, shape)]
     steps_ok = run.all_steps_ok
     run.close()
@@ -582,6 +590,8 @@ def main():
                         timed_expected, ok_all, gather_state["ok"], reject_check, t_forge, PL)
         if args.mode == "rlc":
             result["config"]["rlc_steps_routed_to_the_per_proof_kernels"] = round(max(routed_state.values()), 3) if routed_state else 0.0
+        if len(parts) > 1 and args.pipeline == "lanes":
+            result["config"]["workspaces"] = "one laned workspace for all plans (h2v_workspace_create_multi)" if args.shared_workspace else "one laned workspace per plan"
         result["config"]["tuned_launch_shapes"] = tuned_state or None    # h2v_workspace_tune per plan (0 = the launcher's rule was not beaten by 3 %)
         if rlc_secondary is not None:
             result["rlc_mode"] = rlc_secondary

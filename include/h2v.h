@@ -126,6 +126,16 @@ void h2v_workspace_free(h2v_workspace *ws);
  *   most host batches h2v_verify_batch_submit keeps in flight on one workspace (h2v::BatchStream / backend.BatchStream: depth
  *   <= 16).  A laned workspace has no trace buffer (h2v_trace creates its own). */
 int h2v_workspace_create_lanes(const h2v_plan *plan, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk, h2v_workspace **out);
+/* One laned workspace for SEVERAL plans of one device - a node that verifies proofs of several circuits (BASELINE configs[2]: a
+ * mixed batch of two circuits).  The lanes are sized for the largest of every dimension of the listed plans (a workspace
+ * accepts any plan whose dimensions fit its buffers), so the calls of all of them - each names its plan as usual - go round
+ * robin through ONE set of lanes and streams; with one laned workspace per plan the lanes of the two share the pool's sixteen
+ * streams pairwise.  chunk = 0: the smallest of the plans' own chunks.  Everything else as h2v_workspace_create_lanes; options
+ * (h2v_workspace_set_option, h2v_workspace_tune) hold for the workspace, i.e. for every plan on it.  The RLC mode keeps one set
+ * of its buffers per plan shape on such a workspace (up to eight).  The reference has no counterpart: its verifier objects
+ * are per proof (src/lib.rs:9-15) and a mixed batch is a Vec of (vk, proof) pairs. */
+int h2v_workspace_create_multi(const h2v_plan *const *plans, uint32_t n_plans, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk,
+                               h2v_workspace **out);
 /* Deferred joins (laned workspaces): with defer = 1 a device-resident verify call returns without making the caller's stream
  * wait for its chunks, so the chunks of CONSECUTIVE calls overlap in the lanes - one workspace then does what five
  * workspaces on five streams did (a stream of batches: DESIGN.md section 6).  The inputs of a call must stay untouched, and

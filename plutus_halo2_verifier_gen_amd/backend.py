@@ -76,7 +76,7 @@ def _rlc_opts(seed, one_stream: bool = False):
 
 EXPORTS = [
     "h2v_plan_load", "h2v_plan_load_ex", "h2v_plan_free", "h2v_plan_info", "h2v_plan_compile", "h2v_blob_free", "h2v_workspace_create", "h2v_workspace_free",
-    "h2v_workspace_timings", "h2v_workspace_hint_in_flight", "h2v_workspace_create_lanes", "h2v_workspace_defer_joins",
+    "h2v_workspace_timings", "h2v_workspace_hint_in_flight", "h2v_workspace_create_lanes", "h2v_workspace_create_multi", "h2v_workspace_defer_joins",
     "h2v_workspace_join", "h2v_workspace_lanes", "h2v_workspace_depth", "h2v_workspace_set_option", "h2v_workspace_get_option", "h2v_workspace_tune", "h2v_probe_set_option",
     "h2v_verify_batch", "h2v_verify_batch_submit", "h2v_verify_batch_wait", "h2v_verify_batch_device", "h2v_verify_batch_rlc", "h2v_verify_batch_rlc_device",
     "h2v_workspace_rlc_result", "h2v_probe_g1_msm_pippenger", "h2v_plan_trace_slots", "h2v_trace", "h2v_probe_field",
@@ -115,6 +115,7 @@ def lib():
         L.h2v_workspace_create.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         L.h2v_workspace_free.argtypes = [C.c_void_p]
         L.h2v_workspace_create_lanes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.h2v_workspace_create_multi.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         L.h2v_workspace_defer_joins.argtypes = [C.c_void_p, C.c_int]
         L.h2v_workspace_join.argtypes = [C.c_void_p, C.c_void_p]
         L.h2v_workspace_lanes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -319,6 +320,16 @@ class Workspace:
         else:
             check(lib().h2v_workspace_create_lanes(plan.handle, max_batch, lanes or 0, chunk or 0, C.byref(self._h)))
         self.max_batch = max_batch
+
+    @classmethod
+    def multi(cls, plans, max_batch: int, lanes: int = 0, chunk: int = 0) -> "Workspace":
+        """h2v_workspace_create_multi: ONE laned workspace for several plans of one device (calls name their plan as usual)"""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        arr = (C.c_void_p * len(plans))(*[p.handle for p in plans])
+        check(lib().h2v_workspace_create_multi(arr, len(plans), max_batch, lanes, chunk, C.byref(self._h)))
+        self.max_batch = max_batch
+        return self
 
     def lanes(self):
         """(number of lanes, chunk size); (1, max_batch) for a workspace that is not laned"""

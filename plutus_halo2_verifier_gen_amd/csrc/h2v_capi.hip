@@ -154,6 +154,7 @@ struct h2v_workspace {
     uint8_t ring_pipes[RING] = {}, ring_split[RING] = {}, ring_lpt[RING] = {}, ring_pair[RING] = {}, ring_var[RING] = {};
     uint64_t calls = 0;
     struct RlcWs *rlc = nullptr;   // buffers of the RLC batch mode, created by its first call
+    std::vector<struct RlcWs *> rlc_parked;   // the same for OTHER plans this workspace has served in that mode (rlc_ensure swaps; never freed before the workspace)
     int32_t opt[H2V_OPT_COUNT] = {};   // h2v_workspace_set_option / h2v_workspace_tune: 0 = the launcher's choice
     int one_stream_mode = -1;      // lanes: 1 = the whole pipeline on the stream it is given (-1: decided from the hint)
     // ---- lanes (h2v_workspace_create_lanes): a laned workspace owns no kernel buffers of its own, only n_lanes ordinary
@@ -196,6 +197,7 @@ struct h2v_workspace {
     // what h2v_workspace_timings / _rlc_result need to find the chunks' event sets in the lanes' own rings
     uint32_t lring_chunks[RING] = {}, lring_first[RING] = {}, lring_mod[RING] = {};
     uint64_t lring_calls[RING][MAXL] = {}, lring_rlc_calls[RING][MAXL] = {};
+    const struct RlcWs *lring_rlc_obj[RING][MAXL] = {};   // (whose counter lring_rlc_calls holds: a lane serves one plan's RLC buffers at a time)
     uint8_t lring_rlc[RING] = {};
 };
 
@@ -499,6 +501,8 @@ static void ws_release(h2v_workspace *w) {
     }
     w->n_lanes = 0;
     if (w->rlc) { rlc_release(w->rlc); w->rlc = nullptr; }
+    for (struct RlcWs *r : w->rlc_parked) rlc_release(r);
+    w->rlc_parked.clear();
     if (w->h_rlc_stats) (void)hipHostFree(w->h_rlc_stats);
     void *ptrs[] = {w->rlc_stats, w->rlc_fail, w->regs, w->scalars, w->pts, w->er, w->status, w->trace, w->valid, w->valid_sub, w->er_fix, w->dec_ctr, w->accept, w->in_block, w->msm_tab,
                     w->accl, w->accr, w->fold_pts, w->fold_scal, w->el2, w->er2, w->pt_tab};
@@ -603,18 +607,15 @@ static int ensure_lane(h2v_workspace *w, uint32_t l) {
     w->lane[l] = lw;
     return H2V_OK;
 }
-extern "C" int h2v_workspace_create_lanes(const h2v_plan *p, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk, h2v_workspace **out) {
-    if (!p || !out) return fail(H2V_E_ARG, "null argument");
+static int create_lanes_for(const H2vDevPlan &d, int device, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk, h2v_workspace **out) {
     if (max_batch == 0 || max_batch > (1ull << 24)) return fail(H2V_E_ARG, "max_batch out of range");
     if (n_lanes > (uint32_t)h2v_workspace::MAXL) return fail(H2V_E_ARG, "at most 16 lanes");
-    ALIVE(p);
-    if (chunk == 0) chunk = default_chunk(p->d);
+    if (chunk == 0) chunk = default_chunk(d);
     if ((uint64_t)chunk > max_batch) chunk = (uint32_t)max_batch;
-    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipSetDevice(device));
     h2v_workspace *w = new h2v_workspace();
-    w->device = p->device; w->cap = max_batch; w->chunk = chunk;
+    w->device = device; w->cap = max_batch; w->chunk = chunk;
     w->stride = (uint32_t)((max_batch + 63) / 64 * 64);
-    const H2vDevPlan &d = p->d;
     w->lane_plan = d;
     w->sz_terms = d.n_terms; w->sz_slots = (uint32_t)H2V_SLOTS(d); w->sz_regs = vm_lds_slots(d) == 0 ? d.n_regs : 0; w->sz_trace = 0; w->sz_ivc = d.ivc != 0; w->sz_fix = d.fix_tab != nullptr;
     w->lanes_per_proof = n_lanes ? n_lanes : H2V_PER_PROOF_LANES;     // an explicit lane count holds for both modes
@@ -628,6 +629,43 @@ extern "C" int h2v_workspace_create_lanes(const h2v_plan *p, uint64_t max_batch,
     reg_add(g_ws_live, w);
     *out = w;
     return H2V_OK;
+}
+extern "C" int h2v_workspace_create_lanes(const h2v_plan *p, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk, h2v_workspace **out) {
+    if (!p || !out) return fail(H2V_E_ARG, "null argument");
+    ALIVE(p);
+    return create_lanes_for(p->d, p->device, max_batch, n_lanes, chunk, out);
+}
+// One set of lanes for SEVERAL plans of one device (a node that verifies proofs of several circuits; BASELINE configs[2] names a
+// mixed batch): the lane workspaces are sized for the largest of every dimension - MSM terms, point slots, the combiner's
+// global register file where a plan needs one, the recursion and fixed-base buffers where a plan has them - so every listed plan
+// passes ws_fits, and the calls of all of them go round robin through the SAME lanes and streams.  (One laned workspace per plan
+// also works, but their lanes share the pool's sixteen streams pairwise: two plans x 2048 proofs, 6.70 ms per step on two
+// workspaces.)  The shape below is a synthetic H2vDevPlan that only ws_create_for / default_chunk / laned_depth ever read.
+extern "C" int h2v_workspace_create_multi(const h2v_plan *const *plans, uint32_t n_plans, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk, h2v_workspace **out) {
+    if (!plans || !out || n_plans == 0) return fail(H2V_E_ARG, "null argument");
+    for (uint32_t k = 0; k < n_plans; k++) {
+        if (!plans[k]) return fail(H2V_E_ARG, "null plan");
+        ALIVE(plans[k]);
+        if (plans[k]->device != plans[0]->device) return fail(H2V_E_ARG, "the plans of one workspace must live on one device");
+    }
+    H2vDevPlan u = plans[0]->d;
+    uint32_t slots = 0, regs_global = 0, chunk_min = 0;
+    for (uint32_t k = 0; k < n_plans; k++) {
+        const H2vDevPlan &d = plans[k]->d;
+        u.n_terms = d.n_terms > u.n_terms ? d.n_terms : u.n_terms;
+        u.n_main_terms = d.n_main_terms > u.n_main_terms ? d.n_main_terms : u.n_main_terms;
+        slots = (uint32_t)H2V_SLOTS(d) > slots ? (uint32_t)H2V_SLOTS(d) : slots;
+        if (vm_lds_slots(d) == 0 && d.n_regs > regs_global) regs_global = d.n_regs;
+        if (d.ivc) u.ivc = d.ivc;
+        if (d.fix_tab) u.fix_tab = d.fix_tab;
+        const uint32_t c = default_chunk(d);
+        chunk_min = chunk_min == 0 || c < chunk_min ? c : chunk_min;
+    }
+    u.n_ci = 0;
+    u.n_points = slots - 2u * (u.ivc ? 1u : 0u);                  // H2V_SLOTS(u) == the largest plan's
+    if (regs_global) { u.vm_lanes = 1; u.n_regs = regs_global; }   // vm_lds_slots(u) == 0: a global register file of that size
+    else if (vm_lds_slots(u) == 0) return fail(H2V_E_ARG, "internal: union shape");
+    return create_lanes_for(u, plans[0]->device, max_batch, n_lanes, chunk ? chunk : chunk_min, out);
 }
 extern "C" int h2v_workspace_create(const h2v_plan *p, uint64_t max_batch, h2v_workspace **out) {
     if (!p || !out) return fail(H2V_E_ARG, "null argument");
@@ -1450,6 +1488,7 @@ static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const
     for (uint32_t l = 0; l < w->n_lanes; l++) {
         w->lring_calls[slot][l] = w->lane[l] ? w->lane[l]->calls : 0;
         w->lring_rlc_calls[slot][l] = w->lane[l] ? rlc_calls_of(w->lane[l]) : 0;
+        w->lring_rlc_obj[slot][l] = w->lane[l] ? w->lane[l]->rlc : nullptr;
     }
     if (never_join) return H2V_OK;
     if (!w->defer_joins || force_join) return lanes_join(w, st);
@@ -2040,6 +2079,7 @@ struct RlcWs {
     static constexpr int NEV = 11;
     hipEvent_t ring[h2v_workspace::RING][NEV] = {};
     uint64_t calls = 0;
+    uint64_t run_len = 0;       // calls since these buffers last became the workspace's current ones (rlc_ensure)
     uint32_t last_c = 0, last_W = 0, last_chain = 0, last_terms = 0;
     bool last_routed = false;   // the most recent call on this (ordinary) workspace went straight to the per-proof kernels
     uint8_t routed_ring[64] = {};
@@ -2053,9 +2093,26 @@ static void rlc_release(RlcWs *r) {
     for (auto &set : r->ring) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
     delete r;
 }
+// One set of buffers per plan SHAPE (n_var, n_fix) the workspace has served: a workspace that alternates between plans (ws_fits
+// allows any plan that fits; h2v_workspace_create_multi is made for it) swaps between parked sets instead of freeing and
+// re-allocating at every switch - hipFree waits for the whole device.  At most eight shapes are kept.
 static int rlc_ensure(h2v_workspace *w, const h2v_plan *p) {
     if (w->rlc && w->rlc->n_var == p->n_var && w->rlc->n_fix == p->n_fix) return H2V_OK;
-    if (w->rlc) { rlc_release(w->rlc); w->rlc = nullptr; }
+    for (size_t k = 0; k < w->rlc_parked.size(); k++) {
+        RlcWs *q = w->rlc_parked[k];
+        if (q->n_var == p->n_var && q->n_fix == p->n_fix) {
+            w->rlc_parked[k] = w->rlc;
+            if (!w->rlc_parked[k]) w->rlc_parked.erase(w->rlc_parked.begin() + (long)k);
+            w->rlc = q;
+            q->run_len = 0;
+            return H2V_OK;
+        }
+    }
+    if (w->rlc) {
+        if (w->rlc_parked.size() >= 8) { rlc_release(w->rlc_parked.front()); w->rlc_parked.erase(w->rlc_parked.begin()); }
+        w->rlc_parked.push_back(w->rlc);
+        w->rlc = nullptr;
+    }
     RlcWs *r = new RlcWs();
     r->cap = w->cap; r->n_var = p->n_var; r->n_fix = p->n_fix;
     const size_t nr = (size_t)w->cap * p->n_var + p->n_fix, blocks = (w->cap + 63) / 64;
@@ -2203,6 +2260,7 @@ static int run_rlc(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const u
     const uint32_t slots = H2V_SLOTS(d);
     hipEvent_t *ev = r->ring[r->calls % h2v_workspace::RING];
     r->calls++;
+    r->run_len++;
     // two streams per batch: the caller's (transcript + combiner, then everything else) and one for the decompression
     // one_stream (h2v_rlc_opts.flags & H2V_RLC_ONE_STREAM, or H2V_OPT_STREAMS = 1): everything on
     // the caller's stream, decompression before the combiner - one stream per batch in flight instead of two
@@ -2321,6 +2379,7 @@ static int run_rlc_or_routed(const h2v_plan *p, uint32_t n, const uint8_t *proof
         HIPCHK(hipMemsetAsync(w->rlc->flags, 0, 4, st));
         w->rlc->routed_ring[w->rlc->calls % h2v_workspace::RING] = 1;   // (its event set stays unrecorded: h2v_workspace_rlc_result reports zeros)
         w->rlc->calls++;
+        w->rlc->run_len++;
         w->rlc->last_routed = true;
         rc = run_routed(p, n, proofs, off, inst, ci, accept, status_out, w, st, w->rlc_stats);
     } else {
@@ -2360,6 +2419,7 @@ extern "C" int h2v_verify_batch_rlc(const h2v_plan *p, const h2v_batch *b, uint8
 }
 // After the stream of an RLC call has been synchronised: did the batch check pass (1) or did the per-proof kernels run (0)?
 // kernel times of a past call (calls_back = 0: the most recent).
+static int rlc_timings_of(const RlcWs *r, uint32_t calls_back, h2v_rlc_timings *tm);
 extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, uint32_t *batch_accepted, h2v_rlc_timings *tm) {
     ALIVE(w);
     if (w && w->n_lanes) {
@@ -2384,15 +2444,19 @@ extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, u
             uint32_t l; uint64_t idx;
             laned_chunk_pos(w, slot, c, true, &l, &idx);
             h2v_workspace *lw = w->lane[l];
-            if (!lw->rlc || lw->rlc->calls - 1 - idx >= (uint64_t)h2v_workspace::RING) return fail(H2V_E_ARG, "the lanes' event rings have wrapped since that call");
+            // the buffers (and event ring) the chunk ran on: the lane's current ones, or parked since by another plan's call
+            const RlcWs *r1 = w->lring_rlc_obj[slot][l];
+            bool alive = r1 && lw->rlc == r1;
+            for (const RlcWs *q : lw->rlc_parked) alive = alive || (r1 && q == r1);
+            if (!alive || r1->calls - 1 - idx >= (uint64_t)h2v_workspace::RING) return fail(H2V_E_ARG, "the lanes' event rings have wrapped since that call");
             h2v_rlc_timings t1;
-            int rc = h2v_workspace_rlc_result(lw, (uint32_t)(lw->rlc->calls - 1 - idx), nullptr, &t1);
+            int rc = rlc_timings_of(r1, (uint32_t)(r1->calls - 1 - idx), &t1);
             if (rc) return rc;
             tm->transcript_combiner_ms += t1.transcript_combiner_ms; tm->g1_decompress_ms += t1.g1_decompress_ms; tm->prepare_ms += t1.prepare_ms;
             tm->bucket_sort_ms += t1.bucket_sort_ms; tm->bucket_accumulate_ms += t1.bucket_accumulate_ms; tm->bucket_reduce_ms += t1.bucket_reduce_ms;
             tm->pairing_ms += t1.pairing_ms;
             tm->msm_terms = t1.msm_terms; tm->window_bits = t1.window_bits; tm->windows = t1.windows; tm->max_chain = t1.max_chain;
-            hipEvent_t *ev = lw->rlc->ring[idx % h2v_workspace::RING];
+            const hipEvent_t *ev = r1->ring[idx % h2v_workspace::RING];
             if (!first) first = ev[0];
             float span = 0;
             HIPCHK(hipEventElapsedTime(&span, first, ev[9]));
@@ -2403,10 +2467,14 @@ extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, u
     if (!w || !w->rlc || w->rlc->calls == 0) return fail(H2V_E_ARG, "no RLC call was made with this workspace");
     RlcWs *r = w->rlc;
     HIPCHK(hipSetDevice(w->device));
+    if (calls_back >= r->run_len) return fail(H2V_E_ARG, "an RLC call of another plan has used this workspace since that call");
     if (batch_accepted) HIPCHK(hipMemcpy(batch_accepted, r->flags, 4, hipMemcpyDeviceToHost));
-    if (tm) {
+    return tm ? rlc_timings_of(r, calls_back, tm) : H2V_OK;
+}
+static int rlc_timings_of(const RlcWs *r, uint32_t calls_back, h2v_rlc_timings *tm) {
+    {
         if (calls_back >= h2v_workspace::RING || calls_back >= r->calls) return fail(H2V_E_ARG, "no such call in the event ring");
-        hipEvent_t *ev = r->ring[(r->calls - 1 - calls_back) % h2v_workspace::RING];
+        const hipEvent_t *ev = r->ring[(r->calls - 1 - calls_back) % h2v_workspace::RING];
         memset(tm, 0, sizeof *tm);
         if (r->routed_ring[(r->calls - 1 - calls_back) % h2v_workspace::RING]) return H2V_OK;   // routed: no batch check ran
         HIPCHK(hipEventSynchronize(ev[9]));

@@ -9,7 +9,7 @@ per lane).  Every accept vector is compared with the construction (a forged proo
 the point at infinity, changed lengths) and takes the expected verdicts of the mutated proofs from the ORACLE (which is why
 this file lives under tests/).  The plans are shared by the threads (h2v.h: "may be shared by threads, each with its
 own workspace"); the pool of sixteen library streams is shared by all their laned workspaces.
-Exit code 0: every call agreed.  usage: soak.py [--minutes M] [--threads T] [--max-n N] [--seed S] [--circuits a,b] [--forms host,host_ws,host_laned,host_rlc,submit,device,device_rlc,fuzz,churn]"""
+Exit code 0: every call agreed.  usage: soak.py [--minutes M] [--threads T] [--max-n N] [--seed S] [--circuits a,b] [--forms host,host_ws,host_laned,host_rlc,submit,device,device_rlc,fuzz,churn,multi]"""
 import argparse
 import os
 import random
@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--max-n", type=int, default=4096)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--circuits", default="simple_mul,lookup_table,atms_with_lookups,trashcan_mix,phased,secp256k1,ivc,sha256")
-    ap.add_argument("--forms", default="host,host_ws,host_laned,host_rlc,submit,device,device_rlc,fuzz,churn")
+    ap.add_argument("--forms", default="host,host_ws,host_laned,host_rlc,submit,device,device_rlc,fuzz,churn,multi")
     args = ap.parse_args()
     import json
     import torch
@@ -170,7 +170,29 @@ def main():
             vk, pl, dp, pool = pools[name]
             form = rng.choice(args.forms.split(","))
             try:
-                if form == "churn":                     # a plan and a workspace that live for one call (the registry under concurrency)
+                if form == "multi":                     # ONE laned workspace for all the circuits (h2v_workspace_create_multi), calls of several plans in flight
+                    if "multi" not in wss:
+                        wss["multi"] = backend.Workspace.multi([pools[c][2] for c in pools], args.max_n, lanes=rng.choice([0, 3, 8, 16]), chunk=rng.choice([0, 0, 100, 700]))
+                        wss["multi"].defer_joins(True)
+                    w = wss["multi"]
+                    held = []
+                    for _ in range(rng.randrange(1, 7)):
+                        nm = rng.choice(list(pools))
+                        dpm = pools[nm][2]
+                        b = draw(nm, cap=2048)
+                        d = (up(b.proofs), torch.tensor(b.proof_off, dtype=torch.int64).to(dev), up(b.instances), up(b.committed))
+                        acc = torch.full((b.n,), 7, dtype=torch.uint8, device=dev)
+                        if rng.random() < 0.5:
+                            dpm.verify_batch_rlc_device(b.n, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), acc.data_ptr(), None, ws=w, stream=stream.cuda_stream,
+                                                        seed=bytes(rng.randrange(256) for _ in range(32)))
+                        else:
+                            dpm.verify_batch_device(b.n, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), acc.data_ptr(), None, ws=w, stream=stream.cuda_stream)
+                        held.append((nm, b, d, acc))
+                    w.join(stream.cuda_stream)
+                    stream.synchronize()
+                    for nm, b, d, acc in held:
+                        report(form, nm, b, acc.cpu().tolist())
+                elif form == "churn":                     # a plan and a workspace that live for one call (the registry under concurrency)
                     b = draw(name, cap=300)
                     dp2 = backend.DevicePlan(pl.to_bytes(), 0, fixed_base_window_bits=rng.choice([0, 0, 4, 8, 12]))
                     w2 = backend.Workspace(dp2, b.n) if rng.random() < 0.5 else backend.Workspace(dp2, b.n, lanes=rng.choice([1, 2, 5]), chunk=max(1, b.n // 3))
