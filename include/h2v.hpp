@@ -173,6 +173,13 @@ class Workspace {
     Workspace(const VerifyingKey &vk, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk) : vk_(vk) {
         check(h2v_workspace_create_lanes(vk.handle(), max_batch, n_lanes, chunk, &w_));
     }
+    /// ONE laned workspace for several keys of one device (h2v_workspace_create_multi: lanes sized for the largest of every
+    /// dimension); submit(vk, batch) names the key of each batch, submit(batch) means the first key
+    Workspace(const std::vector<const VerifyingKey *> &vks, uint64_t max_batch, uint32_t n_lanes = 0, uint32_t chunk = 0) : vk_(*vks.at(0)) {
+        std::vector<const h2v_plan *> ps;
+        for (const VerifyingKey *k : vks) ps.push_back(k->handle());
+        check(h2v_workspace_create_multi(ps.data(), (uint32_t)ps.size(), max_batch, n_lanes, chunk, &w_));
+    }
     Workspace(const Workspace &) = delete;
     Workspace &operator=(const Workspace &) = delete;
     ~Workspace() { h2v_workspace_free(w_); }
@@ -186,8 +193,9 @@ class Workspace {
         check(h2v_workspace_depth(w_, n, rlc ? 1 : 0, &d));
         return d;
     }
-    void submit(const h2v_batch &batch, bool rlc = false) {
-        check(h2v_verify_batch_submit(vk_.handle(), &batch, w_, rlc ? H2V_SUBMIT_RLC : 0u, nullptr));
+    void submit(const h2v_batch &batch, bool rlc = false) { submit(vk_, batch, rlc); }
+    void submit(const VerifyingKey &vk, const h2v_batch &batch, bool rlc = false) {
+        check(h2v_verify_batch_submit(vk.handle(), &batch, w_, rlc ? H2V_SUBMIT_RLC : 0u, nullptr));
         n_ = batch.n;
     }
     std::vector<uint8_t> wait(bool *fell_back = nullptr) {

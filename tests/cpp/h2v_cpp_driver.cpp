@@ -109,6 +109,13 @@ int main(int argc, char **argv) {
             std::printf("node_stream %d\n", same ? 1 : 0);
             h2v::Workspace laned(vk, n, 3, 2);     // three lanes, chunks of two proofs
             std::printf("laned %d\n", h2v::verify_batch(vk, batch, laned.handle()) == acc ? 1 : 0);
+            h2v::VerifyingKey vk2(blob.data(), blob.size(), 0);   // a second key (the same circuit loaded again) on one workspace for both
+            h2v::Workspace multi({&vk, &vk2}, n, 2, 3);
+            multi.submit(vk2, batch);
+            bool both = multi.wait() == acc;
+            multi.submit(batch, true);
+            both = both && multi.wait() == acc;
+            std::printf("multi %d\n", both ? 1 : 0);
         }
         // a consumed guard must refuse a second use; a wrong instance count must be refused by prepare
         bool refused = false;

@@ -76,3 +76,4 @@ def test_cpp_prepare_verify_on_gpu(driver, tmp_path, source):
     assert lines["batch_stream_per_proof"] == "1" and lines["batch_stream_rlc"] == "1"   # h2v::BatchStream, depth 3, seven batches
     assert lines["node_stream"] == "1"     # h2v::NodeStream over the device list [0, 0] (per proof) and [0, 0, 0] (RLC)
     assert lines["laned"] == "1"           # a laned workspace through the C++ wrapper
+    assert lines["multi"] == "1"           # one laned workspace for two keys (h2v_workspace_create_multi), submit(vk, batch)
