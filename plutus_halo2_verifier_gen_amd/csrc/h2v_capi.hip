@@ -483,6 +483,7 @@ extern "C" int h2v_plan_trace_slots(const h2v_plan *p, uint32_t *slot_ids, uint3
 // ---------------------------------------------------------------------------------------------- workspace
 static void rlc_release(struct RlcWs *r);
 static hipError_t make_stream(hipStream_t *s);
+static int lane_streams(uint32_t l, hipStream_t *main_st, hipStream_t *side_st);
 static void ws_release(h2v_workspace *w) {
     (void)hipSetDevice(w->device);
     if (w->hs_down) (void)hipStreamSynchronize(w->hs_down);
@@ -596,12 +597,14 @@ static int ensure_lane(h2v_workspace *w, uint32_t l) {
     if (w->lane[l]) return H2V_OK;
     // the lane's stream and event first, the lane itself last: a lane that exists has both (a failure here leaves lane[l]
     // NULL, and the next call tries again instead of enqueueing on a NULL stream)
-    if (!w->lane_st[l] && make_stream(&w->lane_st[l]) != hipSuccess) { w->lane_st[l] = nullptr; return fail(H2V_E_DEVICE, "lane stream creation failed"); }
+    hipStream_t side_st = nullptr;
+    if (int rcs = lane_streams(l, &w->lane_st[l], &side_st)) { w->lane_st[l] = nullptr; return rcs; }
     if (!w->lane_ev[l] && hipEventCreateWithFlags(&w->lane_ev[l], hipEventDisableTiming) != hipSuccess) { w->lane_ev[l] = nullptr; return fail(H2V_E_DEVICE, "lane event creation failed"); }
     h2v_workspace *lw = nullptr;
     int rc = ws_create_for(w->lane_plan, w->device, w->chunk, false, &lw);
     if (rc) return rc;
     lw->one_stream_mode = 2;            // (set per call: laned_depth)
+    lw->pside[0] = side_st;             // (the decompression's stream in the two-stream form: the other half of the lane's pair)
     lw->in_flight_hint = w->in_flight_hint > w->n_lanes ? w->in_flight_hint : w->n_lanes;
     memcpy(lw->opt, w->opt, sizeof lw->opt);
     w->lane[l] = lw;
@@ -814,9 +817,10 @@ static int ws_fits(const h2v_workspace *w, const h2v_plan *p, uint64_t n, bool w
 static std::vector<hipStream_t> g_pool[16];
 static size_t g_pool_next[16] = {};
 extern "C" int h2v_shutdown(int device);
+static const size_t g_pool_cap = []() { const char *e = getenv("H2V_QUEUE_POOL"); const int v = e ? atoi(e) : 16; return (size_t)(v < 1 ? 1 : v > 32 ? 32 : v); }();
 static hipError_t make_stream(hipStream_t *s) {
     static const int cumask = []() { const char *e = getenv("H2V_STREAM_CUMASK"); return e ? atoi(e) : 1; }();
-    static const size_t pool_cap = []() { const char *e = getenv("H2V_QUEUE_POOL"); const int v = e ? atoi(e) : 16; return (size_t)(v < 1 ? 1 : v > 32 ? 32 : v); }();
+    const size_t pool_cap = g_pool_cap;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -845,6 +849,32 @@ static hipError_t make_stream(hipStream_t *s) {
     }
     *s = g_pool[dev][g_pool_next[dev]++ % g_pool[dev].size()];
     return hipSuccess;
+}
+// The two streams of lane l of ANY laned workspace: a fixed place in the pool, so that the lanes of one workspace never share a
+// stream among themselves whatever else was created in between (handing streams out in creation order, two workspaces whose
+// lanes were created alternately ended up with a lane whose side stream WAS its main stream, and with two lanes of one
+// workspace on one pair: 3.7 / 4.1 ms per call where 3.3 / 3.4 are normal - bench.py's mixed workload, round 4).  Lanes 0..7
+// (the per-proof mode's eight two-stream lanes): main 2 l, side 2 l + 1; lanes 8..15 (only the sixteen one-stream lanes of
+// small chunks and of the RLC mode reach them): the odd streams as main.  Lanes of different workspaces with the same index
+// share their pair - with sixteen hardware queues and two plans in flight something has to.
+static int lane_streams(uint32_t l, hipStream_t *main_st, hipStream_t *side_st) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    for (;;) {                                     // fill the pool (make_stream creates while it is below its capacity)
+        size_t have, cap;
+        { std::lock_guard<std::mutex> lock(g_reg_mu); have = g_pool[dev].size(); cap = g_pool_cap; }
+        if (have >= cap && have > 0) break;
+        hipStream_t q;
+        if (make_stream(&q) != hipSuccess) return fail(H2V_E_DEVICE, "lane stream creation failed");
+        { std::lock_guard<std::mutex> lock(g_reg_mu); if (g_pool[dev].size() == have) break; }   // (H2V_QUEUE_POOL smaller than asked: the pool is full)
+    }
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    const size_t n = g_pool[dev].size();
+    if (n == 0) return fail(H2V_E_DEVICE, "no pool stream");
+    const uint32_t m = l < 8 ? 2 * l : 2 * (l - 8) + 1;
+    *main_st = g_pool[dev][m % n];
+    *side_st = g_pool[dev][(m ^ 1u) % n];
+    return H2V_OK;
 }
 // Releases everything the library owns on `device` (-1: on every device): waits for the pool streams, releases every live
 // workspace (they become empty shells: dead) and every plan's device memory, destroys the pool streams.  Idempotent.
