@@ -856,7 +856,8 @@ static hipError_t make_stream(hipStream_t *s) {
 // workspace on one pair: 3.7 / 4.1 ms per call where 3.3 / 3.4 are normal - bench.py's mixed workload, round 4).  Lanes 0..7
 // (the per-proof mode's eight two-stream lanes): main 2 l, side 2 l + 1; lanes 8..15 (only the sixteen one-stream lanes of
 // small chunks and of the RLC mode reach them): the odd streams as main.  Lanes of different workspaces with the same index
-// share their pair - with sixteen hardware queues and two plans in flight something has to.
+// share their pair - with sixteen hardware queues and two plans in flight something has to.  (main l, side l + 8 instead: 1.7 % slower,
+// 3.30-3.32 against 3.24-3.26 ms per simple_mul x 4096 batch; pairs spread over the pool in steps of four: the same.)
 static int lane_streams(uint32_t l, hipStream_t *main_st, hipStream_t *side_st) {
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
