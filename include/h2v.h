@@ -177,7 +177,8 @@ int h2v_workspace_get_option(const h2v_workspace *ws, uint32_t option, int32_t *
  * batch size in between gets the nearest rule, unmeasured.  h2v_workspace_tune runs `batch` (device-resident, as for
  * h2v_verify_batch_device; its verdicts are discarded) repeatedly in the way the workspace is used - a laned workspace with as
  * many calls in flight as it has lanes for that size, an ordinary one call by call -, times the launcher's choice and its
- * neighbours (pairing engine, then MSM terms per lane: <= 7 configurations, about 40 calls in all), and leaves the fastest on
+ * neighbours (pairing engine, then MSM terms per lane: <= 8 measurements of three rounds of the lanes or ~120 ms each, whichever
+ * is longer - about a second in all), and leaves the fastest on
  * the workspace as H2V_OPT_PAIRING_ENGINE / H2V_OPT_MSM_TERMS_PER_LANE (0 = the launcher's rule stays: a candidate must be
  * 3 % faster to replace it).  Call it once per (plan, batch size, workspace) at start-up, on `stream` (not NULL for a laned
  * workspace); it returns when the measurements are done.  flags: 0.  Results of later calls do not depend on it. */

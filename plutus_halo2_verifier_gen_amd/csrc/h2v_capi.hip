@@ -1182,14 +1182,16 @@ static uint32_t launch_pairing(const H2vDevPlan &d, uint32_t n, const uint32_t *
     const double S = msm_n_simd();
     // Eight or more batches in flight (the library's lanes): the chip is full whatever one launch brings, so the engine with the
     // fewest instructions that still has waves to spread wins much earlier - wide (2 x the normal engine's instructions) only up
-    // to #SIMDs / 16 proofs, narrow from #SIMDs / 4.  ms per batch, wide / normal / narrow: secp256k1 shape x 64 0.55 / 0.58 / 0.63;
+    // to #SIMDs / 16 proofs, narrow from 3/8 #SIMDs.  ms per batch, wide / normal / narrow: secp256k1 shape x 64 0.55 / 0.58 / 0.63;
     // sha256 shape x 128 0.67 / 0.66 / 0.72; x 256 1.15 / 1.08 / 1.06; x 512 1.61 / 1.43 / 1.47; secp256k1 x 512 1.67 / 1.57 / 1.55;
     // simple_mul x 512 1.02 / 0.88 / 0.84; x 1024 - / 1.47 / 1.39; sha256 x 1024 - / 2.19 / 2.16.
     // ... and where the narrow engine would run, its twelve-lane packing (five proofs per wave instead of four with four idle lanes
     // each; the line products in a pass of their own): ms per batch, narrow -> twelve: sha256 shape x 1024 1.99 -> 1.96, secp256k1 x 512
     // 1.21 -> 1.17, lookup_table x 2048 3.26 -> 3.16, atms x 2048 3.40 -> 3.34, simple_mul x 1024 1.24 -> 1.17.
     const bool many = in_flight_hint >= 8;
-    const bool prefer_narrow = many ? (double)n >= S / 4.0 : in_flight_hint >= 4 ? (double)n >= 2.0 * S : ((double)n > 2.0 * S && (double)n <= 4.0 * S);
+    // (round 4, from the tuner's measurements: at #SIMDs / 4 proofs - sha256 / secp256k1 shape x 256 - the normal engine beats the
+    //  twelve-lane one by 8-12 % in every run, 0.77-0.80 against 0.85-0.90 ms per batch; at x 512 neither wins by 3 %: the border is 3/8)
+    const bool prefer_narrow = many ? (double)n >= 3.0 * S / 8.0 : in_flight_hint >= 4 ? (double)n >= 2.0 * S : ((double)n > 2.0 * S && (double)n <= 4.0 * S);
     // (the wide engine issues twice the instructions of the normal one: a caller that keeps the chip full takes it only up to
     // #SIMDs / 2 proofs - sha256 shape x 1024, four in flight: wide 3.18, normal 2.98, narrow 3.12 ms per step; secp256k1 x 512:
     // wide 2.37, normal 2.47, narrow 2.64)
@@ -1619,18 +1621,27 @@ extern "C" int h2v_workspace_tune(const h2v_plan *p, const h2v_batch *b, h2v_wor
         return laned ? lanes_join(ws, st) : H2V_OK;
     };
     uint32_t n_meas = 0;
+    float per_call_ms = 0;                    // (the first measurement's result)
     auto measure = [&](int32_t pairing, int32_t tpl, float *ms) -> int {
         set2(pairing, tpl);
         if (laned) ws->defer_joins = true;
         int r = round_of_calls(depth);                                  // fills the lanes (and creates them)
         if (r) return r;
-        const uint32_t calls = laned ? 3 * depth : 4;
+        // three rounds of the lanes, and at least ~120 ms once the first measurement has told what a call takes: the candidates of a
+        // small batch differ by a few per cent of a fraction of a millisecond (secp256k1 shape x 256: the 38 ms measurements of
+        // round 4's first tuner picked the narrow engine in one run and the normal one, 13 % faster, in the next)
+        uint32_t calls = laned ? 3 * depth : 4;
+        if (per_call_ms > 0) {
+            const uint32_t want = (uint32_t)(120.0f / per_call_ms) + 1;
+            calls = want > calls ? (want < 40 * depth ? want : 40 * depth) : calls;
+        }
         if (hipEventRecord(e0, st) != hipSuccess) return fail(H2V_E_DEVICE, "event record failed");
         if ((r = round_of_calls(calls))) return r;
         if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return fail(H2V_E_DEVICE, "tuning: the measured calls failed");
         float t = 0;
         if (hipEventElapsedTime(&t, e0, e1) != hipSuccess) return fail(H2V_E_DEVICE, "event timing failed");
         *ms = t / (float)calls;
+        if (per_call_ms == 0) per_call_ms = *ms;
         n_meas++;
         return H2V_OK;
     };
@@ -1638,22 +1649,31 @@ extern "C" int h2v_workspace_tune(const h2v_plan *p, const h2v_batch *b, h2v_wor
     int32_t best_pair = 0, best_tpl = 0;
     do {
         if ((rc = measure(0, 0, &def_ms))) break;
+        if (laned && 120.0f / def_ms > 3.0f * (float)depth && (rc = measure(0, 0, &def_ms))) break;   // (the baseline at the candidates' length)
         best_ms = def_ms;
         const int32_t full[] = {6, 12, 16}, mid[] = {12, 16, 32}, low[] = {32, 64};
         const int32_t *eng = (double)m >= 2.0 * S ? full : (double)m >= S / 4.0 ? mid : low;
         const int n_eng = (double)m >= S / 4.0 ? 3 : 2;
+        // (the fastest candidate replaces the launcher's rule when it is 3 % faster than THAT - not each candidate against the best so
+        //  far, which favoured whichever engine happened to be measured first)
+        float cand_ms = 0;
+        int32_t cand = 0;
         for (int k = 0; k < n_eng && !rc; k++) {
             float t;
             if ((rc = measure(eng[k], 0, &t))) break;
-            if (t < best_ms * 0.97f) { best_ms = t; best_pair = eng[k]; }
+            if (cand == 0 || t < cand_ms) { cand_ms = t; cand = eng[k]; }
         }
         if (rc) break;
+        if (cand && cand_ms < best_ms * 0.97f) { best_ms = cand_ms; best_pair = cand; }
         const bool ladders_share = !p->d.ivc && (double)m * p->d.n_main_terms / 64.0 >= S / 8.0;   // (k_g1_msm_multi's own preconditions)
+        float cand_t_ms = 0;
+        int32_t cand_tpl = 0;
         for (int32_t tpl = 2; tpl <= 4 && ladders_share && !rc; tpl++) {
             float t;
             if ((rc = measure(best_pair, tpl, &t))) break;
-            if (t < best_ms * 0.97f) { best_ms = t; best_tpl = tpl; }
+            if (cand_tpl == 0 || t < cand_t_ms) { cand_t_ms = t; cand_tpl = tpl; }
         }
+        if (!rc && cand_tpl && cand_t_ms < best_ms * 0.97f) { best_ms = cand_t_ms; best_tpl = cand_tpl; }
     } while (0);
     ws->defer_joins = saved_defer;
     if (rc == H2V_OK) set2(best_pair, best_tpl); else set2(saved_pair, saved_tpl);
