@@ -273,6 +273,7 @@ def main():
     rlc_seed = bytes((7 * k + 1) & 0xff for k in range(32))   # fixed for the timed steps (reproducible); a service draws it per batch
 
     stream_pool = []
+    coalesce_state = []                      # per part: calls of the timed run that share one launch per kernel (1: none)
     caller = torch.cuda.Stream(device=dev)   # --pipeline lanes: the ONE stream the caller submits on (not the legacy NULL stream)
     RING = 16                                # accept / status buffers the steps cycle through (>= lanes: a lane runs its chunks in order)
 
@@ -337,6 +338,8 @@ def main():
             if args.hint:
                 ws.hint_in_flight(args.hint)
         n_lanes = max(ws.lanes()[0] for ws in wss)
+        # (include/h2v.h, COALESCING: per-proof calls of at most half a chunk on a deferring laned workspace run gathered)
+        coalesce_state[:] = [ws.lanes()[1] // P.B if mode == "per-proof" and 2 * P.B <= ws.lanes()[1] else 1 for ws, P in zip(wss, parts)]
         in_flight = min(ws.depth(P.B, mode == "rlc") for ws, P in zip(wss, parts))
         # (--timed-only: the profiled form launches warm-up + timed steps and nothing else - the tuner's candidate engines would show
         #  up in the kernel statistics; profile_round.sh forces the shapes the untimed first run chose instead)
@@ -520,6 +523,7 @@ def main():
     else:
         run = lanes_run(args.mode, args.steps, args.warmup, not args.no_gather)
         inflight = run.in_flight
+    co_main = list(coalesce_state)           # (of the main run: the secondary RLC measurement overwrites the list)
     elapsed, accept = run.el, run.accept
     k_steps = min(args.steps, 48 if not (args.shared_workspace and len(parts) > 1) else 48 // len(parts))   # (the library's event ring holds 64 calls per workspace)
     per_part = [kernel_times(run, args.mode, k_steps, p) for p in range(len(parts))]   # [(kernel_ms overlapped, latency, shape)]
@@ -531,7 +535,10 @@ def main():
     # are computed from ITS durations; the overlapped ones are reported beside them.
     alone = None
     per_part_alone = None
-    if (inflight > 1 or args.timed_only) and not args.no_alone:
+    coalesced = args.pipeline == "lanes" and args.mode == "per-proof" and any(f > 1 for f in co_main)
+    # (coalesced calls: a one-call-at-a-time pass would launch kernels over B proofs that the timed steps never launch - their
+    #  launches serve coalesce_state[p] calls each; the figures stay those of the timed steps, each call's share of its launch)
+    if (inflight > 1 or args.timed_only) and not args.no_alone and not coalesced:
         saved_hint = args.hint
         args.hint = args.hint or inflight
         r1 = streams_run(args.mode, 1, 6, 2, False, sync_every_step=True)
@@ -590,6 +597,9 @@ def main():
                         timed_expected, ok_all, gather_state["ok"], reject_check, t_forge, PL)
         if args.mode == "rlc":
             result["config"]["rlc_steps_routed_to_the_per_proof_kernels"] = round(max(routed_state.values()), 3) if routed_state else 0.0
+        if coalesced:
+            result["config"]["calls_coalesced_per_launch"] = co_main[0] if len(co_main) == 1 else list(co_main)
+            result["kernel_ms_is"] = "each call's SHARE of the launch that served its group of coalesced calls (include/h2v.h: COALESCING), in the timed steps"
         if len(parts) > 1 and args.pipeline == "lanes":
             result["config"]["workspaces"] = "one laned workspace for all plans (h2v_workspace_create_multi)" if args.shared_workspace else "one laned workspace per plan"
         result["config"]["tuned_launch_shapes"] = tuned_state or None    # h2v_workspace_tune per plan (0 = the launcher's rule was not beaten by 3 %)

@@ -150,6 +150,14 @@ int h2v_workspace_create_multi(const h2v_plan *const *plans, uint32_t n_plans, u
  * calls a stream of their own (hipStreamCreateWithFlags(.., hipStreamNonBlocking); torch.cuda.Stream()) and keep other NULL-
  * stream work (synchronous hipMemcpy included) out of the submission loop.  Without deferred joins NULL is accepted: every
  * call then waits for its own chunks anyway.  tests/test_gpu_parity.py::test_null_stream_contract_of_deferred_joins. */
+/* COALESCING (round 4).  With deferred joins a per-proof device-resident call of at most HALF the workspace's chunk is not
+ * launched by itself: its proofs are gathered - at once, behind whatever its `stream` held at the time of the call - behind
+ * those of the small calls before it, and the kernels run ONCE over the group: when the next call would not fit the chunk, when
+ * a call of another plan or another kind (large, RLC, host-buffer, tune) arrives, or at h2v_workspace_join.  Nothing changes for
+ * the caller beyond what deferred joins already say - inputs untouched and accept[] / status[] unread until the join - but a
+ * stream of 64-proof calls costs a 1024-proof launch per sixteen of them instead of sixteen chains of lone waves (the per-GPU
+ * shares of a batch cut over eight GPUs: DESIGN.md section 6.1).  Verdicts do not depend on it.  h2v_workspace_timings of such
+ * a call reports its share of the group's launch.  H2V_OPT_COALESCE = -1 switches it off for a workspace. */
 int h2v_workspace_defer_joins(h2v_workspace *ws, int defer);
 int h2v_workspace_join(h2v_workspace *ws, void *stream);
 /* Launch-shape options of a workspace (round 3: what used to be reachable through environment variables only; results never
@@ -170,7 +178,8 @@ int h2v_workspace_join(h2v_workspace *ws, void *stream);
 #define H2V_OPT_RLC_WINDOW_BITS 12u   /* bucket MSM: window width */
 #define H2V_OPT_RLC_CHAIN 13u         /* bucket MSM: most entries one lane sums */
 #define H2V_OPT_RLC_ROUTE 14u         /* RLC calls are routed by the observed rate of failing groups (h2v_verify_batch_rlc below); -1: always the batch check first */
-#define H2V_OPT_COUNT 15u
+#define H2V_OPT_COALESCE 15u          /* small device-resident calls on a deferring laned workspace are gathered into one launch per kernel (h2v_workspace_defer_joins below); -1: never */
+#define H2V_OPT_COUNT 16u
 int h2v_workspace_set_option(h2v_workspace *ws, uint32_t option, int32_t value);
 int h2v_workspace_get_option(const h2v_workspace *ws, uint32_t option, int32_t *value);
 /* (round 4) MEASURED launch shapes.  The launcher's own rules are thresholds calibrated on five circuit shapes; a circuit or a

@@ -54,8 +54,8 @@ class TuneReport(C.Structure):
 
 # h2v_workspace_set_option / h2v_probe_set_option ids (include/h2v.h)
 OPT_MSM_TERMS_PER_LANE, OPT_PAIRING_ENGINE, OPT_STREAMS, OPT_MSM_LANES_PER_TERM, OPT_MSM_BLOCK_SIZE, OPT_MSM_FIXED_SPLIT = 1, 2, 3, 4, 5, 6
-OPT_COMBINER_SCHEDULE, OPT_COMBINER_PROOFS_PER_BLOCK, OPT_DECOMPRESS_FORM, OPT_PIPES, OPT_RLC_GROUP_STAGE, OPT_RLC_WINDOW_BITS, OPT_RLC_CHAIN, OPT_RLC_ROUTE = 7, 8, 9, 10, 11, 12, 13, 14
-OPT_COUNT = 15
+OPT_COMBINER_SCHEDULE, OPT_COMBINER_PROOFS_PER_BLOCK, OPT_DECOMPRESS_FORM, OPT_PIPES, OPT_RLC_GROUP_STAGE, OPT_RLC_WINDOW_BITS, OPT_RLC_CHAIN, OPT_RLC_ROUTE, OPT_COALESCE = 7, 8, 9, 10, 11, 12, 13, 14, 15
+OPT_COUNT = 16
 
 RLC_SEED_GIVEN = 1
 RLC_ONE_STREAM = 2

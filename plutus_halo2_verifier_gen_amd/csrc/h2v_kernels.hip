@@ -1495,3 +1495,4 @@ extern "C" __global__ void k_export_points(uint32_t n, int jacobian, const uint3
 
 // ============================================================================ RLC batch mode + bucket MSM
 #include "h2v_rlc.hpp"
+#include "h2v_coalesce.hpp"

@@ -938,6 +938,78 @@ def test_debug_sync_path_in_a_child_process(be):
     assert r.returncode == 0 and "modes ok" in r.stdout and "launching k_g1_msm" in r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_small_calls_are_coalesced(be, circuits):
+    """include/h2v.h, COALESCING: small per-proof calls on a deferring laned workspace are gathered into one launch per kernel.
+    Sequences of calls of 1 .. chunk / 2 proofs (every corruption kind among them, so ragged lengths too; proof bytes at odd
+    device addresses), two plans interleaved (a change of plan runs the open group), a large call and an RLC call in between,
+    joins on a stream and on the host: accept[] AND status[] of every call equal the construction and what the same calls give
+    with H2V_OPT_COALESCE = -1; h2v_workspace_timings of a coalesced call reports its share of the group's launch."""
+    import torch
+    from plutus_halo2_verifier_gen_amd import synth
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.Stream(device=dev)
+    rng = random.Random(99)
+    pools = {}
+    for name in ("simple_mul", "sha256"):
+        vk, td, pl, dp, ov = circuits[name]
+        b = synth.forge_batch(vk, td, 400, seed=81, plan=pl, workers=8)
+        pools[name] = (vk, pl, dp, synth.with_rejects(pl, b, vk.n_public_inputs, fraction=0.15, seed=82, kinds=list(synth.CORRUPTIONS)))
+    # the calls: (plan, indices into its pool, kind)
+    calls = []
+    for k in range(40):
+        name = rng.choice(list(pools))
+        n = rng.choice([1, 2, 7, 33, 64, 100, 128, 200])
+        calls.append((name, [rng.randrange(400) for _ in range(n)], "small"))
+        if k == 13:
+            calls.append(("simple_mul", [rng.randrange(400) for _ in range(900)], "large"))
+        if k == 27:
+            calls.append(("simple_mul", [rng.randrange(400) for _ in range(150)], "rlc"))
+    results = {}
+    for coalesce in (0, -1):
+        wss = {name: be.Workspace(pools[name][2], 1024, lanes=0, chunk=512) for name in pools}
+        for w in wss.values():
+            w.defer_joins(True)
+            w.set_option(be.OPT_COALESCE, coalesce)
+            assert w.get_option(be.OPT_COALESCE) == coalesce
+        held = []
+        for ci_, (name, idx, kind) in enumerate(calls):
+            vk, pl, dp, pool = pools[name]
+            b = _permute(pool, idx, vk.n_public_inputs)
+            raw = torch.frombuffer(bytearray(b"\x00" * (1 + ci_ % 3) + b.proofs), dtype=torch.uint8).to(dev)   # proof bytes at an odd address now and then
+            dpr = raw[1 + ci_ % 3:]
+            dof = torch.tensor(b.proof_off, dtype=torch.int64).to(dev)
+            din = torch.frombuffer(bytearray(b.instances), dtype=torch.uint8).to(dev) if b.instances else None
+            dci = torch.frombuffer(bytearray(b.committed), dtype=torch.uint8).to(dev) if b.committed else None
+            acc = torch.full((b.n,), 7, dtype=torch.uint8, device=dev)
+            st = torch.full((b.n,), -1, dtype=torch.int32, device=dev)
+            args = (b.n, dpr.data_ptr(), dof.data_ptr(), din.data_ptr() if din is not None else None, dci.data_ptr() if dci is not None else None, acc.data_ptr(), st.data_ptr())
+            if kind == "rlc":
+                dp.verify_batch_rlc_device(*args, ws=wss[name], stream=s.cuda_stream, seed=bytes(range(32)))
+            else:
+                dp.verify_batch_device(*args, ws=wss[name], stream=s.cuda_stream)
+            held.append((name, b, acc, st, (raw, dof, din, dci), kind))
+            if ci_ == 20:                     # a join in the middle, on the host: everything so far is final
+                for w in wss.values():
+                    w.join(None)
+                for name_, b_, acc_, st_, _k, kind_ in held:
+                    assert acc_.cpu().tolist() == b_.expected, (coalesce, name_, kind_)
+        for w in wss.values():
+            w.join(s.cuda_stream)
+        s.synchronize()
+        out = []
+        for name, b, acc, st, _keep, kind in held:
+            assert acc.cpu().tolist() == b.expected, (coalesce, name, b.n, kind)
+            assert [int(x == 0) for x in st.cpu().tolist()] == b.expected, (coalesce, name, kind)
+            out.append((acc.cpu().tolist(), st.cpu().tolist()))
+        results[coalesce] = out
+        # the last call was a small one: its record is a share of its group's launch
+        tm = wss[calls[-1][0]].timings(0)
+        assert tm.pairing_ms > 0 and tm.g1_decompress_ms > 0
+        for w in wss.values():
+            w.close()
+    assert results[0] == results[-1]
+
+
 def test_threads_sharing_plans_and_the_stream_pool(be):
     """include/h2v.h: a plan "may be shared by threads (each with its own workspace)".  Three host threads for twenty seconds
     through tests/soak.py (its own process: it ends with h2v_shutdown): random circuits, sizes, reject mixes and calling forms -
