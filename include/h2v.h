@@ -150,14 +150,17 @@ int h2v_workspace_create_multi(const h2v_plan *const *plans, uint32_t n_plans, u
  * calls a stream of their own (hipStreamCreateWithFlags(.., hipStreamNonBlocking); torch.cuda.Stream()) and keep other NULL-
  * stream work (synchronous hipMemcpy included) out of the submission loop.  Without deferred joins NULL is accepted: every
  * call then waits for its own chunks anyway.  tests/test_gpu_parity.py::test_null_stream_contract_of_deferred_joins. */
-/* COALESCING (round 4).  With deferred joins a per-proof device-resident call of at most HALF the workspace's chunk is not
+/* COALESCING (round 4).  With deferred joins a device-resident call (per proof or RLC) of at most HALF the workspace's chunk is not
  * launched by itself: its proofs are gathered - at once, behind whatever its `stream` held at the time of the call - behind
  * those of the small calls before it, and the kernels run ONCE over the group: when the next call would not fit the chunk, when
  * a call of another plan or another kind (large, RLC, host-buffer, tune) arrives, or at h2v_workspace_join.  Nothing changes for
  * the caller beyond what deferred joins already say - inputs untouched and accept[] / status[] unread until the join - but a
  * stream of 64-proof calls costs a 1024-proof launch per sixteen of them instead of sixteen chains of lone waves (the per-GPU
  * shares of a batch cut over eight GPUs: DESIGN.md section 6.1).  Verdicts do not depend on it.  h2v_workspace_timings of such
- * a call reports its share of the group's launch.  H2V_OPT_COALESCE = -1 switches it off for a workspace. */
+ * a call reports its share of the group's launch.  RLC calls are gathered among themselves: ONE batch check over the group, with
+ * the coefficients of its first call's seed; accept[] stays per proof and exact, h2v_workspace_rlc_result of each call reports the
+ * GROUP's batch verdict (a rejecting proof of a neighbouring call fails the check for all of them) and the call's share of the
+ * times.  H2V_OPT_COALESCE = -1 switches it off for a workspace. */
 int h2v_workspace_defer_joins(h2v_workspace *ws, int defer);
 int h2v_workspace_join(h2v_workspace *ws, void *stream);
 /* Launch-shape options of a workspace (round 3: what used to be reachable through environment variables only; results never

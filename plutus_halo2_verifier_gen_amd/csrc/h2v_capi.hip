@@ -1563,6 +1563,8 @@ struct Coalesce {
     const h2v_plan *plan = nullptr;      // of the open group
     uint64_t plan_gen = 0;
     uint32_t count = 0;
+    bool rlc = false;                    // the open group's mode: per proof, or ONE batch check over the whole group
+    uint32_t seed[8] = {};               // (RLC: the first call's - one fresh seed makes every coefficient unpredictable)
     struct Part { uint8_t *accept; uint32_t *status; uint32_t base, n; int slot; };
     std::vector<Part> parts;
 };
@@ -1609,13 +1611,42 @@ static int co_flush(h2v_workspace *w) {
     lw->one_stream_mode = stream_mode;
     lw->in_flight_hint = w->hint_given ? w->in_flight_hint : w->n_lanes;
     const h2v_plan *p = c.plan;
-    int rc = run_pipeline(p->d, c.count, c.proofs, c.off, p->d.n_pi ? c.inst : nullptr, p->d.n_ci ? c.ci : nullptr, c.accept, c.status, lw, ls, nullptr, false);
+    const uint8_t *inst_g = p->d.n_pi ? c.inst : nullptr, *ci_g = p->d.n_ci ? c.ci : nullptr;
+    int rc = H2V_OK;
+    bool routed = false;
+    const int slot0 = c.parts.empty() ? 0 : c.parts.front().slot;
+    if (c.rlc) {
+        // one batch check over the group (as a chunk of run_laned): the verdict counter of the group's FIRST call takes the
+        // kernel's report and is copied to the other calls' counters behind it
+        if ((rc = rlc_stats_ensure(w)) == H2V_OK) {
+            routed = rlc_route(w);
+            if (hipMemsetAsync(w->rlc_fail + slot0, routed ? 1 : 0, 4, ls) != hipSuccess) rc = fail(H2V_E_DEVICE, "memset failed");
+        }
+        if (rc == H2V_OK) {
+            lw->rlc_fail_ptr = w->rlc_fail + slot0;
+            lw->rlc_stats_ptr = w->rlc_stats;
+            lw->opt[H2V_OPT_RLC_GROUP_STAGE] = w->opt[H2V_OPT_RLC_GROUP_STAGE];
+            if (routed) { lw->one_stream_mode = 1; rc = run_routed(p, c.count, c.proofs, c.off, inst_g, ci_g, c.accept, c.status, lw, ls, w->rlc_stats); }
+            else rc = run_rlc(p, c.count, c.proofs, c.off, inst_g, ci_g, c.accept, c.status, lw, ls, c.seed, true);
+            if (rc == H2V_OK && hipMemcpyAsync(w->h_rlc_stats, w->rlc_stats, 8, hipMemcpyDeviceToHost, ls) != hipSuccess) rc = fail(H2V_E_DEVICE, "routing counters: copy failed");
+        }
+    } else {
+        rc = run_pipeline(p->d, c.count, c.proofs, c.off, inst_g, ci_g, c.accept, c.status, lw, ls, nullptr, false);
+    }
     for (const Coalesce::Part &q : c.parts) {
         if (rc) break;
         if (hipMemcpyAsync(q.accept, c.accept + q.base, q.n, hipMemcpyDeviceToDevice, ls) != hipSuccess ||
-            (q.status && hipMemcpyAsync(q.status, c.status + q.base, (size_t)q.n * 4, hipMemcpyDeviceToDevice, ls) != hipSuccess))
+            (q.status && hipMemcpyAsync(q.status, c.status + q.base, (size_t)q.n * 4, hipMemcpyDeviceToDevice, ls) != hipSuccess) ||
+            (c.rlc && q.slot != slot0 && hipMemcpyAsync(w->rlc_fail + q.slot, w->rlc_fail + slot0, 4, hipMemcpyDeviceToDevice, ls) != hipSuccess))
             rc = fail(H2V_E_DEVICE, "coalesced calls: copying the verdicts out failed");
+        // the call's record: its group ran as this lane's most recent call; its share of that launch
         w->lring_share[q.slot] = (float)q.n / (float)c.count;
+        w->lring_routed[q.slot] = routed ? 1 : 0;
+        for (uint32_t k = 0; k < w->n_lanes; k++) {
+            w->lring_calls[q.slot][k] = w->lane[k] ? w->lane[k]->calls : 0;
+            w->lring_rlc_calls[q.slot][k] = w->lane[k] ? rlc_calls_of(w->lane[k]) : 0;
+            w->lring_rlc_obj[q.slot][k] = w->lane[k] ? w->lane[k]->rlc : nullptr;
+        }
     }
     c.parts.clear();
     c.count = 0;
@@ -1635,11 +1666,12 @@ static bool co_wanted(const h2v_workspace *w, const h2v_plan *p, uint64_t n) {
     (void)p;
 }
 // one small call: gathered into the open group (opening one, or running the open one first when this call does not fit it)
-static int coalesce_call(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, uint32_t *status, h2v_workspace *w, hipStream_t st) {
+static int coalesce_call(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, uint32_t *status, h2v_workspace *w, hipStream_t st, bool rlc = false,
+                         const uint32_t *seed = nullptr) {
     const uint32_t n = (uint32_t)b->n;
     if (w->co_lane >= 0) {
         const Coalesce &o = *w->co[w->co_lane];
-        if (o.plan != p || o.plan_gen != p->gen || o.count + n > o.cap)
+        if (o.plan != p || o.plan_gen != p->gen || o.rlc != rlc || o.count + n > o.cap)
             if (int rcf = co_flush(w)) return rcf;
     }
     if (w->co_lane < 0) {
@@ -1651,6 +1683,8 @@ static int coalesce_call(const h2v_plan *p, const h2v_batch *b, uint8_t *accept,
         if ((rc = co_ensure(w, l, p))) return rc;
         Coalesce &c = *w->co[l];
         c.plan = p; c.plan_gen = p->gen; c.count = 0; c.parts.clear();
+        c.rlc = rlc;
+        for (int k = 0; k < 8; k++) c.seed[k] = rlc && seed ? seed[k] : 0;
         HIPCHK(hipMemsetAsync(c.off, 0, 8, w->lane_st[l]));     // off[0] = 0: behind the previous group's pipeline on this stream
         w->co_lane = (int)l;
     }
@@ -1667,9 +1701,9 @@ static int coalesce_call(const h2v_plan *p, const h2v_batch *b, uint8_t *accept,
     // the call's record in the ring: one "chunk" on lane l, that lane's NEXT pipeline call (nothing else runs there before the flush)
     const int slot = (int)(w->calls % h2v_workspace::RING);
     w->calls++;
-    w->lring_chunks[slot] = 1; w->lring_first[slot] = l; w->lring_mod[slot] = w->n_lanes; w->lring_rlc[slot] = 0; w->lring_routed[slot] = 0;
+    w->lring_chunks[slot] = 1; w->lring_first[slot] = l; w->lring_mod[slot] = w->n_lanes; w->lring_rlc[slot] = rlc ? 1 : 0; w->lring_routed[slot] = 0;
     w->lring_co[slot] = 1; w->lring_share[slot] = 1.0f;
-    for (uint32_t q = 0; q < w->n_lanes; q++) w->lring_calls[slot][q] = w->lane[q] ? w->lane[q]->calls + (q == l ? 1 : 0) : 0;
+    for (uint32_t q = 0; q < w->n_lanes; q++) { w->lring_calls[slot][q] = 0; w->lring_rlc_calls[slot][q] = 0; w->lring_rlc_obj[slot][q] = nullptr; }   // (filled in by the flush)
     c.parts.push_back({accept, status, c.count, n, slot});
     c.count += n;
     w->lane_busy[l] = true;              // (h2v_workspace_join must look at this lane; its event is recorded by the flush)
@@ -2616,6 +2650,7 @@ extern "C" int h2v_verify_batch_rlc_device(const h2v_plan *p, const h2v_batch *b
     }
     uint32_t seed[8];
     if ((rc = rlc_seed(opts, seed))) return rc;
+    if (ws->n_lanes && co_wanted(ws, p, b->n)) return coalesce_call(p, b, accept, status, ws, (hipStream_t)stream, true, seed);
     if (ws->n_lanes) return run_laned(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, true, seed, false);
     return run_rlc_or_routed(p, (uint32_t)b->n, b->proofs, b->proof_off, b->instances, b->committed, accept, status, ws, (hipStream_t)stream, seed,
                              opts && (opts->flags & H2V_RLC_ONE_STREAM));
@@ -2670,6 +2705,11 @@ extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, u
             float span = 0;
             HIPCHK(hipEventElapsedTime(&span, first, ev[9]));
             if (span > tm->total_ms) tm->total_ms = span;
+        }
+        if (w->lring_co[slot]) {     // a coalesced call: its share of the one batch check that served its group (total_ms: the group's)
+            const float f = w->lring_share[slot];
+            tm->transcript_combiner_ms *= f; tm->g1_decompress_ms *= f; tm->prepare_ms *= f; tm->bucket_sort_ms *= f;
+            tm->bucket_accumulate_ms *= f; tm->bucket_reduce_ms *= f; tm->pairing_ms *= f;
         }
         return H2V_OK;
     }

@@ -939,7 +939,8 @@ def test_debug_sync_path_in_a_child_process(be):
 
 
 def test_small_calls_are_coalesced(be, circuits):
-    """include/h2v.h, COALESCING: small per-proof calls on a deferring laned workspace are gathered into one launch per kernel.
+    """include/h2v.h, COALESCING: small calls on a deferring laned workspace are gathered into one launch per kernel (RLC calls: one
+    batch check per group).
     Sequences of calls of 1 .. chunk / 2 proofs (every corruption kind among them, so ragged lengths too; proof bytes at odd
     device addresses), two plans interleaved (a change of plan runs the open group), a large call and an RLC call in between,
     joins on a stream and on the host: accept[] AND status[] of every call equal the construction and what the same calls give
@@ -959,7 +960,7 @@ def test_small_calls_are_coalesced(be, circuits):
     for k in range(40):
         name = rng.choice(list(pools))
         n = rng.choice([1, 2, 7, 33, 64, 100, 128, 200])
-        calls.append((name, [rng.randrange(400) for _ in range(n)], "small"))
+        calls.append((name, [rng.randrange(400) for _ in range(n)], "small" if rng.random() < 0.6 else "rlc"))   # (RLC calls are gathered among themselves)
         if k == 13:
             calls.append(("simple_mul", [rng.randrange(400) for _ in range(900)], "large"))
         if k == 27:
@@ -1002,9 +1003,13 @@ def test_small_calls_are_coalesced(be, circuits):
             assert [int(x == 0) for x in st.cpu().tolist()] == b.expected, (coalesce, name, kind)
             out.append((acc.cpu().tolist(), st.cpu().tolist()))
         results[coalesce] = out
-        # the last call was a small one: its record is a share of its group's launch
-        tm = wss[calls[-1][0]].timings(0)
-        assert tm.pairing_ms > 0 and tm.g1_decompress_ms > 0
+        # the last call was a small one: its record is a share of its group's launch (or of its group's batch check)
+        if calls[-1][2] == "rlc":
+            ok_, tm = wss[calls[-1][0]].rlc_result(0)
+            assert tm.g1_decompress_ms > 0 or not ok_
+        else:
+            tm = wss[calls[-1][0]].timings(0)
+            assert tm.pairing_ms > 0 and tm.g1_decompress_ms > 0
         for w in wss.values():
             w.close()
     assert results[0] == results[-1]
