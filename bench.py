@@ -599,6 +599,9 @@ def main():
             result["config"]["rlc_steps_routed_to_the_per_proof_kernels"] = round(max(routed_state.values()), 3) if routed_state else 0.0
         if coalesced:
             result["config"]["calls_coalesced_per_launch"] = co_main[0] if len(co_main) == 1 else list(co_main)
+            if result.get("issue_budget"):       # (the counter passes launch the kernels over B proofs, one call at a time: not the launches of the timed steps)
+                result["issue_budget"] = None
+                result["issue_budget_note"] = "not computed: the timed steps run coalesced launches, the counter passes single calls"
             result["kernel_ms_is"] = "each call's SHARE of the launch that served its group of coalesced calls (include/h2v.h: COALESCING), in the timed steps"
         if len(parts) > 1 and args.pipeline == "lanes":
             result["config"]["workspaces"] = "one laned workspace for all plans (h2v_workspace_create_multi)" if args.shared_workspace else "one laned workspace per plan"
