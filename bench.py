@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--pipeline", default="lanes", choices=["lanes", "streams"],
                     help="lanes: one laned workspace per plan, the library pipelines the steps (default); streams: --inflight workspaces on torch streams")
     ap.add_argument("--lanes", type=int, default=0, help="--pipeline lanes: number of lanes (0: the library's choice)")
+    ap.add_argument("--chunk", type=int, default=0, help="--pipeline lanes: proofs per lane launch (0: the library's choice for the plan); calls of at most half of it are coalesced")
     ap.add_argument("--inflight", type=int, default=0, help="--pipeline streams: steps in flight (workspaces / streams); default: probed")
     ap.add_argument("--reject-fraction", type=float, default=0.0, help="timed steps run on a batch in which this fraction of the proofs has the reference example's byte flip")
     ap.add_argument("--reject-count", type=int, default=0, help="timed steps run on a batch with exactly this many corrupted proofs (pairing-only rejects: wrong_pi)")
@@ -331,7 +332,7 @@ def main():
             one = backend.Workspace.multi([P.dp for P in parts], max(P.B for P in parts), lanes=args.lanes if lanes is None else lanes, chunk=0)
             wss = [one] * len(parts)
         else:
-            wss = [backend.Workspace(P.dp, P.B, lanes=args.lanes if lanes is None else lanes, chunk=0) for P in parts]
+            wss = [backend.Workspace(P.dp, max(P.B, args.chunk), lanes=args.lanes if lanes is None else lanes, chunk=args.chunk) for P in parts]
         for ws, P in zip(wss, parts):
             ws.defer_joins(True)
             apply_options(ws, P)
@@ -599,6 +600,10 @@ def main():
             result["config"]["rlc_steps_routed_to_the_per_proof_kernels"] = round(max(routed_state.values()), 3) if routed_state else 0.0
         if coalesced:
             result["config"]["calls_coalesced_per_launch"] = co_main[0] if len(co_main) == 1 else list(co_main)
+            for key in ("roofline", "msm_roofline"):   # (counter files describe launches of B x calls proofs: per-call traffic is not in them)
+                if isinstance(result.get(key), dict) and result[key].get("traffic") is not None:
+                    result[key]["traffic"] = None
+                    result[key]["traffic_source"] = None
             if result.get("issue_budget"):       # (the counter passes launch the kernels over B proofs, one call at a time: not the launches of the timed steps)
                 result["issue_budget"] = None
                 result["issue_budget_note"] = "not computed: the timed steps run coalesced launches, the counter passes single calls"

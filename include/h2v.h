@@ -120,9 +120,11 @@ void h2v_workspace_free(h2v_workspace *ws);
  * the last one (unless joins are deferred, below).  Device memory is n_lanes x chunk proofs' worth, whatever max_batch is.
  * Verdicts never depend on n_lanes or chunk (tests/test_gpu_parity.py::test_verdicts_do_not_depend_on_the_chunking); in
  * RLC mode every chunk is its own batch check.
- *   n_lanes = 0 / chunk = 0: the library's choice for this plan (chunk = the batch that gives every kernel one wave per
- *   SIMD: 4096 proofs for 16 MSM terms, 1024 for 60; 16 lanes, of which the per-proof mode cycles through 8 - all 16 for chunks too small to fill the chip: h2v_workspace_depth).  h2v_workspace_create(plan, max_batch) itself
- *   returns a laned workspace when max_batch >= 4 x that chunk (an ordinary one below that).  n_lanes <= 16: that is also the
+ *   n_lanes = 0 / chunk = 0: the library's choice (chunk = 4096 proofs whatever the plan and whatever max_batch - the largest
+ *   single call - is: small calls are gathered into the lanes, COALESCING below; 16 lanes, of which the per-proof mode cycles
+ *   through 8 - all 16 for launches too small to fill the chip: h2v_workspace_depth).  An explicit chunk is cut to max_batch.
+ *   h2v_workspace_create(plan, max_batch) itself returns a laned workspace when max_batch >= 4 x the batch that gives every kernel
+ *   of the plan one wave per SIMD (4096 proofs for 16 MSM terms, 1024 for 60; an ordinary workspace below that).  n_lanes <= 16: that is also the
  *   most host batches h2v_verify_batch_submit keeps in flight on one workspace (h2v::BatchStream / backend.BatchStream: depth
  *   <= 16).  A laned workspace has no trace buffer (h2v_trace creates its own). */
 int h2v_workspace_create_lanes(const h2v_plan *plan, uint64_t max_batch, uint32_t n_lanes, uint32_t chunk, h2v_workspace **out);

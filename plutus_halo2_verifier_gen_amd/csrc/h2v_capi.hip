@@ -200,9 +200,10 @@ struct h2v_workspace {
     const struct RlcWs *lring_rlc_obj[RING][MAXL] = {};   // (whose counter lring_rlc_calls holds: a lane serves one plan's RLC buffers at a time)
     uint8_t lring_rlc[RING] = {};
     // ---- coalescing of small device-resident calls (coalesce_call): per lane a staging area the proofs of several calls are
-    // gathered into; co_lane = the lane whose group is open (-1: none); per call slot: coalesced?, its share of the group
+    // gathered into; co_open: the lanes whose groups are open, oldest first (one group per plan and mode, at most four); per call
+    // slot: coalesced?, its share of the group
     struct Coalesce *co[MAXL] = {};
-    int co_lane = -1;
+    std::vector<uint32_t> co_open;
     uint8_t lring_co[RING] = {};
     float lring_share[RING] = {};
 };
@@ -594,6 +595,14 @@ static uint32_t default_chunk(const H2vDevPlan &d) {
     while (c < 4096 && (double)c * 1.4142 < want) c <<= 1;
     return c;
 }
+// What a LANE holds (h2v_workspace_create_lanes with chunk = 0): 4096 proofs whatever the plan.  With several batches in flight
+// the launch that pays is the large one - the six-lane pairing engine, ladders that share their doublings, fewer and longer
+// launches - and since small calls are gathered (coalesce_call) a lane's capacity is no longer the size of the calls.  Measured,
+// ms per call of the BASELINE size with the lanes at default_chunk -> 4096 (-> 8192): lookup_table x 2048 3.17 -> 2.92 (2.86),
+// atms x 2048 3.30 -> 2.78 (2.70), sha256 shape x 1024 1.96 -> 1.86 (1.87), secp256k1 x 512 1.01 -> 0.87, their shares x 128 / x 64
+// 0.32 / 0.17 -> 0.27 / 0.15; simple_mul x 4096 is at 4096 already (8192: the same).  A call that waits for its own chunks is
+// still cut down to default_chunk / 2 per lane (run_laned).
+static uint32_t lane_chunk(const H2vDevPlan &d) { (void)d; return 4096u; }
 // Lanes: measured on MI355X, simple_mul, a stream of 4096-proof batches through one laned workspace (deferred joins; ms per
 // batch): per-proof mode, each lane's pipeline on the lane's stream with the decompression beside it on a side stream:
 // 4 lanes 4.60, 5: 4.35, 6: 4.31, 11: 4.72; everything on the lane's stream: 5: 4.64, 8: 4.26, 11: 4.43 (five caller-owned
@@ -625,7 +634,7 @@ static int create_lanes_for(const H2vDevPlan &d, int device, uint64_t max_batch,
     if (n_lanes > (uint32_t)h2v_workspace::MAXL) return fail(H2V_E_ARG, "at most 16 lanes");
     // chunk = 0, the library's choice: the plan's own chunk even when max_batch - the largest single call - is smaller: the lanes
     // are what small calls are gathered into (coalesce_call).  An explicit chunk is the caller's, cut to max_batch.
-    if (chunk == 0) chunk = default_chunk(d);
+    if (chunk == 0) chunk = lane_chunk(d);
     else if ((uint64_t)chunk > max_batch) chunk = (uint32_t)max_batch;
     HIPCHK(hipSetDevice(device));
     h2v_workspace *w = new h2v_workspace();
@@ -673,14 +682,15 @@ extern "C" int h2v_workspace_create_multi(const h2v_plan *const *plans, uint32_t
         if (vm_lds_slots(d) == 0 && d.n_regs > regs_global) regs_global = d.n_regs;
         if (d.ivc) u.ivc = d.ivc;
         if (d.fix_tab) u.fix_tab = d.fix_tab;
-        const uint32_t c = default_chunk(d);
+        const uint32_t c = lane_chunk(d);
         chunk_min = chunk_min == 0 || c < chunk_min ? c : chunk_min;
     }
     u.n_ci = 0;
     u.n_points = slots - 2u * (u.ivc ? 1u : 0u);                  // H2V_SLOTS(u) == the largest plan's
     if (regs_global) { u.vm_lanes = 1; u.n_regs = regs_global; }   // vm_lds_slots(u) == 0: a global register file of that size
     else if (vm_lds_slots(u) == 0) return fail(H2V_E_ARG, "internal: union shape");
-    return create_lanes_for(u, plans[0]->device, max_batch, n_lanes, chunk ? chunk : chunk_min, out);
+    (void)chunk_min;
+    return create_lanes_for(u, plans[0]->device, max_batch, n_lanes, chunk, out);      // (chunk = 0: the library's lane size, whatever max_batch is)
 }
 extern "C" int h2v_workspace_create(const h2v_plan *p, uint64_t max_batch, h2v_workspace **out) {
     if (!p || !out) return fail(H2V_E_ARG, "null argument");
@@ -1476,7 +1486,7 @@ static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const
     //  and whole chunks keep the full-chip launch shapes - a stream of 16 384-proof calls: 15.9 ms per call cut in 2048s, ~13 in 4096s)
     if (!rlc && !w->defer_joins && !never_join && n > chunk && (uint64_t)n < (uint64_t)L * chunk) {
         const uint32_t c2 = (uint32_t)(((n + L - 1) / L + 511) / 512 * 512);
-        if (c2 >= 2048 && c2 < chunk) chunk = c2;
+        if (c2 >= default_chunk(d) / 2 && c2 < chunk) chunk = c2;       // (simple_mul: 2048; T = 60: 512)
     }
     const uint32_t nch = (n + chunk - 1) / chunk;
     // What the chunks' launch shapes may assume about the chip: with deferred joins (and the host-buffer stream of batches)
@@ -1576,7 +1586,7 @@ static void co_release(h2v_workspace *w) {
         delete c;
         c = nullptr;
     }
-    w->co_lane = -1;
+    w->co_open.clear();
 }
 // the staging buffers of lane l for groups of plan p (grown when a plan with longer proofs / more public inputs comes along)
 static int co_ensure(h2v_workspace *w, uint32_t l, const h2v_plan *p) {
@@ -1597,11 +1607,17 @@ static int co_ensure(h2v_workspace *w, uint32_t l, const h2v_plan *p) {
     c.cap = cap; c.cap_proof_bytes = bp; c.cap_inst = bi;
     return H2V_OK;
 }
-// runs the open group: ONE pass of the per-proof pipeline over everything gathered so far, then every call's verdicts to the caller's buffers
+// runs every open group, oldest first
+static int co_flush_lane(h2v_workspace *w, uint32_t l);
 static int co_flush(h2v_workspace *w) {
-    if (w->co_lane < 0) return H2V_OK;
-    const uint32_t l = (uint32_t)w->co_lane;
-    w->co_lane = -1;
+    while (!w->co_open.empty())
+        if (int rc = co_flush_lane(w, w->co_open.front())) return rc;
+    return H2V_OK;
+}
+// runs the open group of lane l: ONE pass of the pipeline over everything gathered so far, then every call's verdicts to the caller's buffers
+static int co_flush_lane(h2v_workspace *w, uint32_t l) {
+    for (size_t k = 0; k < w->co_open.size(); k++)
+        if (w->co_open[k] == l) { w->co_open.erase(w->co_open.begin() + (long)k); break; }
     Coalesce &c = *w->co[l];
     if (c.count == 0) return H2V_OK;
     h2v_workspace *lw = w->lane[l];
@@ -1669,15 +1685,29 @@ static bool co_wanted(const h2v_workspace *w, const h2v_plan *p, uint64_t n) {
 static int coalesce_call(const h2v_plan *p, const h2v_batch *b, uint8_t *accept, uint32_t *status, h2v_workspace *w, hipStream_t st, bool rlc = false,
                          const uint32_t *seed = nullptr) {
     const uint32_t n = (uint32_t)b->n;
-    if (w->co_lane >= 0) {
-        const Coalesce &o = *w->co[w->co_lane];
-        if (o.plan != p || o.plan_gen != p->gen || o.rlc != rlc || o.count + n > o.cap)
-            if (int rcf = co_flush(w)) return rcf;
+    // the open group of this plan and mode (a workspace that serves several plans keeps one group per plan open: calls that
+    // alternate between two plans would otherwise run every group at one call)
+    int found = -1;
+    for (uint32_t q : w->co_open) {
+        const Coalesce &o = *w->co[q];
+        if (o.plan == p && o.plan_gen == p->gen && o.rlc == rlc) { found = (int)q; break; }
     }
-    if (w->co_lane < 0) {
+    if (found >= 0 && w->co[found]->count + n > w->co[found]->cap) {
+        if (int rcf = co_flush_lane(w, (uint32_t)found)) return rcf;
+        found = -1;
+    }
+    if (found < 0) {
+        if (w->co_open.size() >= 4)
+            if (int rcf = co_flush_lane(w, w->co_open.front())) return rcf;
         int sm = 1;
         const uint32_t L = laned_depth(w, w->chunk, false, &sm);
-        const uint32_t l = (uint32_t)(w->next_lane++ % L);
+        uint32_t l = (uint32_t)(w->next_lane++ % L);
+        for (uint32_t tries = 0; tries < L; tries++) {          // (a lane whose group is still open is not a place for another)
+            bool taken = false;
+            for (uint32_t q : w->co_open) taken = taken || q == l;
+            if (!taken) break;
+            l = (uint32_t)(w->next_lane++ % L);
+        }
         int rc = ensure_lane(w, l);
         if (rc) return rc;
         if ((rc = co_ensure(w, l, p))) return rc;
@@ -1686,9 +1716,10 @@ static int coalesce_call(const h2v_plan *p, const h2v_batch *b, uint8_t *accept,
         c.rlc = rlc;
         for (int k = 0; k < 8; k++) c.seed[k] = rlc && seed ? seed[k] : 0;
         HIPCHK(hipMemsetAsync(c.off, 0, 8, w->lane_st[l]));     // off[0] = 0: behind the previous group's pipeline on this stream
-        w->co_lane = (int)l;
+        w->co_open.push_back(l);
+        found = (int)l;
     }
-    const uint32_t l = (uint32_t)w->co_lane;
+    const uint32_t l = (uint32_t)found;
     Coalesce &c = *w->co[l];
     hipStream_t ls = w->lane_st[l];
     HIPCHK(hipEventRecord(w->ev_fork, st));
@@ -1707,7 +1738,7 @@ static int coalesce_call(const h2v_plan *p, const h2v_batch *b, uint8_t *accept,
     c.parts.push_back({accept, status, c.count, n, slot});
     c.count += n;
     w->lane_busy[l] = true;              // (h2v_workspace_join must look at this lane; its event is recorded by the flush)
-    if (c.count >= c.cap) return co_flush(w);
+    if (c.count >= c.cap) return co_flush_lane(w, l);
     return H2V_OK;
 }
 

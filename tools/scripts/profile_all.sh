@@ -13,7 +13,7 @@ bash $S ${P}_secp256k1_512 secp256k1 512 per-proof >> gpurun_out/pa_${P}.log 2>&
 bash $S ${P}_sha256_128 sha256 128 per-proof >> gpurun_out/pa_${P}.log 2>&1 || exit 1
 bash $S ${P}_secp256k1_64 secp256k1 64 per-proof >> gpurun_out/pa_${P}.log 2>&1 || exit 1
 for cfg in "sha256 512" "sha256 256" "secp256k1 256" "secp256k1 128"; do set -- $cfg
-  timeout -k 10 300 python bench.py --workload $1 --batch $2 --no-cpu-baseline --no-rlc-secondary --no-alone > gpurun_out/b_${P}_$1_$2.log 2>&1 || exit 1
+  timeout -k 10 300 python bench.py --workload $1 --batch $2 --no-cpu-baseline --no-rlc-secondary --no-alone --steps $((240 * 4096 / $2 / 4)) > gpurun_out/b_${P}_$1_$2.log 2>&1 || exit 1   # (60 launches of 4096 gathered proofs)
   grep "^{" gpurun_out/b_${P}_$1_$2.log | tail -1 > gpurun_out/${P}_$1_$2_sweep_bench.json
 done
 for f in gpurun_out/${P}*_bench.json; do python - "$f" <<'PY'
