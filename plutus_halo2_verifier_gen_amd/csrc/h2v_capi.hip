@@ -1697,10 +1697,13 @@ static int coalesce_call(const h2v_plan *p, const h2v_batch *b, uint8_t *accept,
         found = -1;
     }
     if (found < 0) {
-        if (w->co_open.size() >= 4)
-            if (int rcf = co_flush_lane(w, w->co_open.front())) return rcf;
         int sm = 1;
         const uint32_t L = laned_depth(w, w->chunk, false, &sm);
+        // at most four groups open, and never as many as there are lanes to put them on (a workspace of three lanes that served
+        // five plans opened a group on a lane that still held one: its calls were never run - found by tests/soak.py)
+        const size_t max_open = L < 4 ? L : 4;
+        while (w->co_open.size() >= max_open)
+            if (int rcf = co_flush_lane(w, w->co_open.front())) return rcf;
         uint32_t l = (uint32_t)(w->next_lane++ % L);
         for (uint32_t tries = 0; tries < L; tries++) {          // (a lane whose group is still open is not a place for another)
             bool taken = false;

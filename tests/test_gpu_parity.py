@@ -1013,6 +1013,36 @@ def test_small_calls_are_coalesced(be, circuits):
         for w in wss.values():
             w.close()
     assert results[0] == results[-1]
+    # more plans and modes than lanes: a workspace of TWO lanes serving three plans, per proof and RLC alternating - six kinds of
+    # group, at most two of them open at a time (the soak met a three-lane workspace whose fifth group was opened on a lane that
+    # still held one: the calls of the overwritten group were never run)
+    pools["lookup_table"] = (circuits["lookup_table"][0], circuits["lookup_table"][2], circuits["lookup_table"][3],
+                             synth.with_rejects(circuits["lookup_table"][2], synth.forge_batch(circuits["lookup_table"][0], circuits["lookup_table"][1], 120, seed=83,
+                                                                                            plan=circuits["lookup_table"][2], workers=8),
+                                                circuits["lookup_table"][0].n_public_inputs, fraction=0.15, seed=84, kinds=list(synth.CORRUPTIONS)))
+    two = be.Workspace.multi([pools[k][2] for k in pools], 512, lanes=2)
+    two.defer_joins(True)
+    held = []
+    for k in range(18):
+        name = list(pools)[k % 3]
+        vk, pl, dp, pool = pools[name]
+        b = _permute(pool, [rng.randrange(pool.n) for _ in range(40 + k)], vk.n_public_inputs)
+        dpr = torch.frombuffer(bytearray(b.proofs), dtype=torch.uint8).to(dev)
+        dof = torch.tensor(b.proof_off, dtype=torch.int64).to(dev)
+        din = torch.frombuffer(bytearray(b.instances), dtype=torch.uint8).to(dev) if b.instances else None
+        dci = torch.frombuffer(bytearray(b.committed), dtype=torch.uint8).to(dev) if b.committed else None
+        acc = torch.full((b.n,), 7, dtype=torch.uint8, device=dev)
+        args = (b.n, dpr.data_ptr(), dof.data_ptr(), din.data_ptr() if din is not None else None, dci.data_ptr() if dci is not None else None, acc.data_ptr(), None)
+        if (k // 3) % 2:
+            dp.verify_batch_rlc_device(*args, ws=two, stream=s.cuda_stream, seed=bytes(range(32)))
+        else:
+            dp.verify_batch_device(*args, ws=two, stream=s.cuda_stream)
+        held.append((name, b, acc, (dpr, dof, din, dci)))
+    two.join(s.cuda_stream)
+    s.synchronize()
+    for name, b, acc, _keep in held:
+        assert acc.cpu().tolist() == b.expected, ("two lanes, three plans", name, b.n)
+    two.close()
 
 
 def test_threads_sharing_plans_and_the_stream_pool(be):
