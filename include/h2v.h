@@ -162,7 +162,9 @@ int h2v_workspace_create_multi(const h2v_plan *const *plans, uint32_t n_plans, u
  * a call reports its share of the group's launch.  RLC calls are gathered among themselves: ONE batch check over the group, with
  * the coefficients of its first call's seed; accept[] stays per proof and exact, h2v_workspace_rlc_result of each call reports the
  * GROUP's batch verdict (a rejecting proof of a neighbouring call fails the check for all of them) and the call's share of the
- * times.  H2V_OPT_COALESCE = -1 switches it off for a workspace. */
+ * times.  A workspace keeps one group open per plan and mode (at most four, and fewer than it has lanes).  Host-buffer calls
+ * (h2v_verify_batch, _submit) are not gathered: a host that collects small batches concatenates them itself.
+ * H2V_OPT_COALESCE = -1 switches it off for a workspace. */
 int h2v_workspace_defer_joins(h2v_workspace *ws, int defer);
 int h2v_workspace_join(h2v_workspace *ws, void *stream);
 /* Launch-shape options of a workspace (round 3: what used to be reachable through environment variables only; results never
