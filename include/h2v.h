@@ -162,7 +162,9 @@ int h2v_workspace_create_multi(const h2v_plan *const *plans, uint32_t n_plans, u
  * a call reports its share of the group's launch.  RLC calls are gathered among themselves: ONE batch check over the group, with
  * the coefficients of its first call's seed; accept[] stays per proof and exact, h2v_workspace_rlc_result of each call reports the
  * GROUP's batch verdict (a rejecting proof of a neighbouring call fails the check for all of them) and the call's share of the
- * times.  A workspace keeps one group open per plan and mode (at most four, and fewer than it has lanes).  Host-buffer calls
+ * times.  An open group does not start by itself: a caller that stops submitting for a while and wants the GPU to get on with
+ * what it has calls h2v_workspace_join(ws, stream) with a stream of its own - that runs the open groups and does not block the
+ * host.  A workspace keeps one group open per plan and mode (at most four, and fewer than it has lanes).  Host-buffer calls
  * (h2v_verify_batch, _submit) are not gathered: a host that collects small batches concatenates them itself.
  * H2V_OPT_COALESCE = -1 switches it off for a workspace. */
 int h2v_workspace_defer_joins(h2v_workspace *ws, int defer);
