@@ -1736,7 +1736,7 @@ static int coalesce_call(const h2v_plan *p, const h2v_batch *b, uint8_t *accept,
     const int slot = (int)(w->calls % h2v_workspace::RING);
     w->calls++;
     w->lring_chunks[slot] = 1; w->lring_first[slot] = l; w->lring_mod[slot] = w->n_lanes; w->lring_rlc[slot] = rlc ? 1 : 0; w->lring_routed[slot] = 0;
-    w->lring_co[slot] = 1; w->lring_share[slot] = 1.0f;
+    w->lring_co[slot] = 1; w->lring_share[slot] = 0.0f;      // (0: its group has not run yet)
     for (uint32_t q = 0; q < w->n_lanes; q++) { w->lring_calls[slot][q] = 0; w->lring_rlc_calls[slot][q] = 0; w->lring_rlc_obj[slot][q] = nullptr; }   // (filled in by the flush)
     c.parts.push_back({accept, status, c.count, n, slot});
     c.count += n;
@@ -1920,6 +1920,7 @@ extern "C" int h2v_workspace_timings(h2v_workspace *w, uint32_t calls_back, h2v_
     const int slot = (int)((w->calls - 1 - calls_back) % h2v_workspace::RING);
     if (w->n_lanes) {
         // sums over the call's chunks (h2v_timings: `launches` = chunks); total_ms = first chunk's start .. the last end
+        if (w->lring_co[slot] && w->lring_share[slot] == 0.0f) return fail(H2V_E_ARG, "that call is in a group of coalesced calls that has not run yet: h2v_workspace_join first");
         if (w->lring_rlc[slot] && !w->lring_routed[slot]) return fail(H2V_E_ARG, "that call ran in RLC mode: h2v_workspace_rlc_result");
         memset(tm, 0, sizeof *tm);
         const uint32_t nch = w->lring_chunks[slot];
@@ -2705,6 +2706,7 @@ extern "C" int h2v_workspace_rlc_result(h2v_workspace *w, uint32_t calls_back, u
         if (w->calls == 0 || calls_back >= h2v_workspace::RING || calls_back >= w->calls) return fail(H2V_E_ARG, "no such call in the event ring");
         const int slot = (int)((w->calls - 1 - calls_back) % h2v_workspace::RING);
         if (!w->lring_rlc[slot]) return fail(H2V_E_ARG, "that call did not run in RLC mode");
+        if (w->lring_co[slot] && w->lring_share[slot] == 0.0f) return fail(H2V_E_ARG, "that call is in a group of coalesced calls that has not run yet: h2v_workspace_join first");
         if (w->lring_routed[slot]) {       // routed to the per-proof kernels: no batch check ran (h2v_workspace_timings has no record either)
             if (batch_accepted) *batch_accepted = 0;
             if (tm) memset(tm, 0, sizeof *tm);
