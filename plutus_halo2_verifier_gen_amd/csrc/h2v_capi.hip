@@ -1555,7 +1555,7 @@ static int run_laned(const h2v_plan *p, uint32_t n, const uint8_t *proofs, const
     return H2V_OK;
 }
 // ---- coalescing of small calls (round 4; VERDICT r3 #6: "let lanes pack units of several small calls of the same plan into one
-// launch per kernel").  A device-resident per-proof call of at most HALF a chunk on a laned workspace with deferred joins is not
+// launch per kernel").  A device-resident call (per proof, or RLC among RLC calls) of at most HALF a chunk on a laned workspace with deferred joins is not
 // launched by itself: its proofs are gathered (h2v_coalesce.hpp, on a lane's stream, behind whatever the caller's stream held at
 // the time of the call - so the caller's buffers are read at once, as always) behind those of the calls before it, and the
 // pipeline runs ONCE over the group - when the next call would not fit, when a call of another plan or kind arrives, or at
